@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixels/s of embed + extract + similarity on a batch of 4K frames.
+
+One "step" = one pass of the whole hot path over the rank's batch of synthetic frames:
+    ssw_batch_embed   (Writer::new + mark:            rgb->yiq, DCT2, top-k, embed, DCT3, yiq->rgb)
+    ssw_batch_extract (Reader::base + derived + extract + Tester::similarity: 2x(rgb->y, DCT2), top-k, ...)
+Inputs (frames, marks) are resident in HBM before the timed region starts.  Work shards by frame
+across ranks (one process per GPU, no data-path collective: frames are independent) -> weak scaling.
+
+Contract: python bench.py --gpus N --steps K --warmup W   prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X spec sheet: FP64 matrix
+PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
+
+
+def shard_frames(total_frames: int, world: int, rank: int):
+    """Contiguous block split of SURVEY 8(e): frame b -> rank floor(b * world / total)."""
+    lo = (rank * total_frames) // world
+    hi = ((rank + 1) * total_frames) // world
+    return lo, hi
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="frames per GPU (configs[3]: 2048 frames / 8 GPUs)")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--chunk", type=int, default=16, help="frames per internal pass (workspace = 4 planes x chunk)")
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import spread_spectrum_watermarking_amd as wm
+    from spread_spectrum_watermarking_amd import _lib as L
+    from spread_spectrum_watermarking_amd.api import check
+
+    lib = L.load()
+    ctx = wm.Context(local_rank)
+    ctx.set_chunk_frames(args.chunk)
+    W, H, K, B = args.width, args.height, args.k, args.batch
+    precision = L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32
+    cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, precision)
+
+    # ---- inputs resident in HBM ------------------------------------------------------------------
+    first_frame = rank * B                       # global frame index of this rank's shard (weak scaling)
+    rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
+    rgb_out = torch.empty_like(rgb)
+    gen = torch.Generator().manual_seed(args.seed * 1000003 + rank)
+    marks_host = torch.randn((B, K), generator=gen, dtype=torch.float32)
+    marks = marks_host.to(dev)
+    extracted = torch.zeros((B, K), dtype=torch.float32, device=dev)
+    sims = torch.zeros((B,), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    check(lib.ssw_synth_frames(ctx.handle, args.seed, first_frame, B, W, H, rgb.data_ptr()), "ssw_synth_frames")
+    ctx.synchronize()
+
+    def step():
+        check(lib.ssw_batch_embed(ctx.handle, C.byref(cfg), rgb.data_ptr(), B, W, H, marks.data_ptr(), K,
+                                  rgb_out.data_ptr(), None, None), "ssw_batch_embed")
+        check(lib.ssw_batch_extract(ctx.handle, C.byref(cfg), rgb.data_ptr(), rgb_out.data_ptr(), B, W, H, K,
+                                    extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.enable_timing(True)                      # hipEvent pairs around every kernel on the ctx stream
+    ctx.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    stage = ctx.timing()
+    ctx.enable_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sims_host = sims.cpu().numpy()
+    norms = marks_host.norm(dim=1).numpy()
+    if not np.all(sims_host > 0.9 * norms):
+        raise SystemExit(f"rank {rank}: similarity check failed: min sim/|mark| = {(sims_host / norms).min():.3f}")
+
+    # ---- roofline of the dominant kernel (DCT row-pass GEMM) from the live event timers ------------
+    steps = args.steps
+    n_chunks = (B + args.chunk - 1) // args.chunk
+    transforms_per_step = 4                       # DCT2, DCT3 (embed), DCT2, DCT2 (extract)
+    row_flops_total = 2.0 * B * H * W * W * transforms_per_step * steps
+    col_flops_total = 2.0 * B * W * H * H * transforms_per_step * steps
+    row_ms, row_n = stage["dct_row"]["ms"], max(stage["dct_row"]["launches"], 1)
+    col_ms, col_n = stage["dct_col"]["ms"], max(stage["dct_col"]["launches"], 1)
+    peak = PEAK_F64_MFMA_TFLOPS if args.precision == "f64" else PEAK_F32_MFMA_TFLOPS
+    row_tf = row_flops_total / (row_ms * 1e-3) / 1e12 if row_ms > 0 else 0.0
+    col_tf = col_flops_total / (col_ms * 1e-3) / 1e12 if col_ms > 0 else 0.0
+    px_total = float(B) * W * H * steps
+    def gbs(bytes_per_px, passes, ms):
+        return (bytes_per_px * px_total * passes) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    kernels = {
+        "dct_rows": {"tflops": round(row_tf, 2), "frac_mfma": round(row_tf / peak, 4),
+                     "avg_launch_ms": round(row_ms / row_n, 4), "launches": row_n,
+                     "flop_per_launch": row_flops_total / row_n},
+        "dct_cols": {"tflops": round(col_tf, 2), "frac_mfma": round(col_tf / peak, 4),
+                     "avg_launch_ms": round(col_ms / col_n, 4), "launches": col_n,
+                     "flop_per_launch": col_flops_total / col_n},
+        # algorithmic bytes: writer rgb->yiq 24 B/px + two reader rgb->y 16 B/px = 56 B/px
+        "rgb_to_yiq": {"gbs": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]), 1),
+                       "frac_hbm": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]) / PEAK_HBM_GBS, 4)},
+        "yiq_to_rgb": {"gbs": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]), 1),
+                       "frac_hbm": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]) / PEAK_HBM_GBS, 4)},
+        # top-k: 4 B/px algorithmic, two selections per step (writer + base reader)
+        "select": {"gbs": round(gbs(4.0, 2, stage["select"]["ms"]), 1),
+                   "frac_hbm": round(gbs(4.0, 2, stage["select"]["ms"]) / PEAK_HBM_GBS, 4)},
+    }
+    stage_ms = {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
+
+    result = None
+    if rank == 0:
+        mpix = world * px_total / 1e6
+        result = {
+            "metric": "Mpixels/sec embed+extract (4K batch)",
+            "value": round(mpix / elapsed, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {"workload": f"batch={B}/GPU {W}x{H} f32 frames, {K}-coeff mark, embed+extract+similarity "
+                                   f"(per-GPU shard of configs[3]: batch=2048 3840x2160 across 8 GPUs)",
+                       "frames_per_gpu": B, "width": W, "height": H, "k": K, "alpha": 0.1,
+                       "method": "Option2", "ordering": "Energy", "chunk_frames": args.chunk,
+                       "parallelism": f"frame-sharded x{world}, no collectives"},
+            "roofline": {"bound": "mfma", "kernel": "dct_rows_%s_kernel" % args.precision,
+                         "achieved": round(row_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(row_tf / peak, 4), "traffic": None},
+            "kernels": kernels,
+            "stage_ms_per_step": stage_ms,
+            "sim_mean": round(float(sims_host.mean()), 4),
+        }
+
+    # ---- CPU baseline: the oracle (faithful mode) on a bounded sample, rank 0 at N=1 only ----------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        frame0 = rgb[0].cpu().numpy()
+        mark0 = marks_host[0].numpy()
+        gpu_marked0 = rgb_out[0].cpu().numpy()
+        t0 = time.perf_counter()
+        cpu_marked = O.embed_frame(frame0, mark0, backend=O.BACKEND_F32, full_sort=True)
+        cpu_ext, cpu_sim = O.extract_frame(frame0, cpu_marked, mark0, backend=O.BACKEND_F32, full_sort=True)
+        cpu_s = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(W * H / 1e6 / cpu_s, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": f"1 frame {W}x{H} (frame 0 of the batch), embed+extract+similarity, oracle C restatement: "
+                      f"f32 FFT DCT + full stable sort like the reference, single thread, {cpu_s:.1f} s",
+        }
+        result["parity"] = {"sim_gpu": float(sims_host[0]), "sim_cpu": float(cpu_sim),
+                            "sim_delta": abs(float(sims_host[0]) - float(cpu_sim)),
+                            "marked_frame_max_abs_diff": float(np.abs(gpu_marked0 - cpu_marked).max())}
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,228 @@
+/*
+ * ssw.h -- C ABI of the MI355X-native spread-spectrum watermarking hot path.
+ *
+ * Drop-in boundary for the `yiq -> dct2d -> ordering/top-k -> embed | extract ->
+ * similarity` path of iwanders/spread_spectrum_watermarking.  The reference has
+ * no FFI of its own (it is a pure-Rust crate); each entry point below replaces
+ * the *body* of the reference function it cites (file:line relative to the
+ * reference tree), and INTEGRATION.md shows the Rust `-sys` binding a maintainer
+ * would add.  Plain pointers and sizes only; no exceptions or aborts cross this
+ * boundary -- every call returns an ssw_status.
+ *
+ * Threading: a context is bound to one GPU and must be used by one host thread
+ * at a time (like the reference's `!Send` Writer/Reader).  Multi-GPU = one
+ * context (and one process or thread) per GPU; frames are independent so there
+ * is no collective anywhere.
+ *
+ * Memory: "host" pointers are ordinary CPU memory; "dev" pointers are HIP device
+ * memory on the context's GPU (e.g. from ssw_dev_alloc or a torch tensor's
+ * data_ptr()).  Handles own their device planes; the caller owns all I/O buffers.
+ */
+#ifndef SSW_H
+#define SSW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ssw_status {
+    SSW_OK = 0,
+    SSW_ERR_BAD_ARG = 1,          /* null pointer, unknown enum value                      */
+    SSW_ERR_BAD_DIMS = 2,         /* w*h == 0 or data length != w*h   (src/dct2d.rs:90)     */
+    SSW_ERR_LENGTH_MISMATCH = 3,  /* derived vs base length (src/algorithm.rs:550-552),
+                                     similarity lengths (:697-700)                          */
+    SSW_ERR_K_TOO_LARGE = 4,      /* extraction length >= coefficients (:553-555)           */
+    SSW_ERR_NOT_BASE = 5,         /* derived reader used as base (:507, :530 unwrap)        */
+    SSW_ERR_UNSUPPORTED = 6,      /* Custom(closure) variants cannot cross to the device    */
+    SSW_ERR_CONSUMED = 7,         /* writer already consumed by mark()/result() (:355,:361) */
+    SSW_ERR_HIP = 8,              /* HIP runtime error; see ssw_last_error()                */
+    SSW_ERR_NO_DEVICE = 9,        /* no usable gfx950 device: there is NO CPU fallback      */
+    SSW_ERR_OUT_OF_MEMORY = 10
+} ssw_status;
+
+/* OrderingMethod (src/algorithm.rs:143-152) */
+typedef enum ssw_ordering {
+    SSW_ORDER_ENERGY = 0,
+    SSW_ORDER_ENERGY_ORTHOGONAL = 1,
+    SSW_ORDER_LEGACY = 2,
+    SSW_ORDER_CUSTOM = 3          /* -> SSW_ERR_UNSUPPORTED */
+} ssw_ordering;
+
+/* Insertion / Extraction (src/algorithm.rs:68-77, :115-124) */
+typedef enum ssw_method {
+    SSW_OPTION1 = 1,
+    SSW_OPTION2 = 2,
+    SSW_OPTION3 = 3,
+    SSW_METHOD_CUSTOM = 4         /* -> SSW_ERR_UNSUPPORTED */
+} ssw_method;
+
+/* dct2d::Type (src/dct2d.rs:71-79) */
+typedef enum ssw_dct_type {
+    SSW_DCT2 = 0,
+    SSW_DCT2_ORTHOGONAL = 1,
+    SSW_DCT3 = 2
+} ssw_dct_type;
+
+/* Arithmetic of the DCT basis GEMMs (no counterpart in the reference, which
+   delegates to rustdct's f32 FFT kernels). */
+typedef enum ssw_precision {
+    SSW_PRECISION_F32 = 0,        /* v_mfma_f32_32x32x2_f32: exact-f32 fma chain            */
+    SSW_PRECISION_F64 = 1         /* v_mfma_f64_16x16x4_f64, f64 basis, result rounded to
+                                     f32: "canonical" correctly-rounded transform           */
+} ssw_precision;
+
+/* WriteConfig / ReadConfig (src/algorithm.rs:99-140).  ssw_config_default() is
+   Option2(0.1) + Energy like the reference's Default impls (:104-111, :132-139). */
+typedef struct ssw_config {
+    int32_t ordering;             /* ssw_ordering  */
+    int32_t method;               /* ssw_method    */
+    float alpha;
+    int32_t precision;            /* ssw_precision */
+} ssw_config;
+
+typedef struct ssw_ctx ssw_ctx;
+typedef struct ssw_writer ssw_writer;
+typedef struct ssw_reader ssw_reader;
+
+/* ---- library / context ---------------------------------------------------- */
+const char* ssw_version(void);
+const char* ssw_status_string(int status);
+/* Text of the last failing HIP call on this thread (empty string if none). */
+const char* ssw_last_error(void);
+void ssw_config_default(ssw_config* cfg);
+
+/* One context per GPU.  Fails with SSW_ERR_NO_DEVICE when no HIP device is
+   present -- the library never computes on the CPU. */
+int ssw_ctx_create(int device_id, ssw_ctx** out);
+int ssw_ctx_destroy(ssw_ctx* ctx);
+int ssw_ctx_synchronize(ssw_ctx* ctx);
+/* hipStream_t of the context, as an opaque pointer (for event timing by callers). */
+void* ssw_ctx_stream(ssw_ctx* ctx);
+/* Frames processed per internal pass of the batch entry points (bounds the
+   workspace: 4 planes * chunk).  Default 16. */
+int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
+
+/* Per-stage device timers (hipEvent pairs on the context's stream). */
+typedef enum ssw_stage {
+    SSW_STAGE_RGB_TO_YIQ = 0,     /* rgb -> y,i,q (24 B/px) or rgb -> y (16 B/px)   */
+    SSW_STAGE_DCT_ROW = 1,        /* basis GEMM along the width                     */
+    SSW_STAGE_DCT_COL = 2,        /* basis GEMM along the height                    */
+    SSW_STAGE_SELECT = 3,         /* top-k ordering (radix select + sort)           */
+    SSW_STAGE_EMBED = 4,
+    SSW_STAGE_EXTRACT = 5,
+    SSW_STAGE_SIMILARITY = 6,
+    SSW_STAGE_YIQ_TO_RGB = 7,
+    SSW_STAGE_COUNT = 8
+} ssw_stage;
+int ssw_ctx_enable_timing(ssw_ctx* ctx, int enable);
+int ssw_ctx_reset_timing(ssw_ctx* ctx);
+/* Synchronises, then returns accumulated milliseconds and launch counts per stage
+   (arrays of SSW_STAGE_COUNT). */
+int ssw_ctx_get_timing(ssw_ctx* ctx, double* ms, uint64_t* launches);
+
+/* Device memory helpers for hosts without their own allocator. */
+int ssw_dev_alloc(ssw_ctx* ctx, size_t bytes, void** dev_ptr);
+int ssw_dev_free(ssw_ctx* ctx, void* dev_ptr);
+int ssw_copy_to_dev(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int ssw_copy_to_host(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+
+/* ---- transforms (device-resident, batched) --------------------------------- */
+
+/* From<&Rgb32FImage> for YIQ32FImage, src/yiq.rs:177-186.  rgb: [n][h][w][3] f32.
+   dev_i / dev_q may both be NULL (readers never use them: algorithm.rs:476). */
+int ssw_rgb_to_yiq(ssw_ctx* ctx, const float* dev_rgb, size_t n_frames, size_t w, size_t h,
+                   float* dev_y, float* dev_i, float* dev_q);
+/* From<&YIQ32FImage> for Rgb32FImage, src/yiq.rs:187-197 (clamps to [0,1]). */
+int ssw_yiq_to_rgb(ssw_ctx* ctx, const float* dev_y, const float* dev_i, const float* dev_q,
+                   size_t n_frames, size_t w, size_t h, float* dev_rgb);
+/* dct2d::dct2_2d, src/dct2d.rs:83-219, in place on n_frames contiguous row-major
+   planes.  Same pass order (larger dimension first), same f32 store between the
+   passes, same scaling points. */
+int ssw_dct2d(ssw_ctx* ctx, int dct_type, int precision, size_t n_frames, size_t w, size_t h,
+              float* dev_planes);
+
+/* ---- ordering (src/algorithm.rs:200-280) ----------------------------------- */
+/* First k entries of obtain_indices_by_function (src/algorithm.rs:200-210) for each of
+   n_frames coefficient planes: stable descending order, DC skipped, ties -> lower index first.
+   dev_indices: [n_frames][k] u32.  k <= w*h-1. */
+int ssw_topk_indices(ssw_ctx* ctx, const float* dev_coef, size_t n_frames, size_t w, size_t h,
+                     int ordering, size_t k, uint32_t* dev_indices);
+
+/* ---- embed / extract / similarity on device-resident coefficient planes ---- */
+/* Writer::embed_watermark, src/algorithm.rs:382-410.  marks: [n_frames][n_marks][k]
+   f32 (every mark of length k); indices [n_frames][k]. */
+int ssw_embed_coefficients(ssw_ctx* ctx, float* dev_coef, size_t n_frames, size_t plane_len,
+                           const uint32_t* dev_indices, size_t k, int method, float alpha,
+                           const float* dev_marks, size_t n_marks);
+/* Reader::extract_watermark, src/algorithm.rs:543-562.  out: [n_frames][k]. */
+int ssw_extract_coefficients(ssw_ctx* ctx, const float* dev_base, const float* dev_derived,
+                             size_t n_frames, size_t plane_len, const uint32_t* dev_indices,
+                             size_t k, int method, float alpha, float* dev_out);
+/* Tester::similarity, src/algorithm.rs:696-714, n_pairs independent (extracted,
+   mark) pairs of length k; sequential f32 accumulation order preserved. */
+int ssw_similarity_batch(ssw_ctx* ctx, const float* dev_extracted, const float* dev_marks,
+                         size_t n_pairs, size_t k, float* dev_sims);
+
+/* ---- whole path, batched & device-resident (the bench path) ---------------- */
+/* Writer::new + Writer::mark for n_frames frames (algorithm.rs:295-316, :355-379):
+   rgb -> yiq -> DCT2 -> top-k -> embed -> DCT3 -> rgb.  One mark of length k per
+   frame: dev_marks [n_frames][k].  Optional outputs (may be NULL):
+   dev_coef_out [n_frames][h][w] = Writer::coefficient_image() before embedding,
+   dev_indices_out [n_frames][k]. */
+int ssw_batch_embed(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_rgb, size_t n_frames,
+                    size_t w, size_t h, const float* dev_marks, size_t k, float* dev_rgb_out,
+                    float* dev_coef_out, uint32_t* dev_indices_out);
+/* Reader::base + Reader::derived + extract (+ Tester::similarity when dev_marks
+   is given) for n_frames frame pairs (algorithm.rs:462-562, :696-714).
+   dev_extracted [n_frames][k]; dev_sims [n_frames] (NULL allowed with dev_marks NULL). */
+int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base_rgb,
+                      const float* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
+                      float* dev_extracted, const float* dev_marks, float* dev_sims);
+
+/* ---- single-image handles mirroring the crate's types (host buffers) ------- */
+/* Writer::new(image, config), src/algorithm.rs:295-316.  rgb_hwc: host [h][w][3]
+   f32 (what `into_rgb32f()` yields, :308).  The ordering is computed lazily at
+   embed time, when the mark length is known (only the first k entries are ever
+   consumed, :396). */
+int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
+                      const ssw_config* cfg, ssw_writer** out);
+/* Writer::coefficient_image(), src/algorithm.rs:319-321 -> host [h][w]. */
+int ssw_writer_coefficients(ssw_writer* wr, float* out_plane);
+/* Writer::embed(&mut self, marks), src/algorithm.rs:348-352.  marks[m] has lens[m] floats (host). */
+int ssw_writer_embed(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks);
+/* Writer::result(self), src/algorithm.rs:361-379 -> host [h][w][3]; consumes the writer. */
+int ssw_writer_result(ssw_writer* wr, float* out_rgb_hwc);
+/* Writer::mark(self, marks), src/algorithm.rs:355-358 = embed + result. */
+int ssw_writer_mark(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks,
+                    float* out_rgb_hwc);
+int ssw_writer_destroy(ssw_writer* wr);
+
+/* Reader::base(image, config) when is_base != 0 (src/algorithm.rs:462-464), else
+   Reader::derived / ReaderDerived::new (:453-455, :469-471); cfg may be NULL for a derived reader. */
+int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, int is_base,
+                      const ssw_config* cfg, ssw_reader** out);
+/* Reader::coefficients(), src/algorithm.rs:502-504 -> host [h*w]. */
+int ssw_reader_coefficients(ssw_reader* rd, float* out_plane);
+/* Reader::indices(), src/algorithm.rs:506-508: first k entries (k <= w*h-1) as u64 (`usize`). */
+int ssw_reader_indices(ssw_reader* rd, size_t k, uint64_t* out);
+/* Reader::extract(&self, &derived, &mut [f32]), src/algorithm.rs:529-539. */
+int ssw_reader_extract(ssw_reader* base, ssw_reader* derived, float* out, size_t k);
+int ssw_reader_destroy(ssw_reader* rd);
+
+/* Tester::new(extracted).similarity(mark), src/algorithm.rs:689-714 (host buffers, computed on the GPU). */
+int ssw_similarity(ssw_ctx* ctx, const float* extracted, size_t n_extracted,
+                   const float* mark, size_t n_mark, float* out_similarity);
+
+/* ---- synthetic input (bench / parity plumbing, not in the reference) ------- */
+/* Deterministic multi-octave value-noise frames, bit-identical to the oracle's
+   generator: frame index = first_frame + i.  dev_rgb: [n_frames][h][w][3]. */
+int ssw_synth_frames(ssw_ctx* ctx, uint32_t seed, uint32_t first_frame, size_t n_frames,
+                     size_t w, size_t h, float* dev_rgb);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSW_H */

@@ -1,0 +1,376 @@
+"""Host-side mirror of the crate's public surface (lib.rs:81-85) over the C ABI.
+
+Same names, argument meaning and error behaviour as the Rust reference
+(file:line relative to the reference tree):
+
+  Writer / WriteConfig / Insertion        src/algorithm.rs:68-112, :285-433
+  Reader / ReaderDerived / ReadConfig      src/algorithm.rs:114-140, :435-594
+  OrderingMethod                           src/algorithm.rs:142-191
+  MarkBuf (Mark)                           src/algorithm.rs:596-666
+  Tester / Similarity                      src/algorithm.rs:668-715
+
+Images are numpy arrays [H, W, 3]: float32 in [0, 1] (what `into_rgb32f()` yields,
+algorithm.rs:308) or uint8 (converted with v / 255 like the image crate does).
+Where the reference panics, an SswError is raised.  All arithmetic runs on the
+GPU through libssw_hip.so; there is no CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import SswError, check
+
+
+# ---- context ---------------------------------------------------------------------------------
+class Context:
+    """One per GPU (include/ssw.h: ssw_ctx).  Not thread-safe, like the reference's !Send types."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = L.load()
+        h = C.c_void_p()
+        check(self._lib.ssw_ctx_create(device_id, C.byref(h)), "ssw_ctx_create")
+        self.handle = h
+        self.device_id = device_id
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.ssw_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(self._lib.ssw_ctx_synchronize(self.handle), "ssw_ctx_synchronize")
+
+    def set_chunk_frames(self, n: int):
+        check(self._lib.ssw_ctx_set_chunk_frames(self.handle, n), "ssw_ctx_set_chunk_frames")
+
+    def enable_timing(self, on: bool = True):
+        check(self._lib.ssw_ctx_enable_timing(self.handle, int(on)), "ssw_ctx_enable_timing")
+
+    def reset_timing(self):
+        check(self._lib.ssw_ctx_reset_timing(self.handle), "ssw_ctx_reset_timing")
+
+    def timing(self) -> dict:
+        ms = (C.c_double * len(L.STAGES))()
+        n = (C.c_uint64 * len(L.STAGES))()
+        check(self._lib.ssw_ctx_get_timing(self.handle, ms, n), "ssw_ctx_get_timing")
+        return {s: {"ms": ms[i], "launches": int(n[i])} for i, s in enumerate(L.STAGES)}
+
+    # device memory for hosts without their own allocator (tests; the bench uses torch tensors)
+    def alloc(self, nbytes: int) -> "DeviceBuffer":
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, array: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(array)
+        buf = DeviceBuffer(self, a.nbytes)
+        check(self._lib.ssw_copy_to_dev(self.handle, buf.ptr, a.ctypes.data, a.nbytes), "ssw_copy_to_dev")
+        return buf
+
+
+class DeviceBuffer:
+    def __init__(self, ctx: Context, nbytes: int):
+        self.ctx, self.nbytes = ctx, nbytes
+        p = C.c_void_p()
+        check(ctx._lib.ssw_dev_alloc(ctx.handle, nbytes, C.byref(p)), "ssw_dev_alloc")
+        self.ptr = p
+
+    def to_host(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(self.ctx._lib.ssw_copy_to_host(self.ctx.handle, out.ctypes.data, self.ptr, out.nbytes), "ssw_copy_to_host")
+        return out
+
+    def free(self):
+        if self.ptr and self.ctx.handle:
+            self.ctx._lib.ssw_dev_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+_default_ctx: Optional[Context] = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None or _default_ctx.handle is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+# ---- configuration enums (algorithm.rs:68-77, :115-124, :143-152) ---------------------------
+@dataclass(frozen=True)
+class _Method:
+    tag: int
+    alpha: float = 0.0
+    function: Optional[Callable] = None
+
+
+class Insertion:
+    """x' = x + a w | x (1 + a w) | x exp(a w) | custom closure (algorithm.rs:68-77)."""
+    @staticmethod
+    def Option1(alpha: float): return _Method(L.OPTION1, float(alpha))
+    @staticmethod
+    def Option2(alpha: float): return _Method(L.OPTION2, float(alpha))
+    @staticmethod
+    def Option3(alpha: float): return _Method(L.OPTION3, float(alpha))
+    @staticmethod
+    def Custom(function: Callable): return _Method(L.METHOD_CUSTOM, 0.0, function)
+
+
+Extraction = Insertion      # same variants, inverse functions (algorithm.rs:115-124)
+
+
+@dataclass(frozen=True)
+class _Ordering:
+    tag: int
+    function: Optional[Callable] = None
+
+
+class OrderingMethod:
+    Energy = _Ordering(L.ORDER_ENERGY)
+    EnergyOrthogonal = _Ordering(L.ORDER_ENERGY_ORTHOGONAL)
+    Legacy = _Ordering(L.ORDER_LEGACY)
+    @staticmethod
+    def Custom(function: Callable): return _Ordering(L.ORDER_CUSTOM, function)
+
+
+class Precision:
+    F32 = L.PRECISION_F32      # v_mfma_f32_32x32x2_f32 basis GEMMs
+    F64 = L.PRECISION_F64      # v_mfma_f64_16x16x4_f64, correctly rounded ("canonical")
+
+
+@dataclass
+class WriteConfig:
+    """algorithm.rs:99-112; default Option2(0.1) + Energy."""
+    insertion: _Method = field(default_factory=lambda: Insertion.Option2(0.1))
+    ordering: _Ordering = OrderingMethod.Energy
+    precision: int = Precision.F32
+
+    @staticmethod
+    def default(): return WriteConfig()
+
+    def _c(self) -> L.Config:
+        return L.Config(self.ordering.tag, self.insertion.tag, self.insertion.alpha, self.precision)
+
+
+@dataclass
+class ReadConfig:
+    """algorithm.rs:127-140; default Option2(0.1) + Energy."""
+    extraction: _Method = field(default_factory=lambda: Extraction.Option2(0.1))
+    ordering: _Ordering = OrderingMethod.Energy
+    precision: int = Precision.F32
+
+    @staticmethod
+    def default(): return ReadConfig()
+
+    def _c(self) -> L.Config:
+        return L.Config(self.ordering.tag, self.extraction.tag, self.extraction.alpha, self.precision)
+
+
+def _as_rgb32f(image) -> np.ndarray:
+    """`DynamicImage::into_rgb32f()` (algorithm.rs:308, :476): u8 -> v/255, f32 -> as is."""
+    a = np.asarray(image)
+    if a.ndim != 3 or a.shape[2] not in (3, 4):
+        raise ValueError("image must be [H, W, 3] (or RGBA [H, W, 4])")
+    a = a[:, :, :3]
+    if a.dtype == np.uint8:
+        a = a.astype(np.float32) / np.float32(255)
+    elif a.dtype == np.uint16:
+        a = a.astype(np.float32) / np.float32(65535)
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---- marks (algorithm.rs:596-666) --------------------------------------------------------------
+class MarkBuf:
+    def __init__(self, data: Optional[Sequence[float]] = None):
+        self._data = np.zeros(0, np.float32) if data is None else np.array(data, np.float32).ravel().copy()
+
+    @staticmethod
+    def new() -> "MarkBuf":
+        return MarkBuf()
+
+    @staticmethod
+    def generate_normal(length: int) -> "MarkBuf":
+        """algorithm.rs:619-626: StandardNormal from a thread-local, non-deterministic RNG (host side)."""
+        return MarkBuf(np.random.default_rng().standard_normal(length).astype(np.float32))
+
+    @staticmethod
+    def from_(data) -> "MarkBuf":            # `from` is a Python keyword
+        return MarkBuf(data)
+
+    def data(self) -> np.ndarray:
+        return self._data
+
+    def set_data(self, data):
+        self._data = np.array(data, np.float32).ravel().copy()
+
+    def __len__(self):
+        return self._data.size
+
+
+def _mark_data(m) -> np.ndarray:
+    """The `Mark` trait (algorithm.rs:597-600, :659-666): anything exposing a f32 slice."""
+    if isinstance(m, MarkBuf):
+        return m.data()
+    return np.ascontiguousarray(m, dtype=np.float32).ravel()
+
+
+def _marks_c(marks):
+    arrs = [np.ascontiguousarray(_mark_data(m), dtype=np.float32) for m in marks]
+    ptrs = (C.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+    lens = (C.c_size_t * max(len(arrs), 1))(*[a.size for a in arrs])
+    return arrs, ptrs, lens
+
+
+# ---- Writer (algorithm.rs:285-433) -------------------------------------------------------------
+class Writer:
+    def __init__(self, image, config: Optional[WriteConfig] = None, ctx: Optional[Context] = None):
+        """Writer::new (algorithm.rs:295-316): rgb -> yiq, DCT-II of the Y plane on the GPU."""
+        self._ctx = ctx or default_context()
+        self._lib = self._ctx._lib
+        config = config or WriteConfig.default()
+        rgb = _as_rgb32f(image)
+        self.height, self.width = rgb.shape[:2]
+        h = C.c_void_p()
+        cfg = config._c()
+        check(self._lib.ssw_writer_create(self._ctx.handle, rgb.ctypes.data, self.width, self.height,
+                                          C.byref(cfg), C.byref(h)), "Writer::new")
+        self._h = h
+
+    new = classmethod(lambda cls, image, config=None, ctx=None: cls(image, config, ctx))
+
+    def coefficient_image(self) -> np.ndarray:
+        out = np.empty((self.height, self.width), np.float32)
+        check(self._lib.ssw_writer_coefficients(self._h, out.ctypes.data), "Writer::coefficient_image")
+        return out
+
+    def embed(self, marks):
+        arrs, ptrs, lens = _marks_c(marks)
+        check(self._lib.ssw_writer_embed(self._h, ptrs, lens, len(arrs)), "Writer::embed")
+
+    def result(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 3), np.float32)
+        check(self._lib.ssw_writer_result(self._h, out.ctypes.data), "Writer::result")
+        return out
+
+    def mark(self, marks) -> np.ndarray:
+        arrs, ptrs, lens = _marks_c(marks)
+        out = np.empty((self.height, self.width, 3), np.float32)
+        check(self._lib.ssw_writer_mark(self._h, ptrs, lens, len(arrs), out.ctypes.data), "Writer::mark")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._ctx.handle:
+                self._lib.ssw_writer_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+
+# ---- Reader (algorithm.rs:435-594) -------------------------------------------------------------
+class Reader:
+    def __init__(self, image, is_base: bool, config: Optional[ReadConfig], ctx: Optional[Context] = None):
+        self._ctx = ctx or default_context()
+        self._lib = self._ctx._lib
+        rgb = _as_rgb32f(image)
+        self.height, self.width = rgb.shape[:2]
+        self.is_base = is_base
+        h = C.c_void_p()
+        cfg = config._c() if config is not None else None
+        check(self._lib.ssw_reader_create(self._ctx.handle, rgb.ctypes.data, self.width, self.height, int(is_base),
+                                          C.byref(cfg) if cfg is not None else None, C.byref(h)), "Reader::new_impl")
+        self._h = h
+
+    @staticmethod
+    def base(image, config: Optional[ReadConfig] = None, ctx: Optional[Context] = None) -> "Reader":
+        """Reader::base (algorithm.rs:462-464)."""
+        return Reader(image, True, config or ReadConfig.default(), ctx)
+
+    @staticmethod
+    def derived(image, ctx: Optional[Context] = None, precision: int = Precision.F32) -> "ReaderDerived":
+        """Reader::derived (algorithm.rs:469-471)."""
+        return ReaderDerived(image, ctx, precision)
+
+    def coefficients(self) -> np.ndarray:
+        out = np.empty(self.height * self.width, np.float32)
+        check(self._lib.ssw_reader_coefficients(self._h, out.ctypes.data), "Reader::coefficients")
+        return out
+
+    def indices(self, k: Optional[int] = None) -> np.ndarray:
+        """Reader::indices (algorithm.rs:506-508); `k` limits the list to its first k entries."""
+        n = self.height * self.width - 1
+        k = n if k is None else int(k)
+        out = np.empty(max(k, 0), np.uint64)
+        check(self._lib.ssw_reader_indices(self._h, k, out.ctypes.data), "Reader::indices")
+        return out
+
+    def extract(self, derived: "ReaderDerived", extracted) -> np.ndarray:
+        """Reader::extract (algorithm.rs:529-539).  `extracted` is the output buffer (numpy f32,
+        written in place) or an int length; the filled array is returned."""
+        out = np.empty(int(extracted), np.float32) if isinstance(extracted, (int, np.integer)) else extracted
+        if out.dtype != np.float32 or not out.flags.c_contiguous:
+            raise ValueError("extracted must be a contiguous float32 array")
+        d = derived._reader if isinstance(derived, ReaderDerived) else derived
+        check(self._lib.ssw_reader_extract(self._h, d._h, out.ctypes.data, out.size), "Reader::extract")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._ctx.handle:
+                self._lib.ssw_reader_destroy(self._h)
+            self._h = None
+        except Exception:
+            pass
+
+
+class ReaderDerived:
+    """algorithm.rs:448-456: a Reader that can only be read from."""
+
+    def __init__(self, image, ctx: Optional[Context] = None, precision: int = Precision.F32):
+        cfg = ReadConfig(precision=precision)
+        self._reader = Reader(image, False, cfg, ctx)
+
+    new = classmethod(lambda cls, image, ctx=None, precision=Precision.F32: cls(image, ctx, precision))
+
+    def coefficients(self) -> np.ndarray:
+        return self._reader.coefficients()
+
+
+# ---- Tester (algorithm.rs:668-715) -------------------------------------------------------------
+@dataclass
+class Similarity:
+    similarity: float
+
+    def exceeds_sigma(self, n_sigma: float) -> bool:
+        return self.similarity > n_sigma
+
+
+class Tester:
+    def __init__(self, extracted_watermark, ctx: Optional[Context] = None):
+        self._e = np.ascontiguousarray(extracted_watermark, dtype=np.float32).ravel()
+        self._ctx = ctx or default_context()
+
+    new = classmethod(lambda cls, e, ctx=None: cls(e, ctx))
+
+    def similarity(self, comparison_watermark) -> Similarity:
+        m = np.ascontiguousarray(_mark_data(comparison_watermark), dtype=np.float32)
+        out = C.c_float()
+        check(self._ctx._lib.ssw_similarity(self._ctx.handle, self._e.ctypes.data, self._e.size, m.ctypes.data,
+                                            m.size, C.byref(out)), "Tester::similarity")
+        return Similarity(float(out.value))

@@ -1,0 +1,117 @@
+// Internal declarations shared by the HIP translation units of libssw_hip.so.
+// gfx950 (MI355X / CDNA4) only: wave64, MFMA, 160 KiB LDS per CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/ssw.h"
+
+namespace ssw {
+
+void set_last_error(const std::string& s);
+
+#define SSW_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            ::ssw::set_last_error(std::string(#expr) + ": " + hipGetErrorString(e__));   \
+            return (e__ == hipErrorOutOfMemory) ? SSW_ERR_OUT_OF_MEMORY : SSW_ERR_HIP;   \
+        }                                                                                \
+    } while (0)
+
+#define SSW_TRY(expr)                         \
+    do {                                      \
+        int s__ = (expr);                     \
+        if (s__ != SSW_OK) return s__;        \
+    } while (0)
+
+// ---- launchers implemented in the kernel translation units -----------------
+// All are asynchronous on `st` and return the status of the launch.
+
+// color.hip
+int launch_rgb_to_yiq(hipStream_t st, const float* rgb, size_t npix, float* y, float* i, float* q);
+int launch_yiq_to_rgb(hipStream_t st, const float* y, const float* i, const float* q, size_t npix,
+                      float* rgb);
+int launch_synth(hipStream_t st, uint32_t seed, uint32_t first_frame, size_t n_frames, size_t w,
+                 size_t h, float* rgb);
+
+// dct.hip
+// Basis matrices, layout [out][sum], N x N:
+//   forward: D[k][n] = 2 cos(pi k (2n+1) / 2N)          (rustdct DCT-II x the reference's x2)
+//   inverse: E[n][k] = k == 0 ? 1/4 : cos(pi k (2n+1) / 2N) / 2   (rustdct DCT-III x 1/2)
+int launch_make_basis_f32(hipStream_t st, size_t n, bool inverse, float* out);
+int launch_make_basis_f64(hipStream_t st, size_t n, bool inverse, double* out);
+
+struct Epilogue {
+    int mode;        // 0: store acc; 1: orthogonal scale by output index; 2: multiply by corr
+    float s0, sn;    // mode 1
+    float corr;      // mode 2
+};
+// Row pass: out[r][v] = sum_c in[r][c] * basis[v][c]   for rows = n_frames*h rows of width w.
+int launch_dct_rows(hipStream_t st, int precision, const float* in, float* out, size_t rows, size_t w,
+                    const void* basis, Epilogue ep);
+// Column pass: out[f][u][c] = sum_r basis[u][r] * in[f][r][c].
+int launch_dct_cols(hipStream_t st, int precision, const float* in, float* out, size_t n_frames,
+                    size_t w, size_t h, const void* basis, Epilogue ep);
+
+// select.hip
+struct SelectWorkspace {
+    uint32_t* hist = nullptr;       // [n_frames][2048]
+    uint64_t* state = nullptr;      // [n_frames][4]: prefix, prefix_bits|resolved, need, count
+    uint64_t* cand = nullptr;       // [n_frames][cap]
+    uint32_t* cand_count = nullptr; // [n_frames]
+    size_t frames = 0, cap = 0;
+};
+size_t select_max_k();
+int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, size_t h, int ordering,
+                size_t k, const SelectWorkspace& ws, uint32_t* indices);
+int launch_embed(hipStream_t st, float* coef, size_t n_frames, size_t plane_len,
+                 const uint32_t* indices, size_t idx_stride, const float* marks,
+                 const uint32_t* mark_offsets, const uint32_t* mark_lens, size_t n_marks,
+                 size_t max_len, int method, float alpha);
+int launch_extract(hipStream_t st, const float* base, const float* derived, size_t n_frames,
+                   size_t plane_len, const uint32_t* indices, size_t k, int method, float alpha,
+                   float* out);
+int launch_similarity(hipStream_t st, const float* extracted, const float* marks, size_t n_pairs,
+                      size_t k, float* sims);
+int launch_widen_indices(hipStream_t st, const uint32_t* in, size_t n, uint64_t* out);
+
+}  // namespace ssw
+
+// ---- context ----------------------------------------------------------------
+struct ssw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    size_t chunk_frames = 16;
+
+    // basis cache: (N, inverse, f64) -> device pointer
+    std::map<std::tuple<size_t, bool, bool>, void*> basis;
+
+    // growable scratch
+    struct Buf {
+        void* p = nullptr;
+        size_t bytes = 0;
+    };
+    Buf plane[4];                 // y / i / q / t planes of the current chunk
+    Buf idx;                      // [chunk][k] u32
+    ssw::SelectWorkspace sel;
+    Buf small;                    // misc (mark offsets, sims, ...)
+
+    // timing
+    bool timing = false;
+    double stage_ms[SSW_STAGE_COUNT] = {0};
+    uint64_t stage_launches[SSW_STAGE_COUNT] = {0};
+    struct Pending {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> free_events;
+};

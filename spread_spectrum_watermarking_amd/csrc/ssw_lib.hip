@@ -1,0 +1,724 @@
+// C ABI of libssw_hip.so: context, workspace, stage timers and the orchestration of the
+// reference's call stacks (Writer::new / mark, Reader::base / derived / extract, Tester).
+// See include/ssw.h for the reference file:line each entry point replaces.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "ssw_internal.hpp"
+
+namespace ssw {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& s) { g_last_error = s; }
+}  // namespace ssw
+
+using namespace ssw;
+
+// ---- handles --------------------------------------------------------------------------------
+struct ssw_writer {
+    ssw_ctx* ctx;
+    size_t w, h;
+    ssw_config cfg;
+    float *y = nullptr, *i = nullptr, *q = nullptr;   // device planes; y holds the coefficients
+    bool consumed = false;
+};
+struct ssw_reader {
+    ssw_ctx* ctx;
+    size_t w, h;
+    bool is_base;
+    ssw_config cfg;
+    float* y = nullptr;                               // coefficients
+    uint32_t* idx = nullptr;                          // cached first idx_k indices
+    size_t idx_k = 0;
+};
+
+// ---- small helpers --------------------------------------------------------------------------
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+};
+
+int grow(ssw_ctx::Buf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return SSW_OK;
+    if (b.p) { SSW_HIP_CHECK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    if (bytes == 0) bytes = 16;
+    SSW_HIP_CHECK(hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return SSW_OK;
+}
+
+int grow_select(ssw_ctx* ctx, size_t frames, size_t k) {
+    SelectWorkspace& s = ctx->sel;
+    if (s.frames >= frames && s.cap >= k && s.hist) return SSW_OK;
+    const size_t nf = std::max(frames, s.frames), cap = std::max(k, s.cap);
+    if (s.hist) (void)hipFree(s.hist);
+    if (s.state) (void)hipFree(s.state);
+    if (s.cand) (void)hipFree(s.cand);
+    if (s.cand_count) (void)hipFree(s.cand_count);
+    s = SelectWorkspace();
+    SSW_HIP_CHECK(hipMalloc((void**)&s.hist, nf * 2048 * sizeof(uint32_t)));
+    SSW_HIP_CHECK(hipMalloc((void**)&s.state, nf * 4 * sizeof(uint64_t)));
+    SSW_HIP_CHECK(hipMalloc((void**)&s.cand, nf * cap * sizeof(uint64_t)));
+    SSW_HIP_CHECK(hipMalloc((void**)&s.cand_count, nf * sizeof(uint32_t)));
+    s.frames = nf;
+    s.cap = cap;
+    return SSW_OK;
+}
+
+// Stage timer: records an event pair around a region on the context's stream.
+struct StageTimer {
+    ssw_ctx* ctx;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(ssw_ctx* c, int s) : ctx(c), stage(s) {
+        if (!ctx->timing) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
+            else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e;
+        };
+        a = get(); b = get();
+        if (a) (void)hipEventRecord(a, ctx->stream);
+    }
+    ~StageTimer() {
+        if (!ctx->timing || !a || !b) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->pending.push_back({stage, a, b});
+    }
+};
+
+int flush_timers(ssw_ctx* ctx) {
+    for (auto& p : ctx->pending) {
+        float ms = 0.f;
+        SSW_HIP_CHECK(hipEventSynchronize(p.b));
+        SSW_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        ctx->stage_ms[p.stage] += ms;
+        ctx->stage_launches[p.stage] += 1;
+        ctx->free_events.push_back(p.a);
+        ctx->free_events.push_back(p.b);
+    }
+    ctx->pending.clear();
+    return SSW_OK;
+}
+
+int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, const void** out) {
+    auto key = std::make_tuple(n, inverse, f64);
+    auto it = ctx->basis.find(key);
+    if (it != ctx->basis.end()) { *out = it->second; return SSW_OK; }
+    void* p = nullptr;
+    SSW_HIP_CHECK(hipMalloc(&p, n * n * (f64 ? sizeof(double) : sizeof(float))));
+    int rc = f64 ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
+                 : launch_make_basis_f32(ctx->stream, n, inverse, (float*)p);
+    if (rc != SSW_OK) { (void)hipFree(p); return rc; }
+    ctx->basis[key] = p;
+    *out = p;
+    return SSW_OK;
+}
+
+bool valid_method(int m) { return m == SSW_OPTION1 || m == SSW_OPTION2 || m == SSW_OPTION3; }
+bool valid_ordering(int o) { return o == SSW_ORDER_ENERGY || o == SSW_ORDER_ENERGY_ORTHOGONAL || o == SSW_ORDER_LEGACY; }
+bool valid_precision(int p) { return p == SSW_PRECISION_F32 || p == SSW_PRECISION_F64; }
+
+int check_config(const ssw_config* cfg) {
+    if (!cfg) return SSW_ERR_BAD_ARG;
+    if (cfg->method == SSW_METHOD_CUSTOM || cfg->ordering == SSW_ORDER_CUSTOM) return SSW_ERR_UNSUPPORTED;
+    if (!valid_method(cfg->method) || !valid_ordering(cfg->ordering) || !valid_precision(cfg->precision))
+        return SSW_ERR_BAD_ARG;
+    return SSW_OK;
+}
+
+// dct2d::dct2_2d on n contiguous planes, `data` in place, `tmp` same size scratch.
+int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size_t h, float* data, float* tmp) {
+    const bool inverse = (type == SSW_DCT3);
+    const bool f64 = (precision == SSW_PRECISION_F64);
+    const void *bw = nullptr, *bh = nullptr;
+    SSW_TRY(get_basis(ctx, w, inverse, f64, &bw));
+    SSW_TRY(get_basis(ctx, h, inverse, f64, &bh));
+    const bool rows_first = (w >= h);                                  // src/dct2d.rs:93-98
+    Epilogue plain{0, 0.f, 0.f, 0.f};
+    auto ortho = [&](size_t len) {                                      // src/dct2d.rs:154-155
+        Epilogue e{1, std::sqrt(1.0f / (4.0f * (float)len)), std::sqrt(1.0f / (2.0f * (float)len)), 0.f};
+        return e;
+    };
+    Epilogue last = plain;
+    if (type == SSW_DCT3) { last.mode = 2; last.corr = (float)4 / (float)(w * h); }   // :213-217
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool is_row = (pass == 0) ? rows_first : !rows_first;
+        const float* src = (pass == 0) ? data : tmp;
+        float* dst = (pass == 0) ? tmp : data;
+        Epilogue ep = (type == SSW_DCT2_ORTHOGONAL) ? ortho(is_row ? w : h) : (pass == 1 ? last : plain);
+        if (is_row) {
+            StageTimer t(ctx, SSW_STAGE_DCT_ROW);
+            SSW_TRY(launch_dct_rows(ctx->stream, precision, src, dst, n * h, w, bw, ep));
+        } else {
+            StageTimer t(ctx, SSW_STAGE_DCT_COL);
+            SSW_TRY(launch_dct_cols(ctx->stream, precision, src, dst, n, w, h, bh, ep));
+        }
+    }
+    return SSW_OK;
+}
+
+int topk(ssw_ctx* ctx, const float* coef, size_t n, size_t w, size_t h, int ordering, size_t k, uint32_t* idx) {
+    SSW_TRY(grow_select(ctx, n, k));
+    StageTimer t(ctx, SSW_STAGE_SELECT);
+    return launch_topk(ctx->stream, coef, n, w, h, ordering, k, ctx->sel, idx);
+}
+
+}  // namespace
+
+// ---- library / context ----------------------------------------------------------------------
+extern "C" {
+
+const char* ssw_version(void) { return "ssw-hip 0.1.0 (gfx950)"; }
+
+const char* ssw_status_string(int s) {
+    switch (s) {
+    case SSW_OK: return "ok";
+    case SSW_ERR_BAD_ARG: return "bad argument";
+    case SSW_ERR_BAD_DIMS: return "bad dimensions";
+    case SSW_ERR_LENGTH_MISMATCH: return "Derived coefficient length not equal to base coefficient length.";
+    case SSW_ERR_K_TOO_LARGE: return "Desired extraction length exceeds available coefficients.";
+    case SSW_ERR_NOT_BASE: return "reader was not created as a base reader";
+    case SSW_ERR_UNSUPPORTED: return "unsupported (custom closures cannot run on the device)";
+    case SSW_ERR_CONSUMED: return "writer already consumed";
+    case SSW_ERR_HIP: return "HIP runtime error";
+    case SSW_ERR_NO_DEVICE: return "no HIP device (this library has no CPU path)";
+    case SSW_ERR_OUT_OF_MEMORY: return "out of device memory";
+    default: return "unknown status";
+    }
+}
+
+const char* ssw_last_error(void) { return g_last_error.c_str(); }
+
+void ssw_config_default(ssw_config* cfg) {
+    if (!cfg) return;
+    cfg->ordering = SSW_ORDER_ENERGY;        // src/algorithm.rs:104-111
+    cfg->method = SSW_OPTION2;
+    cfg->alpha = 0.1f;
+    cfg->precision = SSW_PRECISION_F32;
+}
+
+int ssw_ctx_create(int device_id, ssw_ctx** out) {
+    if (!out) return SSW_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        set_last_error("hipGetDeviceCount: no device");
+        return SSW_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= count) return SSW_ERR_BAD_ARG;
+    SSW_HIP_CHECK(hipSetDevice(device_id));
+    ssw_ctx* ctx = new (std::nothrow) ssw_ctx();
+    if (!ctx) return SSW_ERR_OUT_OF_MEMORY;
+    ctx->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; set_last_error(hipGetErrorString(e)); return SSW_ERR_HIP; }
+    *out = ctx;
+    return SSW_OK;
+}
+
+int ssw_ctx_destroy(ssw_ctx* ctx) {
+    if (!ctx) return SSW_OK;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->basis) (void)hipFree(kv.second);
+    for (auto& b : ctx->plane) if (b.p) (void)hipFree(b.p);
+    if (ctx->idx.p) (void)hipFree(ctx->idx.p);
+    if (ctx->small.p) (void)hipFree(ctx->small.p);
+    if (ctx->sel.hist) (void)hipFree(ctx->sel.hist);
+    if (ctx->sel.state) (void)hipFree(ctx->sel.state);
+    if (ctx->sel.cand) (void)hipFree(ctx->sel.cand);
+    if (ctx->sel.cand_count) (void)hipFree(ctx->sel.cand_count);
+    for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SSW_OK;
+}
+
+int ssw_ctx_synchronize(ssw_ctx* ctx) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SSW_OK;
+}
+
+void* ssw_ctx_stream(ssw_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames) {
+    if (!ctx || frames == 0) return SSW_ERR_BAD_ARG;
+    ctx->chunk_frames = frames;
+    return SSW_OK;
+}
+
+int ssw_ctx_enable_timing(ssw_ctx* ctx, int enable) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_TRY(flush_timers(ctx));
+    ctx->timing = enable != 0;
+    return SSW_OK;
+}
+
+int ssw_ctx_reset_timing(ssw_ctx* ctx) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_TRY(flush_timers(ctx));
+    for (int s = 0; s < SSW_STAGE_COUNT; ++s) { ctx->stage_ms[s] = 0; ctx->stage_launches[s] = 0; }
+    return SSW_OK;
+}
+
+int ssw_ctx_get_timing(ssw_ctx* ctx, double* ms, uint64_t* launches) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_TRY(flush_timers(ctx));
+    for (int s = 0; s < SSW_STAGE_COUNT; ++s) {
+        if (ms) ms[s] = ctx->stage_ms[s];
+        if (launches) launches[s] = ctx->stage_launches[s];
+    }
+    return SSW_OK;
+}
+
+int ssw_dev_alloc(ssw_ctx* ctx, size_t bytes, void** dev_ptr) {
+    if (!ctx || !dev_ptr) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_HIP_CHECK(hipMalloc(dev_ptr, bytes ? bytes : 16));
+    return SSW_OK;
+}
+int ssw_dev_free(ssw_ctx* ctx, void* dev_ptr) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (dev_ptr) SSW_HIP_CHECK(hipFree(dev_ptr));
+    return SSW_OK;
+}
+int ssw_copy_to_dev(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+    if (!ctx || (bytes && (!dev_dst || !host_src))) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SSW_OK;
+}
+int ssw_copy_to_host(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!ctx || (bytes && (!host_dst || !dev_src))) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SSW_OK;
+}
+
+// ---- transforms -----------------------------------------------------------------------------
+int ssw_rgb_to_yiq(ssw_ctx* ctx, const float* dev_rgb, size_t n_frames, size_t w, size_t h,
+                   float* dev_y, float* dev_i, float* dev_q) {
+    if (!ctx || !dev_rgb || !dev_y || ((dev_i == nullptr) != (dev_q == nullptr))) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
+    return launch_rgb_to_yiq(ctx->stream, dev_rgb, n_frames * w * h, dev_y, dev_i, dev_q);
+}
+
+int ssw_yiq_to_rgb(ssw_ctx* ctx, const float* dev_y, const float* dev_i, const float* dev_q,
+                   size_t n_frames, size_t w, size_t h, float* dev_rgb) {
+    if (!ctx || !dev_rgb || !dev_y || !dev_i || !dev_q) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB);
+    return launch_yiq_to_rgb(ctx->stream, dev_y, dev_i, dev_q, n_frames * w * h, dev_rgb);
+}
+
+int ssw_dct2d(ssw_ctx* ctx, int dct_type, int precision, size_t n_frames, size_t w, size_t h,
+              float* dev_planes) {
+    if (!ctx || !dev_planes) return SSW_ERR_BAD_ARG;
+    if (dct_type < SSW_DCT2 || dct_type > SSW_DCT3 || !valid_precision(precision)) return SSW_ERR_BAD_ARG;
+    if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
+    DeviceGuard g(ctx->device);
+    const size_t chunk = std::min(std::max<size_t>(ctx->chunk_frames, 1), std::max<size_t>(n_frames, 1));
+    SSW_TRY(grow(ctx->plane[3], chunk * w * h * sizeof(float)));
+    for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const size_t n = std::min(chunk, n_frames - f0);
+        SSW_TRY(dct2d_planes(ctx, dct_type, precision, n, w, h, dev_planes + f0 * w * h, (float*)ctx->plane[3].p));
+    }
+    return SSW_OK;
+}
+
+int ssw_topk_indices(ssw_ctx* ctx, const float* dev_coef, size_t n_frames, size_t w, size_t h,
+                     int ordering, size_t k, uint32_t* dev_indices) {
+    if (!ctx || !dev_coef || !dev_indices) return SSW_ERR_BAD_ARG;
+    if (ordering == SSW_ORDER_CUSTOM) return SSW_ERR_UNSUPPORTED;
+    if (!valid_ordering(ordering)) return SSW_ERR_BAD_ARG;
+    if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
+    if (k > w * h - 1) return SSW_ERR_K_TOO_LARGE;
+    DeviceGuard g(ctx->device);
+    return topk(ctx, dev_coef, n_frames, w, h, ordering, k, dev_indices);
+}
+
+int ssw_embed_coefficients(ssw_ctx* ctx, float* dev_coef, size_t n_frames, size_t plane_len,
+                           const uint32_t* dev_indices, size_t k, int method, float alpha,
+                           const float* dev_marks, size_t n_marks) {
+    if (!ctx || !dev_coef || !dev_indices || !dev_marks) return SSW_ERR_BAD_ARG;
+    if (method == SSW_METHOD_CUSTOM) return SSW_ERR_UNSUPPORTED;
+    if (!valid_method(method)) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    StageTimer t(ctx, SSW_STAGE_EMBED);
+    return launch_embed(ctx->stream, dev_coef, n_frames, plane_len, dev_indices, k, dev_marks, nullptr,
+                        nullptr, n_marks, k, method, alpha);
+}
+
+int ssw_extract_coefficients(ssw_ctx* ctx, const float* dev_base, const float* dev_derived,
+                             size_t n_frames, size_t plane_len, const uint32_t* dev_indices,
+                             size_t k, int method, float alpha, float* dev_out) {
+    if (!ctx || !dev_base || !dev_derived || !dev_indices || !dev_out) return SSW_ERR_BAD_ARG;
+    if (method == SSW_METHOD_CUSTOM) return SSW_ERR_UNSUPPORTED;
+    if (!valid_method(method)) return SSW_ERR_BAD_ARG;
+    if (k >= plane_len) return SSW_ERR_K_TOO_LARGE;                   // src/algorithm.rs:553-555
+    DeviceGuard g(ctx->device);
+    StageTimer t(ctx, SSW_STAGE_EXTRACT);
+    return launch_extract(ctx->stream, dev_base, dev_derived, n_frames, plane_len, dev_indices, k, method,
+                          alpha, dev_out);
+}
+
+int ssw_similarity_batch(ssw_ctx* ctx, const float* dev_extracted, const float* dev_marks,
+                         size_t n_pairs, size_t k, float* dev_sims) {
+    if (!ctx || !dev_extracted || !dev_marks || !dev_sims) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    StageTimer t(ctx, SSW_STAGE_SIMILARITY);
+    return launch_similarity(ctx->stream, dev_extracted, dev_marks, n_pairs, k, dev_sims);
+}
+
+// ---- whole path, batched --------------------------------------------------------------------
+int ssw_batch_embed(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_rgb, size_t n_frames,
+                    size_t w, size_t h, const float* dev_marks, size_t k, float* dev_rgb_out,
+                    float* dev_coef_out, uint32_t* dev_indices_out) {
+    if (!ctx || !dev_rgb || !dev_marks || !dev_rgb_out) return SSW_ERR_BAD_ARG;
+    SSW_TRY(check_config(cfg));
+    if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
+    const size_t plane = w * h;
+    const size_t k_eff = std::min(k, plane - 1);                       // zip() truncation, :396
+    if (k_eff > select_max_k()) return SSW_ERR_UNSUPPORTED;
+    DeviceGuard g(ctx->device);
+    const size_t chunk = std::min(std::max<size_t>(ctx->chunk_frames, 1), std::max<size_t>(n_frames, 1));
+    for (int p = 0; p < 4; ++p) SSW_TRY(grow(ctx->plane[p], chunk * plane * sizeof(float)));
+    SSW_TRY(grow(ctx->idx, chunk * std::max<size_t>(k_eff, 1) * sizeof(uint32_t)));
+    float* y = (float*)ctx->plane[0].p;
+    float* pi = (float*)ctx->plane[1].p;
+    float* pq = (float*)ctx->plane[2].p;
+    float* tmp = (float*)ctx->plane[3].p;
+    for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const size_t n = std::min(chunk, n_frames - f0);
+        {   // Writer::new: rgb -> yiq (:308), DCT (:313)
+            StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
+            SSW_TRY(launch_rgb_to_yiq(ctx->stream, dev_rgb + f0 * plane * 3, n * plane, y, pi, pq));
+        }
+        SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, y, tmp));
+        if (dev_coef_out)
+            SSW_HIP_CHECK(hipMemcpyAsync(dev_coef_out + f0 * plane, y, n * plane * sizeof(float),
+                                         hipMemcpyDeviceToDevice, ctx->stream));
+        uint32_t* idx = dev_indices_out ? dev_indices_out + f0 * k_eff : (uint32_t*)ctx->idx.p;
+        if (k_eff > 0) {
+            SSW_TRY(topk(ctx, y, n, w, h, cfg->ordering, k_eff, idx));          // :314 (first k only)
+            StageTimer t(ctx, SSW_STAGE_EMBED);                                 // :356
+            // marks are [frame][k]; only the first k_eff values of each are used
+            if (k_eff == k) {
+                SSW_TRY(launch_embed(ctx->stream, y, n, plane, idx, k_eff, dev_marks + f0 * k, nullptr, nullptr,
+                                     1, k_eff, cfg->method, cfg->alpha));
+            } else {
+                return SSW_ERR_UNSUPPORTED;   // k > w*h-1 in the batch path: use the Writer handle
+            }
+        }
+        SSW_TRY(dct2d_planes(ctx, SSW_DCT3, cfg->precision, n, w, h, y, tmp));   // :368-374
+        {
+            StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB);                            // :377
+            SSW_TRY(launch_yiq_to_rgb(ctx->stream, y, pi, pq, n * plane, dev_rgb_out + f0 * plane * 3));
+        }
+    }
+    return SSW_OK;
+}
+
+int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base_rgb,
+                      const float* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
+                      float* dev_extracted, const float* dev_marks, float* dev_sims) {
+    if (!ctx || !dev_base_rgb || !dev_derived_rgb || !dev_extracted) return SSW_ERR_BAD_ARG;
+    if ((dev_marks == nullptr) != (dev_sims == nullptr)) return SSW_ERR_BAD_ARG;
+    SSW_TRY(check_config(cfg));
+    if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
+    const size_t plane = w * h;
+    if (k >= plane) return SSW_ERR_K_TOO_LARGE;                        // :553-555
+    if (k > select_max_k()) return SSW_ERR_UNSUPPORTED;
+    DeviceGuard g(ctx->device);
+    const size_t chunk = std::min(std::max<size_t>(ctx->chunk_frames, 1), std::max<size_t>(n_frames, 1));
+    for (int p = 0; p < 3; ++p) SSW_TRY(grow(ctx->plane[p], chunk * plane * sizeof(float)));
+    SSW_TRY(grow(ctx->idx, chunk * std::max<size_t>(k, 1) * sizeof(uint32_t)));
+    float* yb = (float*)ctx->plane[0].p;
+    float* yd = (float*)ctx->plane[1].p;
+    float* tmp = (float*)ctx->plane[2].p;
+    uint32_t* idx = (uint32_t*)ctx->idx.p;
+    for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const size_t n = std::min(chunk, n_frames - f0);
+        {   // Reader::base (:474-480): only the Y plane is ever used by a reader
+            StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
+            SSW_TRY(launch_rgb_to_yiq(ctx->stream, dev_base_rgb + f0 * plane * 3, n * plane, yb, nullptr, nullptr));
+        }
+        SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, yb, tmp));
+        if (k > 0) SSW_TRY(topk(ctx, yb, n, w, h, cfg->ordering, k, idx));      // :493
+        {   // Reader::derived
+            StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
+            SSW_TRY(launch_rgb_to_yiq(ctx->stream, dev_derived_rgb + f0 * plane * 3, n * plane, yd, nullptr, nullptr));
+        }
+        SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, yd, tmp));
+        if (k > 0) {
+            StageTimer t(ctx, SSW_STAGE_EXTRACT);                               // :529-539
+            SSW_TRY(launch_extract(ctx->stream, yb, yd, n, plane, idx, k, cfg->method, cfg->alpha,
+                                   dev_extracted + f0 * k));
+        }
+        if (dev_marks) {
+            StageTimer t(ctx, SSW_STAGE_SIMILARITY);                            // :696-714
+            SSW_TRY(launch_similarity(ctx->stream, dev_extracted + f0 * k, dev_marks + f0 * k, n, k, dev_sims + f0));
+        }
+    }
+    return SSW_OK;
+}
+
+// ---- Writer ---------------------------------------------------------------------------------
+int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
+                      const ssw_config* cfg, ssw_writer** out) {
+    if (!ctx || !rgb_hwc || !out) return SSW_ERR_BAD_ARG;
+    *out = nullptr;
+    SSW_TRY(check_config(cfg));
+    if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
+    DeviceGuard g(ctx->device);
+    const size_t plane = w * h;
+    ssw_writer* wr = new (std::nothrow) ssw_writer();
+    if (!wr) return SSW_ERR_OUT_OF_MEMORY;
+    wr->ctx = ctx; wr->w = w; wr->h = h; wr->cfg = *cfg;
+    auto fail = [&](int rc) { ssw_writer_destroy(wr); return rc; };
+    if (hipMalloc((void**)&wr->y, plane * 4) != hipSuccess || hipMalloc((void**)&wr->i, plane * 4) != hipSuccess ||
+        hipMalloc((void**)&wr->q, plane * 4) != hipSuccess)
+        return fail(SSW_ERR_OUT_OF_MEMORY);
+    int rc = grow(ctx->plane[3], std::max(plane * 3, plane) * sizeof(float));
+    if (rc != SSW_OK) return fail(rc);
+    float* stage = (float*)ctx->plane[3].p;                          // rgb staging, then DCT scratch
+    if (hipMemcpyAsync(stage, rgb_hwc, plane * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(SSW_ERR_HIP);
+    {
+        StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
+        rc = launch_rgb_to_yiq(ctx->stream, stage, plane, wr->y, wr->i, wr->q);          // :308
+    }
+    if (rc != SSW_OK) return fail(rc);
+    rc = dct2d_planes(ctx, SSW_DCT2, cfg->precision, 1, w, h, wr->y, stage);             // :313
+    if (rc != SSW_OK) return fail(rc);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(SSW_ERR_HIP);
+    *out = wr;
+    return SSW_OK;
+}
+
+int ssw_writer_coefficients(ssw_writer* wr, float* out_plane) {
+    if (!wr || !out_plane) return SSW_ERR_BAD_ARG;
+    if (wr->consumed) return SSW_ERR_CONSUMED;
+    return ssw_copy_to_host(wr->ctx, out_plane, wr->y, wr->w * wr->h * sizeof(float));
+}
+
+int ssw_writer_embed(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks) {
+    if (!wr || (n_marks && (!marks || !lens))) return SSW_ERR_BAD_ARG;
+    if (wr->consumed) return SSW_ERR_CONSUMED;
+    ssw_ctx* ctx = wr->ctx;
+    DeviceGuard g(ctx->device);
+    const size_t plane = wr->w * wr->h;
+    if (n_marks == 0) return SSW_OK;
+    // zip(indices, mark) truncates every mark at w*h-1 entries (:396, :402)
+    std::vector<uint32_t> offs(n_marks), lns(n_marks);
+    size_t total = 0, max_len = 0;
+    for (size_t m = 0; m < n_marks; ++m) {
+        if (lens[m] && !marks[m]) return SSW_ERR_BAD_ARG;
+        const size_t len = std::min(lens[m], plane - 1);
+        offs[m] = (uint32_t)total; lns[m] = (uint32_t)len;
+        total += len; max_len = std::max(max_len, len);
+    }
+    if (max_len == 0) return SSW_OK;
+    if (max_len > select_max_k()) return SSW_ERR_UNSUPPORTED;
+    std::vector<float> packed(total);
+    for (size_t m = 0; m < n_marks; ++m)
+        if (lns[m]) std::memcpy(packed.data() + offs[m], marks[m], lns[m] * sizeof(float));
+    const size_t bytes_marks = (total * 4 + 15) / 16 * 16, bytes_tab = (n_marks * 4 + 15) / 16 * 16;
+    SSW_TRY(grow(ctx->small, bytes_marks + 2 * bytes_tab));
+    char* base = (char*)ctx->small.p;
+    SSW_HIP_CHECK(hipMemcpyAsync(base, packed.data(), total * 4, hipMemcpyHostToDevice, ctx->stream));
+    SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks, offs.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
+    SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks + bytes_tab, lns.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
+    SSW_TRY(grow(ctx->idx, max_len * sizeof(uint32_t)));
+    SSW_TRY(topk(ctx, wr->y, 1, wr->w, wr->h, wr->cfg.ordering, max_len, (uint32_t*)ctx->idx.p));   // :314
+    {
+        StageTimer t(ctx, SSW_STAGE_EMBED);
+        SSW_TRY(launch_embed(ctx->stream, wr->y, 1, plane, (uint32_t*)ctx->idx.p, max_len, (const float*)base,
+                             (const uint32_t*)(base + bytes_marks), (const uint32_t*)(base + bytes_marks + bytes_tab),
+                             n_marks, max_len, wr->cfg.method, wr->cfg.alpha));
+    }
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // host staging vectors die here
+    return SSW_OK;
+}
+
+int ssw_writer_result(ssw_writer* wr, float* out_rgb_hwc) {
+    if (!wr || !out_rgb_hwc) return SSW_ERR_BAD_ARG;
+    if (wr->consumed) return SSW_ERR_CONSUMED;
+    ssw_ctx* ctx = wr->ctx;
+    DeviceGuard g(ctx->device);
+    const size_t plane = wr->w * wr->h;
+    SSW_TRY(grow(ctx->plane[3], plane * 3 * sizeof(float)));
+    float* stage = (float*)ctx->plane[3].p;
+    SSW_TRY(dct2d_planes(ctx, SSW_DCT3, wr->cfg.precision, 1, wr->w, wr->h, wr->y, stage));      // :368-374
+    {
+        StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB);
+        SSW_TRY(launch_yiq_to_rgb(ctx->stream, wr->y, wr->i, wr->q, plane, stage));              // :377
+    }
+    SSW_HIP_CHECK(hipMemcpyAsync(out_rgb_hwc, stage, plane * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    wr->consumed = true;                                              // `result(self)` consumes
+    return SSW_OK;
+}
+
+int ssw_writer_mark(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks,
+                    float* out_rgb_hwc) {
+    SSW_TRY(ssw_writer_embed(wr, marks, lens, n_marks));              // :356
+    return ssw_writer_result(wr, out_rgb_hwc);                        // :357
+}
+
+int ssw_writer_destroy(ssw_writer* wr) {
+    if (!wr) return SSW_OK;
+    DeviceGuard g(wr->ctx->device);
+    (void)hipStreamSynchronize(wr->ctx->stream);
+    if (wr->y) (void)hipFree(wr->y);
+    if (wr->i) (void)hipFree(wr->i);
+    if (wr->q) (void)hipFree(wr->q);
+    delete wr;
+    return SSW_OK;
+}
+
+// ---- Reader ---------------------------------------------------------------------------------
+int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, int is_base,
+                      const ssw_config* cfg, ssw_reader** out) {
+    if (!ctx || !rgb_hwc || !out) return SSW_ERR_BAD_ARG;
+    *out = nullptr;
+    ssw_config c;
+    ssw_config_default(&c);
+    if (cfg) c = *cfg;
+    else if (is_base) return SSW_ERR_BAD_ARG;                         // config.unwrap(), :482
+    SSW_TRY(check_config(&c));
+    if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
+    DeviceGuard g(ctx->device);
+    const size_t plane = w * h;
+    ssw_reader* rd = new (std::nothrow) ssw_reader();
+    if (!rd) return SSW_ERR_OUT_OF_MEMORY;
+    rd->ctx = ctx; rd->w = w; rd->h = h; rd->is_base = is_base != 0; rd->cfg = c;
+    auto fail = [&](int rc) { ssw_reader_destroy(rd); return rc; };
+    if (hipMalloc((void**)&rd->y, plane * 4) != hipSuccess) return fail(SSW_ERR_OUT_OF_MEMORY);
+    int rc = grow(ctx->plane[3], plane * 3 * sizeof(float));
+    if (rc != SSW_OK) return fail(rc);
+    float* stage = (float*)ctx->plane[3].p;
+    if (hipMemcpyAsync(stage, rgb_hwc, plane * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail(SSW_ERR_HIP);
+    {
+        StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
+        rc = launch_rgb_to_yiq(ctx->stream, stage, plane, rd->y, nullptr, nullptr);      // :476
+    }
+    if (rc != SSW_OK) return fail(rc);
+    rc = dct2d_planes(ctx, SSW_DCT2, c.precision, 1, w, h, rd->y, stage);                // :480
+    if (rc != SSW_OK) return fail(rc);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(SSW_ERR_HIP);
+    *out = rd;
+    return SSW_OK;
+}
+
+int ssw_reader_coefficients(ssw_reader* rd, float* out_plane) {
+    if (!rd || !out_plane) return SSW_ERR_BAD_ARG;
+    return ssw_copy_to_host(rd->ctx, out_plane, rd->y, rd->w * rd->h * sizeof(float));
+}
+
+static int reader_ensure_indices(ssw_reader* rd, size_t k) {
+    if (!rd->is_base) return SSW_ERR_NOT_BASE;                        // base.unwrap(), :507 / :530
+    if (k > rd->w * rd->h - 1) return SSW_ERR_K_TOO_LARGE;
+    if (k <= rd->idx_k) return SSW_OK;
+    if (k > select_max_k()) return SSW_ERR_UNSUPPORTED;
+    ssw_ctx* ctx = rd->ctx;
+    if (rd->idx) { SSW_HIP_CHECK(hipFree(rd->idx)); rd->idx = nullptr; rd->idx_k = 0; }
+    SSW_HIP_CHECK(hipMalloc((void**)&rd->idx, k * sizeof(uint32_t)));
+    SSW_TRY(topk(ctx, rd->y, 1, rd->w, rd->h, rd->cfg.ordering, k, rd->idx));           // :493
+    rd->idx_k = k;
+    return SSW_OK;
+}
+
+int ssw_reader_indices(ssw_reader* rd, size_t k, uint64_t* out) {
+    if (!rd || (k && !out)) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(rd->ctx->device);
+    if (k == 0) return rd->is_base ? SSW_OK : SSW_ERR_NOT_BASE;
+    SSW_TRY(reader_ensure_indices(rd, k));
+    ssw_ctx* ctx = rd->ctx;
+    SSW_TRY(grow(ctx->small, k * sizeof(uint64_t)));
+    SSW_TRY(launch_widen_indices(ctx->stream, rd->idx, k, (uint64_t*)ctx->small.p));
+    return ssw_copy_to_host(ctx, out, ctx->small.p, k * sizeof(uint64_t));
+}
+
+int ssw_reader_extract(ssw_reader* base, ssw_reader* derived, float* out, size_t k) {
+    if (!base || !derived || (k && !out)) return SSW_ERR_BAD_ARG;
+    if (!base->is_base) return SSW_ERR_NOT_BASE;                                          // :530
+    if (base->ctx != derived->ctx) return SSW_ERR_BAD_ARG;
+    if (derived->w * derived->h != base->w * base->h) return SSW_ERR_LENGTH_MISMATCH;     // :550-552
+    const size_t plane = base->w * base->h;
+    if (k >= plane) return SSW_ERR_K_TOO_LARGE;                                           // :553-555
+    if (k == 0) return SSW_OK;
+    ssw_ctx* ctx = base->ctx;
+    DeviceGuard g(ctx->device);
+    SSW_TRY(reader_ensure_indices(base, k));
+    SSW_TRY(grow(ctx->small, k * sizeof(float)));
+    {
+        StageTimer t(ctx, SSW_STAGE_EXTRACT);
+        // cached list may be longer than k: its first k entries are the first k of the order
+        SSW_TRY(launch_extract(ctx->stream, base->y, derived->y, 1, plane, base->idx, k, base->cfg.method,
+                               base->cfg.alpha, (float*)ctx->small.p));
+    }
+    return ssw_copy_to_host(ctx, out, ctx->small.p, k * sizeof(float));
+}
+
+int ssw_reader_destroy(ssw_reader* rd) {
+    if (!rd) return SSW_OK;
+    DeviceGuard g(rd->ctx->device);
+    (void)hipStreamSynchronize(rd->ctx->stream);
+    if (rd->y) (void)hipFree(rd->y);
+    if (rd->idx) (void)hipFree(rd->idx);
+    delete rd;
+    return SSW_OK;
+}
+
+// ---- Tester ---------------------------------------------------------------------------------
+int ssw_similarity(ssw_ctx* ctx, const float* extracted, size_t n_extracted, const float* mark,
+                   size_t n_mark, float* out_similarity) {
+    if (!ctx || !out_similarity || (n_extracted && !extracted) || (n_mark && !mark)) return SSW_ERR_BAD_ARG;
+    if (n_extracted != n_mark) return SSW_ERR_LENGTH_MISMATCH;                            // :697-700
+    DeviceGuard g(ctx->device);
+    const size_t k = n_extracted;
+    const size_t bytes = (k * 4 + 15) / 16 * 16;
+    SSW_TRY(grow(ctx->small, 2 * bytes + 16));
+    char* base = (char*)ctx->small.p;
+    if (k) {
+        SSW_HIP_CHECK(hipMemcpyAsync(base, extracted, k * 4, hipMemcpyHostToDevice, ctx->stream));
+        SSW_HIP_CHECK(hipMemcpyAsync(base + bytes, mark, k * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    {
+        StageTimer t(ctx, SSW_STAGE_SIMILARITY);
+        SSW_TRY(launch_similarity(ctx->stream, (const float*)base, (const float*)(base + bytes), 1, k,
+                                  (float*)(base + 2 * bytes)));
+    }
+    return ssw_copy_to_host(ctx, out_similarity, base + 2 * bytes, sizeof(float));
+}
+
+// ---- synthetic frames -----------------------------------------------------------------------
+int ssw_synth_frames(ssw_ctx* ctx, uint32_t seed, uint32_t first_frame, size_t n_frames, size_t w,
+                     size_t h, float* dev_rgb) {
+    if (!ctx || !dev_rgb) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    return launch_synth(ctx->stream, seed, first_frame, n_frames, w, h, dev_rgb);
+}
+
+}  // extern "C"

@@ -1,0 +1,424 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north star):
+  * integer / index work and un-fused f32 arithmetic (yiq, ordering, embed, extract Option1/2,
+    similarity): bit-exact.
+  * DCT, f64 ("canonical") precision: >= 99.9 % of coefficients bit-identical to the oracle's
+    correctly rounded transform, the rest within 1 ulp-scale (2e-7 of the plane's AC max).
+  * DCT, f32 MFMA precision: <= 2e-6 of the plane's AC max (the reference's own tests use 1e-4 abs).
+  * extracted marks: <= 1e-5 relative (canonical), similarity delta < 1e-4.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gpu_util as G
+from conftest import f32_to_u8, u8_to_f32
+from oracle import oracle as O
+from spread_spectrum_watermarking_amd import _lib as L
+import spread_spectrum_watermarking_amd as wm
+
+pytestmark = pytest.mark.gpu
+
+F32, F64 = L.PRECISION_F32, L.PRECISION_F64
+
+
+def ac_max(plane):
+    return np.abs(np.asarray(plane, np.float64).reshape(-1)[1:]).max()
+
+
+# ---- yiq ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 1), (5, 5), (3, 7), (33, 17), (444, 640), (270, 480)])
+def test_rgb_to_yiq_bit_exact(shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    rgb = rng.random(shape + (3,)).astype(np.float32)
+    y, i, q = G.rgb_to_yiq(rgb)
+    ry, ri, rq = O.rgb_to_yiq(rgb)
+    assert np.array_equal(y[0], ry) and np.array_equal(i[0], ri) and np.array_equal(q[0], rq)
+    y_only = G.rgb_to_yiq(rgb, with_iq=False)[0]
+    assert np.array_equal(y_only[0], ry)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (5, 5), (3, 7), (33, 17), (444, 640)])
+def test_yiq_to_rgb_bit_exact_and_clamped(shape):
+    rng = np.random.default_rng(11)
+    y = rng.random(shape).astype(np.float32)
+    i = (rng.random(shape).astype(np.float32) - 0.5) * 1.4      # drives some pixels out of gamut
+    q = (rng.random(shape).astype(np.float32) - 0.5) * 1.2
+    got = G.yiq_to_rgb(y, i, q)[0]
+    ref = O.yiq_to_rgb(y, i, q)
+    assert np.array_equal(got, ref)
+    assert got.min() >= 0.0 and got.max() <= 1.0
+    assert (got == 0.0).any() and (got == 1.0).any()
+
+
+def test_yiq_known_answers(known_answers):
+    ka = known_answers["yiq_triples"]
+    for p in ka["pairs"]:
+        rgb = np.array(p["rgb"], np.float32).reshape(1, 1, 3)
+        y, i, q = G.rgb_to_yiq(rgb)
+        assert np.abs(np.array([y[0, 0, 0], i[0, 0, 0], q[0, 0, 0]]) - p["yiq"]).max() <= ka["tol"]
+        back = G.yiq_to_rgb(y[0], i[0], q[0])
+        assert np.abs(back.reshape(3) - p["rgb"]).max() <= ka["tol"]
+
+
+# ---- dct ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [F32, F64])
+@pytest.mark.parametrize("case", ["dct2d_almost_identity", "dct2d_no_ones", "dct2d_larger", "dct2d_ortho_4x3"])
+def test_dct_reference_known_answers(known_answers, precision, case):
+    """The reference's own scipy-derived goldens (src/dct2d.rs:268-524), tolerance 1e-4 abs."""
+    ka = known_answers[case]
+    x = np.array(ka["input"], np.float32).reshape(ka["h"], ka["w"])
+    if "dct2" in ka:
+        c = G.dct2d(x, L.DCT2, precision)
+        assert np.abs(c.ravel() - ka["dct2"]).max() <= ka["tol"]
+        back = G.dct2d(c, L.DCT3, precision)
+        assert np.abs(back - x).max() <= ka["tol"]
+    if "dct2_orthogonal" in ka:
+        c = G.dct2d(x, L.DCT2_ORTHOGONAL, precision)
+        assert np.abs(c.ravel() - ka["dct2_orthogonal"]).max() <= ka["tol"]
+
+
+SHAPES = [(1, 1), (1, 7), (7, 1), (3, 3), (5, 4), (4, 5), (16, 24), (37, 74), (135, 240), (130, 129),
+          (444, 640), (256, 256), (300, 128)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
+def test_dct_canonical_matches_oracle_bits(shape, dct_type):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    x = rng.random(shape).astype(np.float32)
+    if dct_type == L.DCT3:
+        x = O.dct2d(x, O.DCT2)                      # realistic coefficient plane as input
+    ref = O.dct2d(x, dct_type, O.BACKEND_F64)
+    got = G.dct2d(x, dct_type, F64)
+    scale = max(ac_max(ref) if ref.size > 1 else abs(float(ref.ravel()[0])), 1e-30)
+    assert np.abs(got.astype(np.float64) - ref).max() <= 2e-7 * scale
+    if ref.size >= 64:
+        assert np.mean(got == ref) >= 0.999
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
+def test_dct_f32_mfma_within_tolerance(shape, dct_type):
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    x = rng.random(shape).astype(np.float32)
+    if dct_type == L.DCT3:
+        x = O.dct2d(x, O.DCT2)
+    ref = O.dct2d(x, dct_type, O.BACKEND_F64)
+    got = G.dct2d(x, dct_type, F32)
+    scale = max(ac_max(ref) if ref.size > 1 else abs(float(ref.ravel()[0])), 1e-30)
+    if dct_type == L.DCT3:
+        scale = 1.0                                  # pixel domain, values in [0, 1]
+    assert np.abs(got.astype(np.float64) - ref).max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("precision", [F32, F64])
+def test_dct_batched_equals_single(precision):
+    rng = np.random.default_rng(2)
+    x = rng.random((5, 72, 136)).astype(np.float32)
+    G.ctx().set_chunk_frames(2)                      # exercise the chunk loop incl. a ragged last chunk
+    try:
+        batched = G.dct2d(x, L.DCT2, precision)
+    finally:
+        G.ctx().set_chunk_frames(16)
+    for f in range(5):
+        assert np.array_equal(batched[f], G.dct2d(x[f], L.DCT2, precision))
+
+
+@pytest.mark.parametrize("precision", [F32, F64])
+def test_dct_linearity_and_roundtrip_1080p(precision):
+    """Size-independent properties at a BASELINE.json frame size (1920x1080)."""
+    rgb = G.synth(3, 0, 2, 1920, 1080)
+    a = O.rgb_to_yiq(rgb[0])[0]
+    b = O.rgb_to_yiq(rgb[1])[0]
+    ca, cb = G.dct2d(a, L.DCT2, precision), G.dct2d(b, L.DCT2, precision)
+    s = (a.astype(np.float64) * 0.5 + b.astype(np.float64) * 0.25).astype(np.float32)
+    cs = G.dct2d(s, L.DCT2, precision)
+    lin = ca.astype(np.float64) * 0.5 + cb.astype(np.float64) * 0.25
+    assert np.abs(cs - lin).max() <= 4e-6 * ac_max(lin)
+    assert abs(float(ca[0, 0]) - 4.0 * float(a.astype(np.float64).sum())) <= 1e-6 * abs(float(ca[0, 0]))   # DC = 4 sum
+    back = G.dct2d(ca, L.DCT3, precision)
+    assert np.abs(back - a).max() <= (2e-7 if precision == F64 else 3e-6)
+
+
+# ---- ordering ----------------------------------------------------------------------------------
+ORDERINGS = [L.ORDER_ENERGY, L.ORDER_ENERGY_ORTHOGONAL, L.ORDER_LEGACY]
+
+
+def test_indices_known_answer(known_answers):
+    ka = known_answers["indices"]
+    c = np.array(ka["coefficients"], np.float32).reshape(1, 6)
+    for k in range(1, 6):
+        assert G.topk(c, k).tolist() == ka["expected"][:k]
+
+
+@pytest.mark.parametrize("ordering", ORDERINGS)
+def test_topk_matches_oracle_with_ties(ordering):
+    rng = np.random.default_rng(5)
+    c = rng.integers(-9, 10, size=(3, 40, 56)).astype(np.float32)      # many exact ties, +/- pairs, zeros
+    for k in (1, 2, 17, 100, 1000, 40 * 56 - 1):
+        got = G.topk(c, k, ordering)
+        for f in range(3):
+            assert np.array_equal(got[f], O.indices(c[f], ordering, k=k)), (ordering, k, f)
+
+
+@pytest.mark.parametrize("ordering", ORDERINGS)
+def test_topk_matches_oracle_on_real_coefficients(ordering, cat_images):
+    y = O.rgb_to_yiq(u8_to_f32(cat_images["cat"]))[0]
+    c = O.dct2d(y)
+    for k in (1000, 10000):
+        assert np.array_equal(G.topk(c, k, ordering), O.indices(c, ordering, k=k))
+
+
+def test_topk_degenerate_planes():
+    z = np.zeros((2, 9, 13), np.float32)                               # every key ties: index order
+    assert np.array_equal(G.topk(z, 50)[0], np.arange(1, 51))
+    z[1, 0, 0] = 1e9                                                   # a huge DC must be ignored
+    z[1, 3, 4] = -2.0
+    assert G.topk(z, 3)[1].tolist() == [3 * 13 + 4, 1, 2]
+    one = np.array([[5.0, 3.0]], np.float32)                           # n-1 == 1
+    assert G.topk(one, 1).tolist() == [1]
+
+
+def test_topk_rejects_bad_k():
+    c = np.zeros((4, 4), np.float32)
+    with pytest.raises(wm.SswError) as e:
+        G.topk(c, 16)
+    assert e.value.status == L.SSW_ERR_K_TOO_LARGE
+
+
+# ---- embed / extract / similarity -----------------------------------------------------------------
+def test_embedder_known_answers(known_answers):
+    f, a = np.float32, np.float32(0.1)
+    ka = known_answers["embedder_single"]
+    c = np.array(ka["coefficients"], np.float32).reshape(1, 6)
+    idx = G.topk(c, 3).reshape(1, 3)
+    emb = G.embed(c, idx, np.array(ka["mark"], np.float32).reshape(1, 1, 3))
+    expected = np.array([f(-3), f(5) * (f(1) + f(1) * a), f(-8) * (f(1) + f(1) * a), f(7) * (f(1) - f(0.5) * a), f(1), f(2)], np.float32)
+    assert np.array_equal(emb[0], expected)                           # assert_eq! in the reference
+    ext = G.extract(c, emb, idx)
+    assert np.abs(ext[0] - np.array(ka["mark"], np.float32)).max() < ka["extract_tol"]
+    ka = known_answers["embedder_single_and_zero"]
+    emb2 = G.embed(c, idx, np.array(ka["marks"], np.float32).reshape(1, 2, 3))
+    assert np.array_equal(emb2[0], expected)
+    ka = known_answers["embedder_multiple"]
+    marks = np.array(ka["marks"], np.float32).reshape(1, 2, 3)
+    emb3 = G.embed(c, idx, marks)
+    assert np.array_equal(emb3[0], O.embed(c[0], idx[0], list(marks[0])))
+
+
+@pytest.mark.parametrize("method", [L.OPTION1, L.OPTION2, L.OPTION3])
+@pytest.mark.parametrize("n_marks", [1, 3])
+def test_embed_extract_match_oracle(method, n_marks):
+    rng = np.random.default_rng(method * 10 + n_marks)
+    n, plane, k = 3, 5000, 700
+    coef = (rng.standard_normal((n, plane)) * 100).astype(np.float32)
+    idx = np.stack([rng.permutation(np.arange(1, plane))[:k] for _ in range(n)]).astype(np.uint32)
+    marks = rng.standard_normal((n, n_marks, k)).astype(np.float32)
+    emb = G.embed(coef, idx, marks, method, 0.1)
+    ext = G.extract(coef, emb, idx, method, 0.1)
+    for f in range(n):
+        ref = O.embed(coef[f], idx[f], list(marks[f]), method, 0.1)
+        ref_ext = O.extract(coef[f], ref, idx[f], k, method, 0.1)
+        if method == L.OPTION3:      # expf / logf: libm vs ocml, <= 2 ulp
+            assert np.abs(emb[f] - ref).max() <= 3e-7 * np.abs(ref).max()
+            assert np.abs(ext[f] - ref_ext).max() <= 1e-4
+        else:
+            assert np.array_equal(emb[f], ref)
+            assert np.array_equal(G.extract(coef, ref[None].repeat(n, 0), idx, method, 0.1)[f], ref_ext)
+
+
+@pytest.mark.parametrize("k", [1, 3, 1000, 1024, 1025, 10000])
+def test_similarity_bit_exact(k):
+    rng = np.random.default_rng(k)
+    e = rng.standard_normal((4, k)).astype(np.float32)
+    m = rng.standard_normal((4, k)).astype(np.float32)
+    got = G.similarity_batch(e, m)
+    for f in range(4):
+        assert got[f] == np.float32(O.similarity(e[f], m[f]))
+
+
+def test_extract_error_behaviour():
+    c = np.zeros((1, 6), np.float32)
+    with pytest.raises(wm.SswError) as e:
+        G.extract(c, c, np.zeros((1, 6), np.uint32))                   # k >= n (algorithm.rs:553-555)
+    assert e.value.status == L.SSW_ERR_K_TOO_LARGE
+
+
+# ---- crate surface: Writer / Reader / Tester ------------------------------------------------------
+@pytest.mark.parametrize("precision", [F32, F64])
+def test_single_simple_flow(known_answers, marks, cat_images, precision):
+    """tests/single_simple.rs through the GPU path (self-consistent decode)."""
+    th = known_answers["single_simple_thresholds"]
+    cat = cat_images["cat"]
+    mark = marks["seed_1"]
+    res = wm.Writer(cat, wm.WriteConfig(precision=precision)).mark([mark])
+    img8 = f32_to_u8(res)
+    reader = wm.Reader.base(cat, wm.ReadConfig(precision=precision))
+    derived = wm.Reader.derived(img8, precision=precision)
+    ext = reader.extract(derived, np.zeros(1000, np.float32))
+    assert np.abs(ext - mark).max() < 0.16
+    assert np.abs(ext - mark).mean() < th["mean_err"]
+    tester = wm.Tester(ext)
+    assert tester.similarity(mark).exceeds_sigma(th["sim_gt"])
+    assert not tester.similarity(marks["seed_baaaaaad"]).exceeds_sigma(th["random_sim_lt"])
+    # oracle on the same inputs
+    o_img8 = f32_to_u8(O.embed_frame(u8_to_f32(cat), mark))
+    o_ext, o_sim = O.extract_frame(u8_to_f32(cat), u8_to_f32(o_img8), mark)
+    assert np.mean(img8 == o_img8) > 0.9999
+    assert abs(tester.similarity(mark).similarity - o_sim) < 2e-2      # 8-bit quantisation noise dominates
+
+
+def test_reference_png_carries_seed1_mark(marks, cat_images):
+    reader = wm.Reader.base(cat_images["cat"])
+    ext = reader.extract(wm.Reader.derived(cat_images["watermarked_with_1"]), 1000)
+    assert wm.Tester(ext).similarity(marks["seed_1"]).similarity > 15.0
+    assert abs(wm.Tester(ext).similarity(marks["seed_2"]).similarity) < 3.0
+
+
+def test_canonical_pipeline_matches_oracle(marks, cat_images):
+    """No 8-bit step: Writer::mark -> Reader::extract -> similarity, canonical precision, vs the oracle."""
+    cat = u8_to_f32(cat_images["cat"])
+    mark = marks["seed_1"]
+    cfgw, cfgr = wm.WriteConfig(precision=F64), wm.ReadConfig(precision=F64)
+    writer = wm.Writer(cat, cfgw)
+    coef = writer.coefficient_image()
+    ref_coef = O.dct2d(O.rgb_to_yiq(cat)[0])
+    assert np.mean(coef == ref_coef) > 0.999
+    res = writer.mark([mark])
+    ref_res = O.embed_frame(cat, mark)
+    assert np.abs(res - ref_res).max() <= 2e-7
+    assert np.mean(res == ref_res) > 0.99
+    reader = wm.Reader.base(cat, cfgr)
+    assert np.array_equal(reader.indices(1000), O.indices(ref_coef, k=1000))
+    ext = reader.extract(wm.Reader.derived(res, precision=F64), 1000)
+    ref_ext, ref_sim = O.extract_frame(cat, ref_res, mark)
+    assert np.abs(ext - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert abs(wm.Tester(ext).similarity(mark).similarity - ref_sim) < 1e-4
+
+
+def test_f32_pipeline_matches_oracle_tie_aware(marks, cat_images):
+    """f32 MFMA precision: ordering checked tie-aware against oracle keys, values keyed by index."""
+    cat = u8_to_f32(cat_images["cat"])
+    mark = marks["seed_1"]
+    writer = wm.Writer(cat)
+    coef = writer.coefficient_image()
+    ref_coef = O.dct2d(O.rgb_to_yiq(cat)[0])
+    assert np.abs(coef - ref_coef).max() <= 2e-6 * ac_max(ref_coef)
+    reader = wm.Reader.base(cat)
+    idx = reader.indices(1000).astype(np.int64)
+    assert len(set(idx.tolist())) == 1000 and idx.min() >= 1
+    # (i) the GPU's own coefficients give exactly this order
+    assert np.array_equal(idx, O.indices(coef, k=1000))
+    # (ii) against the oracle's energies the order is monotone up to the DCT tolerance
+    e = ref_coef.reshape(-1).astype(np.float64)[idx] ** 2
+    assert np.all(e[1:] <= e[:-1] * (1 + 1e-5))
+    # (iii) same index list fed to both sides -> extracted values agree, sims agree
+    res = writer.mark([mark])
+    ext = reader.extract(wm.Reader.derived(res), 1000)
+    ref_res = O.embed(ref_coef, idx.astype(np.uint64), [mark])
+    ref_y = O.dct2d(ref_res, O.DCT3)
+    yiq = O.rgb_to_yiq(cat)
+    ref_rgb = O.yiq_to_rgb(ref_y, yiq[1], yiq[2])
+    assert np.abs(res - ref_rgb).max() <= 2e-6
+    ref_derived = O.dct2d(O.rgb_to_yiq(ref_rgb)[0])
+    ref_ext = O.extract(ref_coef, ref_derived, idx.astype(np.uint64), 1000)
+    err = np.abs(ext - ref_ext)
+    assert np.median(err) <= 1e-5 and err.max() <= 2e-3
+    sim = wm.Tester(ext).similarity(mark).similarity
+    assert abs(sim - O.similarity(ref_ext, mark)) < 1e-4 * abs(sim)
+
+
+def test_writer_reader_error_behaviour(cat_images):
+    small = np.random.default_rng(0).random((6, 8, 3)).astype(np.float32)
+    w = wm.Writer(small)
+    w.result()
+    with pytest.raises(wm.SswError) as e:
+        w.result()                                                     # `result(self)` consumed it
+    assert e.value.status == L.SSW_ERR_CONSUMED
+    base = wm.Reader.base(small)
+    derived = wm.Reader.derived(small)
+    with pytest.raises(wm.SswError) as e:
+        derived._reader.extract(derived, 3)                            # unwrap() on a derived reader
+    assert e.value.status == L.SSW_ERR_NOT_BASE
+    with pytest.raises(wm.SswError) as e:
+        derived._reader.indices(3)
+    assert e.value.status == L.SSW_ERR_NOT_BASE
+    with pytest.raises(wm.SswError) as e:
+        base.extract(derived, 48)                                      # k >= coefficients
+    assert e.value.status == L.SSW_ERR_K_TOO_LARGE
+    other = wm.Reader.derived(np.zeros((6, 9, 3), np.float32))
+    with pytest.raises(wm.SswError) as e:
+        base.extract(other, 3)                                         # length mismatch
+    assert e.value.status == L.SSW_ERR_LENGTH_MISMATCH
+    with pytest.raises(wm.SswError) as e:
+        wm.Tester(np.zeros(3, np.float32)).similarity(np.zeros(4, np.float32))
+    assert e.value.status == L.SSW_ERR_LENGTH_MISMATCH
+    with pytest.raises(wm.SswError) as e:
+        wm.Writer(small, wm.WriteConfig(insertion=wm.Insertion.Custom(lambda i, o, m: o)))
+    assert e.value.status == L.SSW_ERR_UNSUPPORTED
+    with pytest.raises(wm.SswError) as e:
+        wm.Reader.base(small, wm.ReadConfig(ordering=wm.OrderingMethod.Custom(lambda *a: 0)))
+    assert e.value.status == L.SSW_ERR_UNSUPPORTED
+
+
+def test_mark_longer_than_coefficients_is_truncated():
+    small = np.random.default_rng(1).random((3, 4, 3)).astype(np.float32)     # 12 coefficients, 11 usable
+    w = wm.Writer(small, wm.WriteConfig(insertion=wm.Insertion.Option1(0.5)))
+    before = w.coefficient_image().reshape(-1)
+    w.embed([np.ones(40, np.float32)])
+    after = w.coefficient_image().reshape(-1)
+    assert after[0] == before[0]
+    assert np.array_equal(after[1:], before[1:] + np.float32(0.5))
+
+
+def test_multiple_marks_ragged_lengths():
+    rgb = O.synth_frame(9, 0, 96, 64)
+    rng = np.random.default_rng(4)
+    m1, m2 = rng.standard_normal(200).astype(np.float32), rng.standard_normal(120).astype(np.float32)
+    w = wm.Writer(rgb, wm.WriteConfig(precision=F64))
+    c0 = w.coefficient_image()
+    w.embed([m1, m2])
+    got = w.coefficient_image()
+    idx = O.indices(c0, k=200)
+    assert np.array_equal(got, O.embed(c0, idx, [m1, m2]))
+
+
+# ---- batch path + synthetic frames ------------------------------------------------------------------
+def test_synth_frames_bit_identical_to_oracle():
+    got = G.synth(7, 3, 2, 160, 90)
+    for f in range(2):
+        assert np.array_equal(got[f], O.synth_frame(7, 3 + f, 160, 90))
+    assert got.min() >= 0.0 and got.max() < 1.0
+
+
+@pytest.mark.parametrize("precision", [F32, F64])
+def test_batch_path_equals_handles_and_oracle(precision):
+    n, w, h, k = 5, 192, 108, 300
+    rgb = G.synth(2, 0, n, w, h)
+    marks = np.random.default_rng(8).standard_normal((n, k)).astype(np.float32)
+    cfg = G.default_config(precision)
+    G.ctx().set_chunk_frames(2)
+    try:
+        res = G.batch_embed(rgb, marks, cfg, want_coef=True, want_idx=True)
+        ext, sims = G.batch_extract(rgb, res["rgb"], k, marks, cfg)
+    finally:
+        G.ctx().set_chunk_frames(16)
+    for f in range(n):
+        wr = wm.Writer(rgb[f], wm.WriteConfig(precision=precision))
+        assert np.array_equal(res["coef"][f], wr.coefficient_image())
+        assert np.array_equal(res["rgb"][f], wr.mark([marks[f]]))
+        rd = wm.Reader.base(rgb[f], wm.ReadConfig(precision=precision))
+        assert np.array_equal(res["idx"][f], rd.indices(k).astype(np.uint32))
+        e1 = rd.extract(wm.Reader.derived(res["rgb"][f], precision=precision), k)
+        assert np.array_equal(ext[f], e1)
+        assert sims[f] == np.float32(wm.Tester(e1).similarity(marks[f]).similarity)
+        assert sims[f] > 0.9 * np.linalg.norm(marks[f])
+        if precision == F64:
+            o_res = O.embed_frame(rgb[f], marks[f])
+            assert np.abs(res["rgb"][f] - o_res).max() <= 2e-7
+            o_ext, o_sim = O.extract_frame(rgb[f], o_res, marks[f])
+            assert abs(sims[f] - o_sim) < 1e-4 * abs(o_sim) + 1e-4
