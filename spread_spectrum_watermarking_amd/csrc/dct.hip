@@ -70,6 +70,12 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDK = BK + 4;          // k-contiguous tiles: 36-float rows -> conflict-free ds_read_b128
 constexpr int LDN = BN + 4;          // n-contiguous tile of the NN kernel
 constexpr int THREADS = 256;
+// f32 path: the MFMA accumulates an exact-f32 fma chain; a chain over all K (up to 7680) lets the
+// rounding error grow with the running sum.  Every ACC_CHUNK k-tiles (256 k) the chain is folded
+// into a second f32 accumulator and restarted, which bounds each chain by its chunk's partial sum
+// (two-level summation): ~8x smaller error on the DC-dominated low frequencies at 4K for 64 extra
+// VGPRs and 64 v_add_f32 per 128 MFMAs.
+constexpr int ACC_CHUNK = 8;
 
 // XCD-aware, L2-friendly block -> tile map.  Blocks b, b+8, b+16, ... share an XCD (observed
 // round-robin placement; speed only).  First give each XCD a contiguous run of tile ids, then
@@ -114,7 +120,7 @@ __device__ inline f32x4 load_k4(const float* __restrict__ row, unsigned k, unsig
 // f32 NT kernel (row pass):  OUT[m][n] = sum_k A[m][k] * B[n][k],  A: MxK, B: NxK, K-contiguous.
 // ---------------------------------------------------------------------------------------------
 template <bool ALIGNED>
-__global__ __launch_bounds__(THREADS) void dct_rows_f32_kernel(
+__global__ __launch_bounds__(THREADS, 2) void dct_rows_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ OUT,
     unsigned M, unsigned N, unsigned K, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][BM * LDK];   // [buf][A|B][row*LDK + k]
@@ -140,13 +146,13 @@ __global__ __launch_bounds__(THREADS) void dct_rows_f32_kernel(
         b_rows[p] = B + (size_t)rb * K;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
     const unsigned nk = (K + BK - 1) / BK;
     f32x4 ra[4], rb[4];
@@ -191,6 +197,16 @@ __global__ __launch_bounds__(THREADS) void dct_rows_f32_kernel(
                     for (int jn = 0; jn < 2; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn][j], acc[i][jn], 0, 0, 0);
         }
+        if ((t + 1) % ACC_CHUNK == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    tot[i][jn] += acc[i][jn];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+                }
+        }
         if (t + 1 < nk) {
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -200,6 +216,10 @@ __global__ __launch_bounds__(THREADS) void dct_rows_f32_kernel(
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = tot[i][jn] + acc[i][jn];
 
     // C/D map of 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -236,7 +256,7 @@ __device__ inline f32x4 load_n4(const float* __restrict__ row, unsigned n, unsig
 }
 
 template <bool ALIGNED>
-__global__ __launch_bounds__(THREADS) void dct_cols_f32_kernel(
+__global__ __launch_bounds__(THREADS, 2) void dct_cols_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ Bz, float* __restrict__ OUTz,
     unsigned M, unsigned N, unsigned K, unsigned tiles_m, unsigned tiles_n, unsigned tiles_per_frame,
     Epilogue ep) {
@@ -265,13 +285,13 @@ __global__ __launch_bounds__(THREADS) void dct_cols_f32_kernel(
         a_rows[p] = A + (size_t)ra * K;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], tot[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
     const unsigned nk = (K + BK - 1) / BK;
     f32x4 ra[4], rb[4];
@@ -318,9 +338,23 @@ __global__ __launch_bounds__(THREADS) void dct_cols_f32_kernel(
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[jn], acc[i][jn], 0, 0, 0);
             }
         }
+        if ((t + 1) % ACC_CHUNK == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    tot[i][jn] += acc[i][jn];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.f;
+                }
+        }
         if (t + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) acc[i][jn] = tot[i][jn] + acc[i][jn];
 
 #pragma unroll
     for (int i = 0; i < 2; ++i)
