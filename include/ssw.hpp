@@ -1,0 +1,230 @@
+// ssw.hpp -- C++17 host-side mirror of the crate's public surface over the C ABI (ssw.h).
+//
+// The reference is compiled code (Rust); no Rust toolchain exists in this image, so the host side
+// above the C ABI is written in C++ with the reference's names, argument meaning and error
+// behaviour (file:line relative to the reference tree):
+//
+//   wm::Writer / WriteConfig / Insertion      src/algorithm.rs:68-112, :285-433
+//   wm::Reader / ReaderDerived / ReadConfig    src/algorithm.rs:114-140, :435-594
+//   wm::OrderingMethod                         src/algorithm.rs:142-191
+//   wm::MarkBuf                                src/algorithm.rs:596-666
+//   wm::Tester / Similarity                    src/algorithm.rs:668-715
+//
+// Where the reference panics, wm::Error (carrying the ssw_status) is thrown.  Images are
+// interleaved RGB f32 buffers [h][w][3] -- what `DynamicImage::into_rgb32f()` yields (:308, :476).
+// Header-only; link against libssw_hip.so.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ssw.h"
+
+namespace wm {
+
+class Error : public std::runtime_error {
+public:
+    Error(int status, const std::string& where)
+        : std::runtime_error(where + ": " + ssw_status_string(status) +
+                             (status == SSW_ERR_HIP ? std::string(" [") + ssw_last_error() + "]" : std::string())),
+          status_(status) {}
+    int status() const { return status_; }
+
+private:
+    int status_;
+};
+
+inline void check(int status, const char* where) {
+    if (status != SSW_OK) throw Error(status, where);
+}
+
+// One per GPU; not thread-safe (the reference's Writer/Reader are !Send).
+class Context {
+public:
+    explicit Context(int device_id = 0) { check(ssw_ctx_create(device_id, &ctx_), "ssw_ctx_create"); }
+    ~Context() { ssw_ctx_destroy(ctx_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    ssw_ctx* get() const { return ctx_; }
+    void synchronize() { check(ssw_ctx_synchronize(ctx_), "ssw_ctx_synchronize"); }
+
+private:
+    ssw_ctx* ctx_ = nullptr;
+};
+
+// Insertion / Extraction (algorithm.rs:68-77, :115-124).  Custom(closure) exists in the reference;
+// it cannot cross to the device and yields SSW_ERR_UNSUPPORTED.
+struct Insertion {
+    int method;
+    float alpha;
+    static Insertion Option1(float a) { return {SSW_OPTION1, a}; }
+    static Insertion Option2(float a) { return {SSW_OPTION2, a}; }
+    static Insertion Option3(float a) { return {SSW_OPTION3, a}; }
+    static Insertion Custom() { return {SSW_METHOD_CUSTOM, 0.f}; }
+};
+using Extraction = Insertion;
+
+enum class OrderingMethod : int {
+    Energy = SSW_ORDER_ENERGY,
+    EnergyOrthogonal = SSW_ORDER_ENERGY_ORTHOGONAL,
+    Legacy = SSW_ORDER_LEGACY,
+    Custom = SSW_ORDER_CUSTOM,
+};
+
+struct WriteConfig {                                   // algorithm.rs:99-112
+    Insertion insertion = Insertion::Option2(0.1f);
+    OrderingMethod ordering = OrderingMethod::Energy;
+    ssw_precision precision = SSW_PRECISION_F32;
+    ssw_config c() const { return {static_cast<int32_t>(ordering), insertion.method, insertion.alpha, precision}; }
+};
+struct ReadConfig {                                    // algorithm.rs:127-140
+    Extraction extraction = Extraction::Option2(0.1f);
+    OrderingMethod ordering = OrderingMethod::Energy;
+    ssw_precision precision = SSW_PRECISION_F32;
+    ssw_config c() const { return {static_cast<int32_t>(ordering), extraction.method, extraction.alpha, precision}; }
+};
+
+// An RGB f32 image [h][w][3].
+struct ImageRgb32F {
+    size_t width = 0, height = 0;
+    std::vector<float> data;
+    ImageRgb32F() = default;
+    ImageRgb32F(size_t w, size_t h) : width(w), height(h), data(w * h * 3) {}
+};
+
+class MarkBuf {                                        // algorithm.rs:607-645
+public:
+    MarkBuf() = default;
+    static MarkBuf generate_normal(size_t length) {    // :619-626 (non-deterministic by design)
+        MarkBuf m;
+        std::random_device rd;
+        std::mt19937_64 gen(rd());
+        std::normal_distribution<float> n(0.f, 1.f);
+        m.data_.resize(length);
+        for (auto& v : m.data_) v = n(gen);
+        return m;
+    }
+    static MarkBuf from(const float* data, size_t n) { MarkBuf m; m.data_.assign(data, data + n); return m; }
+    static MarkBuf from(const std::vector<float>& v) { return from(v.data(), v.size()); }
+    const std::vector<float>& data() const { return data_; }
+    void set_data(const float* data, size_t n) { data_.assign(data, data + n); }
+
+private:
+    std::vector<float> data_;
+};
+
+class Writer {                                         // algorithm.rs:285-433
+public:
+    Writer(Context& ctx, const ImageRgb32F& image, const WriteConfig& config = WriteConfig())
+        : w_(image.width), h_(image.height) {
+        if (image.data.size() != w_ * h_ * 3) throw Error(SSW_ERR_BAD_DIMS, "Writer::new");
+        ssw_config c = config.c();
+        check(ssw_writer_create(ctx.get(), image.data.data(), w_, h_, &c, &wr_), "Writer::new");
+    }
+    ~Writer() { ssw_writer_destroy(wr_); }
+    Writer(const Writer&) = delete;
+    Writer& operator=(const Writer&) = delete;
+
+    std::vector<float> coefficient_image() const {     // :319-321
+        std::vector<float> out(w_ * h_);
+        check(ssw_writer_coefficients(wr_, out.data()), "Writer::coefficient_image");
+        return out;
+    }
+    void embed(const std::vector<const MarkBuf*>& marks) {   // :348-352
+        std::vector<const float*> p; std::vector<size_t> l;
+        for (auto* m : marks) { p.push_back(m->data().data()); l.push_back(m->data().size()); }
+        check(ssw_writer_embed(wr_, p.data(), l.data(), p.size()), "Writer::embed");
+    }
+    ImageRgb32F result() {                             // :361-379 (consumes the writer)
+        ImageRgb32F out(w_, h_);
+        check(ssw_writer_result(wr_, out.data.data()), "Writer::result");
+        return out;
+    }
+    ImageRgb32F mark(const std::vector<const MarkBuf*>& marks) {   // :355-358
+        embed(marks);
+        return result();
+    }
+
+private:
+    size_t w_, h_;
+    ssw_writer* wr_ = nullptr;
+};
+
+class ReaderDerived;
+
+class Reader {                                         // algorithm.rs:441-594
+public:
+    static Reader base(Context& ctx, const ImageRgb32F& image, const ReadConfig& config = ReadConfig()) {   // :462-464
+        return Reader(ctx, image, true, config);
+    }
+    ~Reader() { ssw_reader_destroy(rd_); }
+    Reader(Reader&& o) noexcept : w_(o.w_), h_(o.h_), rd_(o.rd_) { o.rd_ = nullptr; }
+    Reader(const Reader&) = delete;
+    Reader& operator=(const Reader&) = delete;
+
+    std::vector<float> coefficients() const {          // :502-504
+        std::vector<float> out(w_ * h_);
+        check(ssw_reader_coefficients(rd_, out.data()), "Reader::coefficients");
+        return out;
+    }
+    std::vector<uint64_t> indices(size_t k) const {    // :506-508 (first k entries)
+        std::vector<uint64_t> out(k);
+        check(ssw_reader_indices(rd_, k, out.data()), "Reader::indices");
+        return out;
+    }
+    void extract(const ReaderDerived& derived, std::vector<float>& extracted) const;   // :529-539
+
+private:
+    friend class ReaderDerived;
+    Reader(Context& ctx, const ImageRgb32F& image, bool is_base, const ReadConfig& config)
+        : w_(image.width), h_(image.height) {
+        if (image.data.size() != w_ * h_ * 3) throw Error(SSW_ERR_BAD_DIMS, "Reader::new_impl");
+        ssw_config c = config.c();
+        check(ssw_reader_create(ctx.get(), image.data.data(), w_, h_, is_base ? 1 : 0, &c, &rd_), "Reader::new_impl");
+    }
+    size_t w_, h_;
+    ssw_reader* rd_ = nullptr;
+};
+
+class ReaderDerived {                                  // algorithm.rs:448-456
+public:
+    ReaderDerived(Context& ctx, const ImageRgb32F& image, ssw_precision precision = SSW_PRECISION_F32)
+        : r_(ctx, image, false, [&] { ReadConfig c; c.precision = precision; return c; }()) {}
+    std::vector<float> coefficients() const { return r_.coefficients(); }
+
+private:
+    friend class Reader;
+    Reader r_;
+};
+
+inline void Reader::extract(const ReaderDerived& derived, std::vector<float>& extracted) const {
+    check(ssw_reader_extract(rd_, derived.r_.rd_, extracted.data(), extracted.size()), "Reader::extract");
+}
+
+struct Similarity {                                    // algorithm.rs:669-680
+    float similarity;
+    bool exceeds_sigma(float n_sigma) const { return similarity > n_sigma; }
+};
+
+class Tester {                                         // algorithm.rs:683-715
+public:
+    Tester(Context& ctx, const std::vector<float>& extracted_watermark) : ctx_(ctx), e_(extracted_watermark) {}
+    Similarity similarity(const MarkBuf& comparison_watermark) const {
+        float out = 0.f;
+        check(ssw_similarity(ctx_.get(), e_.data(), e_.size(), comparison_watermark.data().data(),
+                             comparison_watermark.data().size(), &out), "Tester::similarity");
+        return {out};
+    }
+
+private:
+    Context& ctx_;
+    const std::vector<float>& e_;
+};
+
+}  // namespace wm

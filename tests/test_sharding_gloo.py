@@ -1,0 +1,79 @@
+"""Multi-GPU path on CPU: world-size-2 gloo run of the frame sharding that bench.py uses.
+
+Frames are independent: rank r processes the contiguous block given by
+bench.shard_frames and no collective touches frame data.  Here each rank runs its shard through
+the CPU oracle (the checker; there is no GPU in this container), the per-frame similarities are
+gathered, and the result must equal a single-process run frame for frame."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _frame_result(seed, frame, w, h, k):
+    from oracle import oracle as O
+    rgb = O.synth_frame(seed, frame, w, h)
+    mark = np.random.default_rng(1000 + frame).standard_normal(k).astype(np.float32)
+    marked = O.embed_frame(rgb, mark)
+    _, sim = O.extract_frame(rgb, marked, mark)
+    return sim
+
+
+def _worker(rank, world, port, total, w, h, k, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    lo, hi = bench.shard_frames(total, world, rank)
+    sims = torch.zeros(total, dtype=torch.float64)
+    for f in range(lo, hi):
+        sims[f] = _frame_result(7, f, w, h, k)
+    dist.barrier()
+    # timing reduction of bench.py: MAX over ranks
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gathered = [torch.zeros(total, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(gathered, sims)          # result gather only: k floats + 1 score per frame
+    if rank == 0:
+        merged = torch.stack(gathered).sum(0).numpy()
+        np.save(out_path, np.concatenate([merged, [t.item()]]))
+    dist.destroy_process_group()
+
+
+def test_shard_frames_partition():
+    import bench
+    for total, world in [(2048, 8), (512, 8), (5, 2), (7, 3), (1, 2)]:
+        covered = []
+        for r in range(world):
+            lo, hi = bench.shard_frames(total, world, r)
+            assert lo <= hi
+            covered += list(range(lo, hi))
+        assert covered == list(range(total))                  # disjoint, complete, ordered
+    assert bench.shard_frames(2048, 8, 3) == (768, 1024)      # 256 frames per GPU (configs[3])
+    assert bench.shard_frames(512, 8, 7) == (448, 512)        # 64 frames per GPU (configs[4])
+
+
+def test_two_rank_gloo_run_equals_single_process(tmp_path):
+    total, w, h, k, world = 5, 96, 64, 50, 2
+    out = str(tmp_path / "sims.npy")
+    mp.spawn(_worker, args=(world, _free_port(), total, w, h, k, out), nprocs=world, join=True)
+    got = np.load(out)
+    assert got[-1] == float(world)                            # MAX-reduce saw every rank
+    single = np.array([_frame_result(7, f, w, h, k) for f in range(total)])
+    assert np.array_equal(got[:-1], single)
