@@ -105,6 +105,11 @@ void* ssw_ctx_stream(ssw_ctx* ctx);
    workspace: 4 planes * chunk).  Default 16. */
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
 
+/* f32 precision only: use the even/odd-folded basis GEMMs (half the multiply-adds; one extra f32
+   rounding per input pair) where the frame shape allows (W % 8 == 0 / H % 8 == 0).  Default on;
+   0 selects the dense GEMMs. */
+int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int enable);
+
 /* Per-stage device timers (hipEvent pairs on the context's stream). */
 typedef enum ssw_stage {
     SSW_STAGE_RGB_TO_YIQ = 0,     /* rgb -> y,i,q (24 B/px) or rgb -> y (16 B/px)   */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ssw_ctx_synchronize": (C.c_int, [_vp]),
     "ssw_ctx_stream": (_vp, [_vp]),
     "ssw_ctx_set_chunk_frames": (C.c_int, [_vp, _sz]),
+    "ssw_ctx_set_dct_folding": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_enable_timing": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_reset_timing": (C.c_int, [_vp]),
     "ssw_ctx_get_timing": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -54,6 +54,9 @@ class Context:
     def set_chunk_frames(self, n: int):
         check(self._lib.ssw_ctx_set_chunk_frames(self.handle, n), "ssw_ctx_set_chunk_frames")
 
+    def set_dct_folding(self, on: bool = True):
+        check(self._lib.ssw_ctx_set_dct_folding(self.handle, int(on)), "ssw_ctx_set_dct_folding")
+
     def enable_timing(self, on: bool = True):
         check(self._lib.ssw_ctx_enable_timing(self.handle, int(on)), "ssw_ctx_enable_timing")
 

@@ -13,13 +13,9 @@
 //           tiles (64 accumulator VGPRs), LDS double-buffered, one barrier per k-step.
 // f64 path: v_mfma_f64_16x16x4_f64 with an f64 basis, result rounded once to f32
 //           ("canonical": the correctly rounded transform almost everywhere).
-#include "ssw_internal.hpp"
+#include "dct_common.hpp"
 
 namespace ssw {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
 // Basis generation (device, f64 cospi with exact integer argument reduction).
@@ -76,45 +72,6 @@ constexpr int THREADS = 256;
 // (two-level summation): ~8x smaller error on the DC-dominated low frequencies at 4K for 64 extra
 // VGPRs and 64 v_add_f32 per 128 MFMAs.
 constexpr int ACC_CHUNK = 8;
-
-// XCD-aware, L2-friendly block -> tile map.  Blocks b, b+8, b+16, ... share an XCD (observed
-// round-robin placement; speed only).  First give each XCD a contiguous run of tile ids, then
-// walk tiles in groups of GROUP_M tile-rows, column-major inside a group, so that the ~32 blocks
-// resident on one XCD cover a compact (8 x 4)-tile rectangle and share A/B panels in its L2.
-__device__ inline void tile_of_block(unsigned bid, unsigned nblk, unsigned tiles_m, unsigned tiles_n,
-                                     unsigned& tm, unsigned& tn) {
-    const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8;
-    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    constexpr unsigned GROUP_M = 8;
-    const unsigned per_group = GROUP_M * tiles_n;
-    const unsigned g = id / per_group;
-    const unsigned first_m = g * GROUP_M;
-    const unsigned gm = (tiles_m - first_m < GROUP_M) ? tiles_m - first_m : GROUP_M;
-    const unsigned in_g = id % per_group;
-    tm = first_m + in_g % gm;
-    tn = in_g / gm;
-}
-
-__device__ inline float apply_epilogue(const Epilogue& ep, float acc, unsigned out_idx) {
-    if (ep.mode == 1) return (out_idx == 0 ? ep.s0 : ep.sn) * acc;
-    if (ep.mode == 2) return acc * ep.corr;
-    return acc;
-}
-
-// Load 4 consecutive floats of a k-contiguous row, zero beyond K.
-template <bool ALIGNED>
-__device__ inline f32x4 load_k4(const float* __restrict__ row, unsigned k, unsigned K) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ALIGNED) {
-        if (k < K) v = *reinterpret_cast<const f32x4*>(row + k);
-    } else {
-        if (k + 0 < K) v[0] = row[k + 0];
-        if (k + 1 < K) v[1] = row[k + 1];
-        if (k + 2 < K) v[2] = row[k + 2];
-        if (k + 3 < K) v[3] = row[k + 3];
-    }
-    return v;
-}
 
 // ---------------------------------------------------------------------------------------------
 // f32 NT kernel (row pass):  OUT[m][n] = sum_k A[m][k] * B[n][k],  A: MxK, B: NxK, K-contiguous.
@@ -240,21 +197,6 @@ __global__ __launch_bounds__(THREADS, 2) void dct_rows_f32_kernel(
 // f32 NN kernel (column pass):  OUT[z][m][n] = sum_k A[m][k] * B[z][k][n]
 //   A: basis MxK (K-contiguous), B: per-frame KxN plane (N-contiguous).
 // ---------------------------------------------------------------------------------------------
-template <bool ALIGNED>
-__device__ inline f32x4 load_n4(const float* __restrict__ row, unsigned n, unsigned N, bool row_ok) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (!row_ok) return v;
-    if (ALIGNED) {
-        if (n < N) v = *reinterpret_cast<const f32x4*>(row + n);
-    } else {
-        if (n + 0 < N) v[0] = row[n + 0];
-        if (n + 1 < N) v[1] = row[n + 1];
-        if (n + 2 < N) v[2] = row[n + 2];
-        if (n + 3 < N) v[3] = row[n + 3];
-    }
-    return v;
-}
-
 template <bool ALIGNED>
 __global__ __launch_bounds__(THREADS, 2) void dct_cols_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ Bz, float* __restrict__ OUTz,
@@ -596,8 +538,6 @@ __global__ __launch_bounds__(THREADS) void dct_cols_f64_kernel(
 // ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
-static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 int launch_dct_rows(hipStream_t st, int precision, const float* in, float* out, size_t rows, size_t w,
                     const void* basis, Epilogue ep) {
     if (rows == 0 || w == 0) return SSW_OK;

@@ -1,0 +1,69 @@
+// Device helpers shared by the dense (dct.hip) and even/odd-folded (dct_folded.hip) basis GEMMs.
+#pragma once
+#include "ssw_internal.hpp"
+
+namespace ssw {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// XCD-aware, L2-friendly block -> tile map.  Blocks b, b+8, b+16, ... share an XCD (observed
+// round-robin placement; speed only).  First give each XCD a contiguous run of tile ids, then
+// walk tiles in groups of GROUP_M tile-rows, column-major inside a group, so that the ~32 blocks
+// resident on one XCD cover a compact (8 x 4)-tile rectangle and share A/B panels in its L2.
+__device__ inline void tile_of_block(unsigned bid, unsigned nblk, unsigned tiles_m, unsigned tiles_n,
+                                     unsigned& tm, unsigned& tn) {
+    const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+    const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+    constexpr unsigned GROUP_M = 8;
+    const unsigned per_group = GROUP_M * tiles_n;
+    const unsigned g = id / per_group;
+    const unsigned first_m = g * GROUP_M;
+    const unsigned gm = (tiles_m - first_m < GROUP_M) ? tiles_m - first_m : GROUP_M;
+    const unsigned in_g = id % per_group;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+}
+
+__device__ inline float apply_epilogue(const Epilogue& ep, float acc, unsigned out_idx) {
+    if (ep.mode == 1) return (out_idx == 0 ? ep.s0 : ep.sn) * acc;
+    if (ep.mode == 2) return acc * ep.corr;
+    return acc;
+}
+
+// Load 4 consecutive floats of a k-contiguous row, zero beyond K.
+template <bool ALIGNED>
+__device__ inline f32x4 load_k4(const float* __restrict__ row, unsigned k, unsigned K) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (ALIGNED) {
+        if (k < K) v = *reinterpret_cast<const f32x4*>(row + k);
+    } else {
+        if (k + 0 < K) v[0] = row[k + 0];
+        if (k + 1 < K) v[1] = row[k + 1];
+        if (k + 2 < K) v[2] = row[k + 2];
+        if (k + 3 < K) v[3] = row[k + 3];
+    }
+    return v;
+}
+
+template <bool ALIGNED>
+__device__ inline f32x4 load_n4(const float* __restrict__ row, unsigned n, unsigned N, bool row_ok) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!row_ok) return v;
+    if (ALIGNED) {
+        if (n < N) v = *reinterpret_cast<const f32x4*>(row + n);
+    } else {
+        if (n + 0 < N) v[0] = row[n + 0];
+        if (n + 1 < N) v[1] = row[n + 1];
+        if (n + 2 < N) v[2] = row[n + 2];
+        if (n + 3 < N) v[3] = row[n + 3];
+    }
+    return v;
+}
+
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace ssw

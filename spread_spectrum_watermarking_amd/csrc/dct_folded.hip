@@ -1,0 +1,371 @@
+// Even/odd-folded basis GEMMs (f32 MFMA): half the multiply-adds of the dense transform.
+//
+// The DCT basis is symmetric about the middle of the summed axis,
+//     D[k][N-1-n] = (-1)^k D[k][n]          (DCT-II, forward)
+//     E[N-1-n][k] = (-1)^k E[n][k]          (DCT-III, inverse)
+// so one length-N transform splits into two independent (N/2 x N/2) products:
+//   forward:  X[2j]   = sum_{n<N/2} (x[n] + x[N-1-n]) * De[j][n],   De[j][n] = D[2j][n]
+//             X[2j+1] = sum_{n<N/2} (x[n] - x[N-1-n]) * Do[j][n],   Do[j][n] = D[2j+1][n]
+//   inverse:  P[n] = sum_j x[2j] * Ee[n][j],  Q[n] = sum_j x[2j+1] * Eo[n][j]   (Ee[n][j] = E[n][2j], ...)
+//             y[n] = P[n] + Q[n],   y[N-1-n] = P[n] - Q[n]                         for n < N/2
+// Same outputs as dct.hip's dense kernels (which replace the rustdct calls of
+// /root/reference/src/dct2d.rs:129-206) up to f32 rounding: the sums/differences (forward) and the
+// final P +/- Q (inverse) each add one f32 rounding.  Used when W % 8 == 0 (row pass) or
+// H % 8 == 0 and W % 4 == 0 (column pass); every other shape takes the dense kernels.
+//
+// Every kernel is "two GEMMs sharing one tile geometry": acc1 = A1*B1, acc2 = A2*B2.
+//   rows (NT):  A = image rows (k-contiguous), B = half bases (k-contiguous)
+//   cols (NN):  A = half bases (k-contiguous), B = image rows of one frame (n-contiguous)
+// Block tile: 128 x 64 output pairs (= 128 x 128 outputs) x 16 k, 256 threads = 4 waves as 2 x 2,
+// each wave 4 MFMA 32x32x2 tiles (2 for acc1, 2 for acc2), LDS double-buffered, one barrier per
+// k-step, two-level accumulation every 256 k as in dct.hip.
+#include "dct_common.hpp"
+
+namespace ssw {
+
+constexpr int FT = 256;                 // threads
+constexpr int FBK = 16;                 // k per step
+constexpr int FLDK = FBK + 4;           // 20-float rows: conflict-free ds_read_b128 for the 32x32 lane map
+constexpr int FLDN = 128 + 4;
+constexpr int FCHUNK = 16;              // k-steps per accumulation chunk (256 k)
+
+// ---------------------------------------------------------------------------------------------
+// Half bases, layout [out][sum], (N/2) x (N/2):
+//   forward, parity p: B[j][n] = 2 cos(pi (2j+p)(2n+1) / 2N)
+//   inverse, parity p: B[n][j] = (2j+p == 0) ? 1/4 : cos(pi (2j+p)(2n+1) / 2N) / 2
+// ---------------------------------------------------------------------------------------------
+__global__ void make_half_basis_f32_kernel(size_t n, bool inverse, int parity, size_t kpad, float* out) {
+    const size_t nh = n / 2, total = nh * kpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = i / kpad, s = i % kpad;
+        if (s >= nh) { out[i] = 0.0f; continue; }                        // zero padding of the sum axis
+        const size_t freq = inverse ? 2 * s + parity : 2 * o + parity;     // k of cos(pi k (2 pos + 1) / 2N)
+        const size_t pos = inverse ? o : s;
+        unsigned long long a = (unsigned long long)freq * (2ull * pos + 1ull);
+        a %= 4ull * n;
+        const double c = cospi((double)a / (double)(2ull * n));
+        double v;
+        if (!inverse) v = 2.0 * c;
+        else v = (freq == 0) ? 0.25 : 0.5 * c;
+        out[i] = (float)v;
+    }
+}
+
+// Rows of the half bases are padded with zeros to a multiple of the k-step, so the GEMM main loops
+// need no tail predication: operand loads past the end of the sum axis are clamped to valid
+// addresses and multiply a zero basis entry.
+size_t half_basis_kpad(size_t n) { return ((n / 2 + FBK - 1) / FBK) * FBK; }
+
+int launch_make_half_basis_f32(hipStream_t st, size_t n, bool inverse, int parity, float* out) {
+    const size_t total = (n / 2) * half_basis_kpad(n);
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    make_half_basis_f32_kernel<<<blocks ? blocks : 1, 256, 0, st>>>(n, inverse, parity, half_basis_kpad(n), out);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+__device__ inline void zero16(f32x16& v) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row pass.  X: M x W (rows of all frames of the chunk), OUT: M x W.  Nh = W/2.
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ __launch_bounds__(FT, 2) void dct_rows_folded_f32_kernel(
+    const float* __restrict__ X, const float* __restrict__ B1g, const float* __restrict__ B2g,
+    float* __restrict__ OUT, unsigned M, unsigned W, unsigned Kp, unsigned tiles_m, unsigned tiles_n,
+    Epilogue ep) {
+    __shared__ __attribute__((aligned(16))) float sA1[2][128 * FLDK];
+    __shared__ __attribute__((aligned(16))) float sA2[2][128 * FLDK];
+    __shared__ __attribute__((aligned(16))) float sB1[2][64 * FLDK];
+    __shared__ __attribute__((aligned(16))) float sB2[2][64 * FLDK];
+
+    const unsigned Nh = W / 2;
+    unsigned tm, tn;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+    const unsigned m0 = tm * 128, p0 = tn * 64;          // p0: first output pair (j or n) of the tile
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63, wave = tid >> 6;
+    const unsigned wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
+    const unsigned lr = lane & 31, lh = lane >> 5;
+
+    // staging: A rows = tid/4 + 64p (p = 0,1), B row = tid/4, k quad = tid%4
+    const unsigned srow = tid >> 2, sk = (tid & 3) * 4;
+    const float* a_rows[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        unsigned r = m0 + srow + 64 * p; r = r < M ? r : M - 1;
+        a_rows[p] = X + (size_t)r * W;
+    }
+    unsigned rb = p0 + srow; rb = rb < Nh ? rb : Nh - 1;
+    const float* b1_row = B1g + (size_t)rb * Kp;
+    const float* b2_row = B2g + (size_t)rb * Kp;
+
+    f32x16 acc1[2], acc2[2], tot1[2], tot2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { zero16(acc1[i]); zero16(acc2[i]); zero16(tot1[i]); zero16(tot2[i]); }
+
+    // Unconditional loads (no tail predication: the basis is zero-padded along k, image addresses
+    // are clamped); the +/- folding is done when the registers are written to LDS, i.e. after the
+    // MFMA block of the current step, so the loads stay in flight behind it.
+    f32x4 ru[2], rv[2], rb1, rb2;
+    auto gload = [&](unsigned t) {
+        const unsigned k = t * FBK + sk;                 // index along the folded sum axis, < Kp
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (!INVERSE) {                              // x[k..k+3] and the mirror quad starting at W-4-k
+                ru[p] = *reinterpret_cast<const f32x4*>(a_rows[p] + k);
+                rv[p] = *reinterpret_cast<const f32x4*>(a_rows[p] + (W - 4 - k));
+            } else {                                     // x[2k..2k+7] = e0 o0 e1 o1 | e2 o2 e3 o3
+                const unsigned kc = k < Nh - 4 ? k : Nh - 4;
+                ru[p] = *reinterpret_cast<const f32x4*>(a_rows[p] + 2 * kc);
+                rv[p] = *reinterpret_cast<const f32x4*>(a_rows[p] + 2 * kc + 4);
+            }
+        }
+        rb1 = *reinterpret_cast<const f32x4*>(b1_row + k);
+        rb2 = *reinterpret_cast<const f32x4*>(b2_row + k);
+    };
+    auto lstore = [&](unsigned buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f32x4 v1, v2;
+            if (!INVERSE) {
+                const f32x4 f = ru[p], m = rv[p];
+                v1 = (f32x4){f[0] + m[3], f[1] + m[2], f[2] + m[1], f[3] + m[0]};
+                v2 = (f32x4){f[0] - m[3], f[1] - m[2], f[2] - m[1], f[3] - m[0]};
+            } else {
+                const f32x4 lo = ru[p], hi = rv[p];
+                v1 = (f32x4){lo[0], lo[2], hi[0], hi[2]};
+                v2 = (f32x4){lo[1], lo[3], hi[1], hi[3]};
+            }
+            *reinterpret_cast<f32x4*>(&sA1[buf][(srow + 64 * p) * FLDK + sk]) = v1;
+            *reinterpret_cast<f32x4*>(&sA2[buf][(srow + 64 * p) * FLDK + sk]) = v2;
+        }
+        *reinterpret_cast<f32x4*>(&sB1[buf][srow * FLDK + sk]) = rb1;
+        *reinterpret_cast<f32x4*>(&sB2[buf][srow * FLDK + sk]) = rb2;
+    };
+
+    const unsigned nk = Kp / FBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (unsigned t = 0; t < nk; ++t) {
+        const unsigned cur = t & 1;
+        if (t + 1 < nk) gload(t + 1);
+#pragma unroll
+        for (int kg = 0; kg < FBK / 8; ++kg) {
+            f32x4 a1[2], a2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a1[i] = *reinterpret_cast<const f32x4*>(&sA1[cur][(wm + 32 * i + lr) * FLDK + kg * 8 + lh * 4]);
+                a2[i] = *reinterpret_cast<const f32x4*>(&sA2[cur][(wm + 32 * i + lr) * FLDK + kg * 8 + lh * 4]);
+            }
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(&sB1[cur][(wn + lr) * FLDK + kg * 8 + lh * 4]);
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(&sB2[cur][(wn + lr) * FLDK + kg * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], b1[j], acc1[i], 0, 0, 0);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i][j], b2[j], acc2[i], 0, 0, 0);
+                }
+        }
+        if ((t + 1) % FCHUNK == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                tot1[i] += acc1[i]; zero16(acc1[i]);
+                tot2[i] += acc2[i]; zero16(acc2[i]);
+            }
+        }
+        if (t + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { acc1[i] = tot1[i] + acc1[i]; acc2[i] = tot2[i] + acc2[i]; }
+
+    // C/D map: col = lane & 31 (output pair), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    const unsigned pair = p0 + wn + lr;
+    if (pair < Nh) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const unsigned row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= M) continue;
+                float* o = OUT + (size_t)row * W;
+                if (!INVERSE) {
+                    const f32x2 v = {apply_epilogue(ep, acc1[i][r], 2 * pair), apply_epilogue(ep, acc2[i][r], 2 * pair + 1)};
+                    *reinterpret_cast<f32x2*>(o + 2 * pair) = v;
+                } else {
+                    o[pair] = apply_epilogue(ep, acc1[i][r] + acc2[i][r], pair);
+                    o[W - 1 - pair] = apply_epilogue(ep, acc1[i][r] - acc2[i][r], W - 1 - pair);
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column pass.  One frame per z: IN, OUT: H x W.  Hh = H/2.
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ __launch_bounds__(FT, 2) void dct_cols_folded_f32_kernel(
+    const float* __restrict__ A1g, const float* __restrict__ A2g, const float* __restrict__ INz,
+    float* __restrict__ OUTz, unsigned H, unsigned W, unsigned Kp, unsigned tiles_m, unsigned tiles_n,
+    unsigned tiles_per_frame, Epilogue ep) {
+    __shared__ __attribute__((aligned(16))) float sA1[2][64 * FLDK];
+    __shared__ __attribute__((aligned(16))) float sA2[2][64 * FLDK];
+    __shared__ __attribute__((aligned(16))) float sB1[2][FBK * FLDN];
+    __shared__ __attribute__((aligned(16))) float sB2[2][FBK * FLDN];
+
+    const unsigned Hh = H / 2;
+    const unsigned z = blockIdx.x / tiles_per_frame;
+    unsigned tm, tn;
+    tile_of_block(blockIdx.x % tiles_per_frame, tiles_per_frame, tiles_m, tiles_n, tm, tn);
+    const unsigned p0 = tm * 64, n0 = tn * 128;          // p0: first output pair (i or n) of the tile
+    const float* __restrict__ IN = INz + (size_t)z * H * W;
+    float* __restrict__ OUT = OUTz + (size_t)z * H * W;
+
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63, wave = tid >> 6;
+    const unsigned wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+    const unsigned lr = lane & 31, lh = lane >> 5;
+
+    const unsigned srow = tid >> 2, sk = (tid & 3) * 4;           // basis: row = tid/4, k quad
+    const unsigned bk = tid >> 5, bn = (tid & 31) * 4;            // image: k row = bk + 8p, n quad
+    unsigned ra = p0 + srow; ra = ra < Hh ? ra : Hh - 1;
+    const float* a1_row = A1g + (size_t)ra * Kp;
+    const float* a2_row = A2g + (size_t)ra * Kp;
+    const unsigned ncol = (n0 + bn) < W ? (n0 + bn) : W - 4;      // clamped: feeds outputs never stored
+
+    f32x16 acc1[2], acc2[2], tot1[2], tot2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { zero16(acc1[i]); zero16(acc2[i]); zero16(tot1[i]); zero16(tot2[i]); }
+
+    f32x4 ra1, ra2, ru[2], rv[2];
+    auto gload = [&](unsigned t) {
+        const unsigned k = t * FBK + sk;
+        ra1 = *reinterpret_cast<const f32x4*>(a1_row + k);
+        ra2 = *reinterpret_cast<const f32x4*>(a2_row + k);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            unsigned kk = t * FBK + bk + 8 * p;                   // index along the folded sum axis
+            kk = kk < Hh ? kk : Hh - 1;                           // past the end: any valid row x zero basis
+            if (!INVERSE) {                                       // rows kk and H-1-kk
+                ru[p] = *reinterpret_cast<const f32x4*>(IN + (size_t)kk * W + ncol);
+                rv[p] = *reinterpret_cast<const f32x4*>(IN + (size_t)(H - 1 - kk) * W + ncol);
+            } else {                                              // rows 2kk and 2kk+1
+                ru[p] = *reinterpret_cast<const f32x4*>(IN + (size_t)(2 * kk) * W + ncol);
+                rv[p] = *reinterpret_cast<const f32x4*>(IN + (size_t)(2 * kk + 1) * W + ncol);
+            }
+        }
+    };
+    auto lstore = [&](unsigned buf) {
+        *reinterpret_cast<f32x4*>(&sA1[buf][srow * FLDK + sk]) = ra1;
+        *reinterpret_cast<f32x4*>(&sA2[buf][srow * FLDK + sk]) = ra2;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x4 v1 = INVERSE ? ru[p] : ru[p] + rv[p];
+            const f32x4 v2 = INVERSE ? rv[p] : ru[p] - rv[p];
+            *reinterpret_cast<f32x4*>(&sB1[buf][(bk + 8 * p) * FLDN + bn]) = v1;
+            *reinterpret_cast<f32x4*>(&sB2[buf][(bk + 8 * p) * FLDN + bn]) = v2;
+        }
+    };
+
+    const unsigned nk = Kp / FBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (unsigned t = 0; t < nk; ++t) {
+        const unsigned cur = t & 1;
+        if (t + 1 < nk) gload(t + 1);
+#pragma unroll
+        for (int kg = 0; kg < FBK / 8; ++kg) {
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sA1[cur][(wm + lr) * FLDK + kg * 8 + lh * 4]);
+            const f32x4 a2 = *reinterpret_cast<const f32x4*>(&sA2[cur][(wm + lr) * FLDK + kg * 8 + lh * 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned krow = kg * 8 + lh * 4 + j;
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    const float b1 = sB1[cur][krow * FLDN + wn + 32 * jn + lr];
+                    const float b2 = sB2[cur][krow * FLDN + wn + 32 * jn + lr];
+                    acc1[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1, acc1[jn], 0, 0, 0);
+                    acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], b2, acc2[jn], 0, 0, 0);
+                }
+            }
+        }
+        if ((t + 1) % FCHUNK == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                tot1[i] += acc1[i]; zero16(acc1[i]);
+                tot2[i] += acc2[i]; zero16(acc2[i]);
+            }
+        }
+        if (t + 1 < nk) lstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { acc1[i] = tot1[i] + acc1[i]; acc2[i] = tot2[i] + acc2[i]; }
+
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const unsigned col = n0 + wn + 32 * jn + lr;
+        if (col >= W) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned pair = p0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (pair >= Hh) continue;
+            if (!INVERSE) {
+                OUT[(size_t)(2 * pair) * W + col] = apply_epilogue(ep, acc1[jn][r], 2 * pair);
+                OUT[(size_t)(2 * pair + 1) * W + col] = apply_epilogue(ep, acc2[jn][r], 2 * pair + 1);
+            } else {
+                OUT[(size_t)pair * W + col] = apply_epilogue(ep, acc1[jn][r] + acc2[jn][r], pair);
+                OUT[(size_t)(H - 1 - pair) * W + col] = apply_epilogue(ep, acc1[jn][r] - acc2[jn][r], H - 1 - pair);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------------
+bool dct_rows_can_fold(size_t w, const float* in, const float* out) {
+    return w >= 16 && (w % 8 == 0) && aligned16(in) && aligned16(out);
+}
+bool dct_cols_can_fold(size_t w, size_t h, const float* in, const float* out) {
+    return h >= 16 && (h % 8 == 0) && (w % 4 == 0) && aligned16(in) && aligned16(out);
+}
+
+int launch_dct_rows_folded_f32(hipStream_t st, bool inverse, const float* in, float* out, size_t rows,
+                               size_t w, const float* b1, const float* b2, Epilogue ep) {
+    if (rows == 0) return SSW_OK;
+    if (rows > 0xFFFFFFFFull || w > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned M = (unsigned)rows, W = (unsigned)w, Nh = W / 2, Kp = (unsigned)half_basis_kpad(w);
+    const unsigned tiles_m = (M + 127) / 128, tiles_n = (Nh + 63) / 64;
+    const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if (inverse) dct_rows_folded_f32_kernel<true><<<(unsigned)nblk, FT, 0, st>>>(in, b1, b2, out, M, W, Kp, tiles_m, tiles_n, ep);
+    else         dct_rows_folded_f32_kernel<false><<<(unsigned)nblk, FT, 0, st>>>(in, b1, b2, out, M, W, Kp, tiles_m, tiles_n, ep);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+int launch_dct_cols_folded_f32(hipStream_t st, bool inverse, const float* in, float* out, size_t n_frames,
+                               size_t w, size_t h, const float* a1, const float* a2, Epilogue ep) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned H = (unsigned)h, W = (unsigned)w, Hh = H / 2, Kp = (unsigned)half_basis_kpad(h);
+    const unsigned tiles_m = (Hh + 63) / 64, tiles_n = (W + 127) / 128;
+    const unsigned tiles_per_frame = tiles_m * tiles_n;
+    const unsigned long long nblk = (unsigned long long)tiles_per_frame * n_frames;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if (inverse) dct_cols_folded_f32_kernel<true><<<(unsigned)nblk, FT, 0, st>>>(a1, a2, in, out, H, W, Kp, tiles_m, tiles_n, tiles_per_frame, ep);
+    else         dct_cols_folded_f32_kernel<false><<<(unsigned)nblk, FT, 0, st>>>(a1, a2, in, out, H, W, Kp, tiles_m, tiles_n, tiles_per_frame, ep);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+}  // namespace ssw

@@ -61,6 +61,17 @@ int launch_dct_rows(hipStream_t st, int precision, const float* in, float* out, 
 int launch_dct_cols(hipStream_t st, int precision, const float* in, float* out, size_t n_frames,
                     size_t w, size_t h, const void* basis, Epilogue ep);
 
+// dct_folded.hip: even/odd-folded f32 GEMMs (half the multiply-adds); see the file header.
+// Half bases: (N/2)x(N/2), layout [out][sum], parity 0 = even frequencies, 1 = odd.
+size_t half_basis_kpad(size_t n);   // row stride of a half basis: N/2 rounded up to the k-step, zero padded
+int launch_make_half_basis_f32(hipStream_t st, size_t n, bool inverse, int parity, float* out);
+bool dct_rows_can_fold(size_t w, const float* in, const float* out);
+bool dct_cols_can_fold(size_t w, size_t h, const float* in, const float* out);
+int launch_dct_rows_folded_f32(hipStream_t st, bool inverse, const float* in, float* out, size_t rows,
+                               size_t w, const float* b_even, const float* b_odd, Epilogue ep);
+int launch_dct_cols_folded_f32(hipStream_t st, bool inverse, const float* in, float* out, size_t n_frames,
+                               size_t w, size_t h, const float* b_even, const float* b_odd, Epilogue ep);
+
 // select.hip
 struct SelectWorkspace {
     uint32_t* hist = nullptr;       // [n_frames][2048]
@@ -91,8 +102,10 @@ struct ssw_ctx {
     hipStream_t stream = nullptr;
     size_t chunk_frames = 16;
 
-    // basis cache: (N, inverse, f64) -> device pointer
-    std::map<std::tuple<size_t, bool, bool>, void*> basis;
+    // basis cache: (N, inverse, f64, kind) -> device pointer; kind 0 = dense N x N,
+    // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded f32 kernels
+    std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
+    bool fold = true;             // use the even/odd-folded f32 GEMMs where the shape allows
 
     // growable scratch
     struct Buf {

@@ -108,14 +108,16 @@ int flush_timers(ssw_ctx* ctx) {
     return SSW_OK;
 }
 
-int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, const void** out) {
-    auto key = std::make_tuple(n, inverse, f64);
+int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const void** out) {
+    auto key = std::make_tuple(n, inverse, f64, kind);
     auto it = ctx->basis.find(key);
     if (it != ctx->basis.end()) { *out = it->second; return SSW_OK; }
     void* p = nullptr;
-    SSW_HIP_CHECK(hipMalloc(&p, n * n * (f64 ? sizeof(double) : sizeof(float))));
-    int rc = f64 ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
-                 : launch_make_basis_f32(ctx->stream, n, inverse, (float*)p);
+    const size_t elems = kind == 0 ? n * n : (n / 2) * half_basis_kpad(n);
+    SSW_HIP_CHECK(hipMalloc(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float))));
+    int rc = kind != 0 ? launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p)
+             : f64     ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
+                       : launch_make_basis_f32(ctx->stream, n, inverse, (float*)p);
     if (rc != SSW_OK) { (void)hipFree(p); return rc; }
     ctx->basis[key] = p;
     *out = p;
@@ -138,9 +140,6 @@ int check_config(const ssw_config* cfg) {
 int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size_t h, float* data, float* tmp) {
     const bool inverse = (type == SSW_DCT3);
     const bool f64 = (precision == SSW_PRECISION_F64);
-    const void *bw = nullptr, *bh = nullptr;
-    SSW_TRY(get_basis(ctx, w, inverse, f64, &bw));
-    SSW_TRY(get_basis(ctx, h, inverse, f64, &bh));
     const bool rows_first = (w >= h);                                  // src/dct2d.rs:93-98
     Epilogue plain{0, 0.f, 0.f, 0.f};
     auto ortho = [&](size_t len) {                                      // src/dct2d.rs:154-155
@@ -154,12 +153,24 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         const float* src = (pass == 0) ? data : tmp;
         float* dst = (pass == 0) ? tmp : data;
         Epilogue ep = (type == SSW_DCT2_ORTHOGONAL) ? ortho(is_row ? w : h) : (pass == 1 ? last : plain);
+        const bool fold = ctx->fold && !f64 &&
+                          (is_row ? dct_rows_can_fold(w, src, dst) : dct_cols_can_fold(w, h, src, dst));
+        const size_t len = is_row ? w : h;
+        const void *b0 = nullptr, *b1 = nullptr;
+        if (fold) {
+            SSW_TRY(get_basis(ctx, len, inverse, false, 1, &b0));
+            SSW_TRY(get_basis(ctx, len, inverse, false, 2, &b1));
+        } else {
+            SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
+        }
         if (is_row) {
             StageTimer t(ctx, SSW_STAGE_DCT_ROW);
-            SSW_TRY(launch_dct_rows(ctx->stream, precision, src, dst, n * h, w, bw, ep));
+            if (fold) SSW_TRY(launch_dct_rows_folded_f32(ctx->stream, inverse, src, dst, n * h, w, (const float*)b0, (const float*)b1, ep));
+            else      SSW_TRY(launch_dct_rows(ctx->stream, precision, src, dst, n * h, w, b0, ep));
         } else {
             StageTimer t(ctx, SSW_STAGE_DCT_COL);
-            SSW_TRY(launch_dct_cols(ctx->stream, precision, src, dst, n, w, h, bh, ep));
+            if (fold) SSW_TRY(launch_dct_cols_folded_f32(ctx->stream, inverse, src, dst, n, w, h, (const float*)b0, (const float*)b1, ep));
+            else      SSW_TRY(launch_dct_cols(ctx->stream, precision, src, dst, n, w, h, b0, ep));
         }
     }
     return SSW_OK;
@@ -255,6 +266,12 @@ void* ssw_ctx_stream(ssw_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames) {
     if (!ctx || frames == 0) return SSW_ERR_BAD_ARG;
     ctx->chunk_frames = frames;
+    return SSW_OK;
+}
+
+int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int enable) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    ctx->fold = enable != 0;
     return SSW_OK;
 }
 

@@ -44,7 +44,7 @@ def test_cpp_doc_test_flow_matches_oracle(tmp_path):
     ref_marked = O.embed_frame(rgb, mark)
     ref_ext, ref_sim = O.extract_frame(rgb, ref_marked, mark)
     assert np.abs(marked - ref_marked).max() <= 5e-6
-    assert np.median(np.abs(ext - ref_ext)) <= 1e-5
+    assert np.median(np.abs(ext - ref_ext)) <= 5e-5        # f32 precision, small frame
     assert abs(float(vals["similarity"]) - ref_sim) < 1e-3 * abs(ref_sim)
     assert vals["exceeds6"] == "1" and vals["consumed_ok"] == "1" and vals["too_large_ok"] == "1"
     assert abs(float(vals["random"])) < 5.0

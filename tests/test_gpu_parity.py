@@ -118,6 +118,26 @@ def test_dct_f32_mfma_within_tolerance(shape, dct_type):
     assert np.abs(got.astype(np.float64) - ref).max() <= (4e-6 if dct_type == L.DCT3 else 1e-6) * scale
 
 
+@pytest.mark.parametrize("shape", [(16, 16), (64, 128), (72, 136), (200, 328), (1080, 1920)])
+@pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
+def test_dct_folded_equals_dense_within_f32_rounding(shape, dct_type):
+    """The even/odd-folded f32 GEMMs (default where W%8 == 0 / H%8 == 0) against the dense ones."""
+    rng = np.random.default_rng(shape[0] + shape[1])
+    x = rng.random((2,) + shape).astype(np.float32)
+    if dct_type == L.DCT3:
+        x = np.stack([O.dct2d(p, O.DCT2) for p in x])
+    folded = G.dct2d(x, dct_type, F32)
+    G.ctx().set_dct_folding(False)
+    try:
+        dense = G.dct2d(x, dct_type, F32)
+    finally:
+        G.ctx().set_dct_folding(True)
+    assert not np.array_equal(folded, dense)                      # really two different code paths
+    ref = np.stack([O.dct2d(p, dct_type) for p in x])
+    tol = (4e-6 if dct_type == L.DCT3 else 1e-6) * np.abs(ref).max()
+    assert np.abs(folded - ref).max() <= tol and np.abs(dense - ref).max() <= tol
+
+
 @pytest.mark.parametrize("precision", [F32, F64])
 def test_dct_batched_equals_single(precision):
     rng = np.random.default_rng(2)
