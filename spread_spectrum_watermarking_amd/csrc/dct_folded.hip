@@ -16,9 +16,12 @@
 // Every kernel is "two GEMMs sharing one tile geometry": acc1 = A1*B1, acc2 = A2*B2.
 //   rows (NT):  A = image rows (k-contiguous), B = half bases (k-contiguous)
 //   cols (NN):  A = half bases (k-contiguous), B = image rows of one frame (n-contiguous)
-// Block tile: 128 x 64 output pairs (= 128 x 128 outputs) x 16 k, 256 threads = 4 waves as 2 x 2,
-// each wave 4 MFMA 32x32x2 tiles (2 for acc1, 2 for acc2), LDS double-buffered, one barrier per
-// k-step, two-level accumulation every 256 k as in dct.hip.
+// Block: 256 threads = 4 waves as 2 x 2, k-step 16, LDS double-buffered, one barrier per k-step,
+// two-level accumulation every 256 k as in dct.hip.  Template parameter SUB = 32-wide MFMA
+// sub-tiles per wave along the image axis:
+//   SUB = 2: block tile 128 x 64 pairs (= 128 x 128 outputs), 4 MFMA tiles per wave, 2 blocks/CU
+//   SUB = 1: block tile  64 x 64 pairs (=  64 x 128 outputs), 2 MFMA tiles per wave, 3 blocks/CU
+// (more resident waves per SIMD de-correlate the per-k-step barriers of different blocks).
 #include "dct_common.hpp"
 
 namespace ssw {
@@ -26,7 +29,6 @@ namespace ssw {
 constexpr int FT = 256;                 // threads
 constexpr int FBK = 16;                 // k per step
 constexpr int FLDK = FBK + 4;           // 20-float rows: conflict-free ds_read_b128 for the 32x32 lane map
-constexpr int FLDN = 128 + 4;
 constexpr int FCHUNK = 16;              // k-steps per accumulation chunk (256 k)
 
 // ---------------------------------------------------------------------------------------------
@@ -72,31 +74,32 @@ __device__ inline void zero16(f32x16& v) {
 // ---------------------------------------------------------------------------------------------
 // Row pass.  X: M x W (rows of all frames of the chunk), OUT: M x W.  Nh = W/2.
 // ---------------------------------------------------------------------------------------------
-template <bool INVERSE>
-__global__ __launch_bounds__(FT, 2) void dct_rows_folded_f32_kernel(
+template <bool INVERSE, int SUB>
+__global__ __launch_bounds__(FT, SUB == 1 ? 3 : 2) void dct_rows_folded_f32_kernel(
     const float* __restrict__ X, const float* __restrict__ B1g, const float* __restrict__ B2g,
     float* __restrict__ OUT, unsigned M, unsigned W, unsigned Kp, unsigned tiles_m, unsigned tiles_n,
     Epilogue ep) {
-    __shared__ __attribute__((aligned(16))) float sA1[2][128 * FLDK];
-    __shared__ __attribute__((aligned(16))) float sA2[2][128 * FLDK];
+    constexpr int BMR = 64 * SUB;                        // image rows per block
+    __shared__ __attribute__((aligned(16))) float sA1[2][BMR * FLDK];
+    __shared__ __attribute__((aligned(16))) float sA2[2][BMR * FLDK];
     __shared__ __attribute__((aligned(16))) float sB1[2][64 * FLDK];
     __shared__ __attribute__((aligned(16))) float sB2[2][64 * FLDK];
 
     const unsigned Nh = W / 2;
     unsigned tm, tn;
     tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
-    const unsigned m0 = tm * 128, p0 = tn * 64;          // p0: first output pair (j or n) of the tile
+    const unsigned m0 = tm * BMR, p0 = tn * 64;          // p0: first output pair (j or n) of the tile
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
-    const unsigned wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
+    const unsigned wm = (wave >> 1) * 32 * SUB, wn = (wave & 1) * 32;
     const unsigned lr = lane & 31, lh = lane >> 5;
 
-    // staging: A rows = tid/4 + 64p (p = 0,1), B row = tid/4, k quad = tid%4
+    // staging: A rows = tid/4 + 64p (p < SUB), B row = tid/4, k quad = tid%4
     const unsigned srow = tid >> 2, sk = (tid & 3) * 4;
-    const float* a_rows[2];
+    const float* a_rows[SUB];
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < SUB; ++p) {
         unsigned r = m0 + srow + 64 * p; r = r < M ? r : M - 1;
         a_rows[p] = X + (size_t)r * W;
     }
@@ -104,18 +107,18 @@ __global__ __launch_bounds__(FT, 2) void dct_rows_folded_f32_kernel(
     const float* b1_row = B1g + (size_t)rb * Kp;
     const float* b2_row = B2g + (size_t)rb * Kp;
 
-    f32x16 acc1[2], acc2[2], tot1[2], tot2[2];
+    f32x16 acc1[SUB], acc2[SUB], tot1[SUB], tot2[SUB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { zero16(acc1[i]); zero16(acc2[i]); zero16(tot1[i]); zero16(tot2[i]); }
+    for (int i = 0; i < SUB; ++i) { zero16(acc1[i]); zero16(acc2[i]); zero16(tot1[i]); zero16(tot2[i]); }
 
     // Unconditional loads (no tail predication: the basis is zero-padded along k, image addresses
     // are clamped); the +/- folding is done when the registers are written to LDS, i.e. after the
-    // MFMA block of the current step, so the loads stay in flight behind it.
-    f32x4 ru[2], rv[2], rb1, rb2;
+    // first MFMA group of the current step, so the loads stay in flight behind it.
+    f32x4 ru[SUB], rv[SUB], rb1, rb2;
     auto gload = [&](unsigned t) {
         const unsigned k = t * FBK + sk;                 // index along the folded sum axis, < Kp
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < SUB; ++p) {
             if (!INVERSE) {                              // x[k..k+3] and the mirror quad starting at W-4-k
                 ru[p] = *reinterpret_cast<const f32x4*>(a_rows[p] + k);
                 rv[p] = *reinterpret_cast<const f32x4*>(a_rows[p] + (W - 4 - k));
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(FT, 2) void dct_rows_folded_f32_kernel(
     };
     auto lstore = [&](unsigned buf) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < SUB; ++p) {
             f32x4 v1, v2;
             if (!INVERSE) {
                 const f32x4 f = ru[p], m = rv[p];
@@ -157,9 +160,12 @@ __global__ __launch_bounds__(FT, 2) void dct_rows_folded_f32_kernel(
         if (t + 1 < nk) gload(t + 1);
 #pragma unroll
         for (int kg = 0; kg < FBK / 8; ++kg) {
-            f32x4 a1[2], a2[2];
+            // the next tile's registers go to LDS between the two k-groups: the loads were issued a
+            // full k-group of MFMAs ago, and the ds_writes overlap the second group's MFMAs
+            if (kg == FBK / 8 - 1 && t + 1 < nk) lstore(cur ^ 1);
+            f32x4 a1[SUB], a2[SUB];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < SUB; ++i) {
                 a1[i] = *reinterpret_cast<const f32x4*>(&sA1[cur][(wm + 32 * i + lr) * FLDK + kg * 8 + lh * 4]);
                 a2[i] = *reinterpret_cast<const f32x4*>(&sA2[cur][(wm + 32 * i + lr) * FLDK + kg * 8 + lh * 4]);
             }
@@ -168,29 +174,28 @@ __global__ __launch_bounds__(FT, 2) void dct_rows_folded_f32_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < SUB; ++i) {
                     acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i][j], b1[j], acc1[i], 0, 0, 0);
                     acc2[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[i][j], b2[j], acc2[i], 0, 0, 0);
                 }
         }
         if ((t + 1) % FCHUNK == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < SUB; ++i) {
                 tot1[i] += acc1[i]; zero16(acc1[i]);
                 tot2[i] += acc2[i]; zero16(acc2[i]);
             }
         }
-        if (t + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { acc1[i] = tot1[i] + acc1[i]; acc2[i] = tot2[i] + acc2[i]; }
+    for (int i = 0; i < SUB; ++i) { acc1[i] = tot1[i] + acc1[i]; acc2[i] = tot2[i] + acc2[i]; }
 
     // C/D map: col = lane & 31 (output pair), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const unsigned pair = p0 + wn + lr;
     if (pair < Nh) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < SUB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const unsigned row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -210,47 +215,51 @@ __global__ __launch_bounds__(FT, 2) void dct_rows_folded_f32_kernel(
 // ---------------------------------------------------------------------------------------------
 // Column pass.  One frame per z: IN, OUT: H x W.  Hh = H/2.
 // ---------------------------------------------------------------------------------------------
-template <bool INVERSE>
-__global__ __launch_bounds__(FT, 2) void dct_cols_folded_f32_kernel(
+template <bool INVERSE, int SUB>
+__global__ __launch_bounds__(FT, SUB == 1 ? 3 : 2) void dct_cols_folded_f32_kernel(
     const float* __restrict__ A1g, const float* __restrict__ A2g, const float* __restrict__ INz,
     float* __restrict__ OUTz, unsigned H, unsigned W, unsigned Kp, unsigned tiles_m, unsigned tiles_n,
     unsigned tiles_per_frame, Epilogue ep) {
+    constexpr int BNC = 64 * SUB;                        // image columns per block
+    constexpr int LDN = BNC + 4;
     __shared__ __attribute__((aligned(16))) float sA1[2][64 * FLDK];
     __shared__ __attribute__((aligned(16))) float sA2[2][64 * FLDK];
-    __shared__ __attribute__((aligned(16))) float sB1[2][FBK * FLDN];
-    __shared__ __attribute__((aligned(16))) float sB2[2][FBK * FLDN];
+    __shared__ __attribute__((aligned(16))) float sB1[2][FBK * LDN];
+    __shared__ __attribute__((aligned(16))) float sB2[2][FBK * LDN];
 
     const unsigned Hh = H / 2;
     const unsigned z = blockIdx.x / tiles_per_frame;
     unsigned tm, tn;
     tile_of_block(blockIdx.x % tiles_per_frame, tiles_per_frame, tiles_m, tiles_n, tm, tn);
-    const unsigned p0 = tm * 64, n0 = tn * 128;          // p0: first output pair (i or n) of the tile
+    const unsigned p0 = tm * 64, n0 = tn * BNC;          // p0: first output pair (i or n) of the tile
     const float* __restrict__ IN = INz + (size_t)z * H * W;
     float* __restrict__ OUT = OUTz + (size_t)z * H * W;
 
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
-    const unsigned wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+    const unsigned wm = (wave >> 1) * 32, wn = (wave & 1) * 32 * SUB;
     const unsigned lr = lane & 31, lh = lane >> 5;
 
     const unsigned srow = tid >> 2, sk = (tid & 3) * 4;           // basis: row = tid/4, k quad
-    const unsigned bk = tid >> 5, bn = (tid & 31) * 4;            // image: k row = bk + 8p, n quad
+    // image: SUB == 2: k row = tid/32 + 8p (p < 2), n quad = tid%32;  SUB == 1: k row = tid/16, n quad = tid%16
+    constexpr int QPR = BNC / 4;                                  // quads per image row of the tile
+    const unsigned bk = tid / QPR, bn = (tid % QPR) * 4;
     unsigned ra = p0 + srow; ra = ra < Hh ? ra : Hh - 1;
     const float* a1_row = A1g + (size_t)ra * Kp;
     const float* a2_row = A2g + (size_t)ra * Kp;
     const unsigned ncol = (n0 + bn) < W ? (n0 + bn) : W - 4;      // clamped: feeds outputs never stored
 
-    f32x16 acc1[2], acc2[2], tot1[2], tot2[2];
+    f32x16 acc1[SUB], acc2[SUB], tot1[SUB], tot2[SUB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { zero16(acc1[i]); zero16(acc2[i]); zero16(tot1[i]); zero16(tot2[i]); }
+    for (int i = 0; i < SUB; ++i) { zero16(acc1[i]); zero16(acc2[i]); zero16(tot1[i]); zero16(tot2[i]); }
 
-    f32x4 ra1, ra2, ru[2], rv[2];
+    f32x4 ra1, ra2, ru[SUB], rv[SUB];
     auto gload = [&](unsigned t) {
         const unsigned k = t * FBK + sk;
         ra1 = *reinterpret_cast<const f32x4*>(a1_row + k);
         ra2 = *reinterpret_cast<const f32x4*>(a2_row + k);
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < SUB; ++p) {
             unsigned kk = t * FBK + bk + 8 * p;                   // index along the folded sum axis
             kk = kk < Hh ? kk : Hh - 1;                           // past the end: any valid row x zero basis
             if (!INVERSE) {                                       // rows kk and H-1-kk
@@ -266,11 +275,11 @@ __global__ __launch_bounds__(FT, 2) void dct_cols_folded_f32_kernel(
         *reinterpret_cast<f32x4*>(&sA1[buf][srow * FLDK + sk]) = ra1;
         *reinterpret_cast<f32x4*>(&sA2[buf][srow * FLDK + sk]) = ra2;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < SUB; ++p) {
             const f32x4 v1 = INVERSE ? ru[p] : ru[p] + rv[p];
             const f32x4 v2 = INVERSE ? rv[p] : ru[p] - rv[p];
-            *reinterpret_cast<f32x4*>(&sB1[buf][(bk + 8 * p) * FLDN + bn]) = v1;
-            *reinterpret_cast<f32x4*>(&sB2[buf][(bk + 8 * p) * FLDN + bn]) = v2;
+            *reinterpret_cast<f32x4*>(&sB1[buf][(bk + 8 * p) * LDN + bn]) = v1;
+            *reinterpret_cast<f32x4*>(&sB2[buf][(bk + 8 * p) * LDN + bn]) = v2;
         }
     };
 
@@ -283,15 +292,16 @@ __global__ __launch_bounds__(FT, 2) void dct_cols_folded_f32_kernel(
         if (t + 1 < nk) gload(t + 1);
 #pragma unroll
         for (int kg = 0; kg < FBK / 8; ++kg) {
+            if (kg == FBK / 8 - 1 && t + 1 < nk) lstore(cur ^ 1);
             const f32x4 a1 = *reinterpret_cast<const f32x4*>(&sA1[cur][(wm + lr) * FLDK + kg * 8 + lh * 4]);
             const f32x4 a2 = *reinterpret_cast<const f32x4*>(&sA2[cur][(wm + lr) * FLDK + kg * 8 + lh * 4]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const unsigned krow = kg * 8 + lh * 4 + j;
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
-                    const float b1 = sB1[cur][krow * FLDN + wn + 32 * jn + lr];
-                    const float b2 = sB2[cur][krow * FLDN + wn + 32 * jn + lr];
+                for (int jn = 0; jn < SUB; ++jn) {
+                    const float b1 = sB1[cur][krow * LDN + wn + 32 * jn + lr];
+                    const float b2 = sB2[cur][krow * LDN + wn + 32 * jn + lr];
                     acc1[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1, acc1[jn], 0, 0, 0);
                     acc2[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], b2, acc2[jn], 0, 0, 0);
                 }
@@ -299,19 +309,18 @@ __global__ __launch_bounds__(FT, 2) void dct_cols_folded_f32_kernel(
         }
         if ((t + 1) % FCHUNK == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < SUB; ++i) {
                 tot1[i] += acc1[i]; zero16(acc1[i]);
                 tot2[i] += acc2[i]; zero16(acc2[i]);
             }
         }
-        if (t + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { acc1[i] = tot1[i] + acc1[i]; acc2[i] = tot2[i] + acc2[i]; }
+    for (int i = 0; i < SUB; ++i) { acc1[i] = tot1[i] + acc1[i]; acc2[i] = tot2[i] + acc2[i]; }
 
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
+    for (int jn = 0; jn < SUB; ++jn) {
         const unsigned col = n0 + wn + 32 * jn + lr;
         if (col >= W) continue;
 #pragma unroll
@@ -339,16 +348,25 @@ bool dct_cols_can_fold(size_t w, size_t h, const float* in, const float* out) {
     return h >= 16 && (h % 8 == 0) && (w % 4 == 0) && aligned16(in) && aligned16(out);
 }
 
+// Tile variant: the 128-wide variant is faster once the grid fills the chip (measured 114 vs 106
+// TFLOP/s at 4K x 16 frames); small launches (a single small frame) take the 64-wide one so that
+// they still produce >= 2 blocks per CU.
+static int pick_sub(unsigned long long blocks_at_sub2) { return blocks_at_sub2 >= 512 ? 2 : 1; }
+
 int launch_dct_rows_folded_f32(hipStream_t st, bool inverse, const float* in, float* out, size_t rows,
                                size_t w, const float* b1, const float* b2, Epilogue ep) {
     if (rows == 0) return SSW_OK;
     if (rows > 0xFFFFFFFFull || w > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned M = (unsigned)rows, W = (unsigned)w, Nh = W / 2, Kp = (unsigned)half_basis_kpad(w);
-    const unsigned tiles_m = (M + 127) / 128, tiles_n = (Nh + 63) / 64;
+    const int sub = pick_sub((unsigned long long)((M + 127) / 128) * ((Nh + 63) / 64));
+    const unsigned bmr = 64u * sub;
+    const unsigned tiles_m = (M + bmr - 1) / bmr, tiles_n = (Nh + 63) / 64;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-    if (inverse) dct_rows_folded_f32_kernel<true><<<(unsigned)nblk, FT, 0, st>>>(in, b1, b2, out, M, W, Kp, tiles_m, tiles_n, ep);
-    else         dct_rows_folded_f32_kernel<false><<<(unsigned)nblk, FT, 0, st>>>(in, b1, b2, out, M, W, Kp, tiles_m, tiles_n, ep);
+#define SSW_LAUNCH_ROWS(INV, SUBV) dct_rows_folded_f32_kernel<INV, SUBV><<<(unsigned)nblk, FT, 0, st>>>(in, b1, b2, out, M, W, Kp, tiles_m, tiles_n, ep)
+    if (sub == 1) { if (inverse) SSW_LAUNCH_ROWS(true, 1); else SSW_LAUNCH_ROWS(false, 1); }
+    else          { if (inverse) SSW_LAUNCH_ROWS(true, 2); else SSW_LAUNCH_ROWS(false, 2); }
+#undef SSW_LAUNCH_ROWS
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
@@ -358,12 +376,16 @@ int launch_dct_cols_folded_f32(hipStream_t st, bool inverse, const float* in, fl
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned H = (unsigned)h, W = (unsigned)w, Hh = H / 2, Kp = (unsigned)half_basis_kpad(h);
-    const unsigned tiles_m = (Hh + 63) / 64, tiles_n = (W + 127) / 128;
+    const int sub = pick_sub((unsigned long long)((Hh + 63) / 64) * ((W + 127) / 128) * n_frames);
+    const unsigned bnc = 64u * sub;
+    const unsigned tiles_m = (Hh + 63) / 64, tiles_n = (W + bnc - 1) / bnc;
     const unsigned tiles_per_frame = tiles_m * tiles_n;
     const unsigned long long nblk = (unsigned long long)tiles_per_frame * n_frames;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-    if (inverse) dct_cols_folded_f32_kernel<true><<<(unsigned)nblk, FT, 0, st>>>(a1, a2, in, out, H, W, Kp, tiles_m, tiles_n, tiles_per_frame, ep);
-    else         dct_cols_folded_f32_kernel<false><<<(unsigned)nblk, FT, 0, st>>>(a1, a2, in, out, H, W, Kp, tiles_m, tiles_n, tiles_per_frame, ep);
+#define SSW_LAUNCH_COLS(INV, SUBV) dct_cols_folded_f32_kernel<INV, SUBV><<<(unsigned)nblk, FT, 0, st>>>(a1, a2, in, out, H, W, Kp, tiles_m, tiles_n, tiles_per_frame, ep)
+    if (sub == 1) { if (inverse) SSW_LAUNCH_COLS(true, 1); else SSW_LAUNCH_COLS(false, 1); }
+    else          { if (inverse) SSW_LAUNCH_COLS(true, 2); else SSW_LAUNCH_COLS(false, 2); }
+#undef SSW_LAUNCH_COLS
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
