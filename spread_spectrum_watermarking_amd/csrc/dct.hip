@@ -31,30 +31,35 @@ __device__ inline double basis_value(size_t out_idx, size_t sum_idx, size_t n, b
     return sum_idx == 0 ? 0.25 : 0.5 * c;
 }
 
-__global__ void make_basis_f32_kernel(size_t n, bool inverse, float* out) {
-    const size_t total = n * n;
+// Basis rows are zero-padded to a multiple of 32 along the sum axis (row stride = dense_basis_kpad):
+// the aligned GEMM main loops then run without tail predication (operand loads past the end of the
+// sum axis are clamped to valid addresses and meet a zero basis entry).
+size_t dense_basis_kpad(size_t n) { return (n + 31) / 32 * 32; }
+
+__global__ void make_basis_f32_kernel(size_t n, size_t kpad, bool inverse, float* out) {
+    const size_t total = n * kpad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x)
-        out[i] = (float)basis_value(i / n, i % n, n, inverse);
+        out[i] = (i % kpad) < n ? (float)basis_value(i / kpad, i % kpad, n, inverse) : 0.0f;
 }
-__global__ void make_basis_f64_kernel(size_t n, bool inverse, double* out) {
-    const size_t total = n * n;
+__global__ void make_basis_f64_kernel(size_t n, size_t kpad, bool inverse, double* out) {
+    const size_t total = n * kpad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x)
-        out[i] = basis_value(i / n, i % n, n, inverse);
+        out[i] = (i % kpad) < n ? basis_value(i / kpad, i % kpad, n, inverse) : 0.0;
 }
 
 int launch_make_basis_f32(hipStream_t st, size_t n, bool inverse, float* out) {
-    const size_t total = n * n;
+    const size_t total = n * dense_basis_kpad(n);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    make_basis_f32_kernel<<<blocks, 256, 0, st>>>(n, inverse, out);
+    make_basis_f32_kernel<<<blocks, 256, 0, st>>>(n, dense_basis_kpad(n), inverse, out);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
 int launch_make_basis_f64(hipStream_t st, size_t n, bool inverse, double* out) {
-    const size_t total = n * n;
+    const size_t total = n * dense_basis_kpad(n);
     const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    make_basis_f64_kernel<<<blocks, 256, 0, st>>>(n, inverse, out);
+    make_basis_f64_kernel<<<blocks, 256, 0, st>>>(n, dense_basis_kpad(n), inverse, out);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
@@ -79,7 +84,7 @@ constexpr int ACC_CHUNK = 8;
 template <bool ALIGNED>
 __global__ __launch_bounds__(THREADS, 2) void dct_rows_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ OUT,
-    unsigned M, unsigned N, unsigned K, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
+    unsigned M, unsigned N, unsigned K, unsigned Kb, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][BM * LDK];   // [buf][A|B][row*LDK + k]
 
     unsigned tm, tn;
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(THREADS, 2) void dct_rows_f32_kernel(
         unsigned ra = m0 + srow + 32 * p; ra = ra < M ? ra : M - 1;     // clamp: rows past the edge
         unsigned rb = n0 + srow + 32 * p; rb = rb < N ? rb : N - 1;     // feed outputs never stored
         a_rows[p] = A + (size_t)ra * K;
-        b_rows[p] = B + (size_t)rb * K;
+        b_rows[p] = B + (size_t)rb * Kb;
     }
 
     f32x16 acc[2][2], tot[2][2];
@@ -111,12 +116,12 @@ __global__ __launch_bounds__(THREADS, 2) void dct_rows_f32_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
-    const unsigned nk = (K + BK - 1) / BK;
+    const unsigned nk = ALIGNED ? Kb / BK : (K + BK - 1) / BK;
     f32x4 ra[4], rb[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        ra[p] = load_k4<ALIGNED>(a_rows[p], sk, K);
-        rb[p] = load_k4<ALIGNED>(b_rows[p], sk, K);
+        ra[p] = load_img_k4<ALIGNED>(a_rows[p], sk, K);
+        rb[p] = load_basis_k4<ALIGNED>(b_rows[p], sk, K);
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(THREADS, 2) void dct_rows_f32_kernel(
             const unsigned k = (t + 1) * BK + sk;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                ra[p] = load_k4<ALIGNED>(a_rows[p], k, K);
-                rb[p] = load_k4<ALIGNED>(b_rows[p], k, K);
+                ra[p] = load_img_k4<ALIGNED>(a_rows[p], k, K);
+                rb[p] = load_basis_k4<ALIGNED>(b_rows[p], k, K);
             }
         }
         const float* As = lds[cur][0];
@@ -200,8 +205,8 @@ __global__ __launch_bounds__(THREADS, 2) void dct_rows_f32_kernel(
 template <bool ALIGNED>
 __global__ __launch_bounds__(THREADS, 2) void dct_cols_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ Bz, float* __restrict__ OUTz,
-    unsigned M, unsigned N, unsigned K, unsigned tiles_m, unsigned tiles_n, unsigned tiles_per_frame,
-    Epilogue ep) {
+    unsigned M, unsigned N, unsigned K, unsigned Kb, unsigned tiles_m, unsigned tiles_n,
+    unsigned tiles_per_frame, Epilogue ep) {
     __shared__ __attribute__((aligned(16))) float ldsA[2][BM * LDK];
     __shared__ __attribute__((aligned(16))) float ldsB[2][BK * LDN];
 
@@ -224,7 +229,7 @@ __global__ __launch_bounds__(THREADS, 2) void dct_cols_f32_kernel(
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         unsigned ra = m0 + srow + 32 * p; ra = ra < M ? ra : M - 1;
-        a_rows[p] = A + (size_t)ra * K;
+        a_rows[p] = A + (size_t)ra * Kb;
     }
 
     f32x16 acc[2][2], tot[2][2];
@@ -235,14 +240,14 @@ __global__ __launch_bounds__(THREADS, 2) void dct_cols_f32_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
 
-    const unsigned nk = (K + BK - 1) / BK;
+    const unsigned nk = ALIGNED ? Kb / BK : (K + BK - 1) / BK;
     f32x4 ra[4], rb[4];
     auto gload = [&](unsigned t) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            ra[p] = load_k4<ALIGNED>(a_rows[p], t * BK + sk, K);
+            ra[p] = load_basis_k4<ALIGNED>(a_rows[p], t * BK + sk, K);
             const unsigned kk = t * BK + bk + 8 * p;
-            rb[p] = load_n4<ALIGNED>(B + (size_t)(kk < K ? kk : 0) * N, n0 + bn, N, kk < K);
+            rb[p] = load_img_n4<ALIGNED>(B, kk, K, n0 + bn, N);
         }
     };
     auto lstore = [&](unsigned buf) {
@@ -327,11 +332,9 @@ constexpr int LDN64 = BN + 4;
 template <bool ALIGNED>
 __device__ inline void load_k4_f64(const double* __restrict__ row, unsigned k, unsigned K, double v[4]) {
     v[0] = v[1] = v[2] = v[3] = 0.0;
-    if (ALIGNED) {
-        if (k < K) {
-            const f64x4 t = *reinterpret_cast<const f64x4*>(row + k);
-            v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-        }
+    if (ALIGNED) {            // zero-padded rows: no predicate
+        const f64x4 t = *reinterpret_cast<const f64x4*>(row + k);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
     } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -341,9 +344,9 @@ __device__ inline void load_k4_f64(const double* __restrict__ row, unsigned k, u
 
 // Row pass, f64:  OUT[m][n] = sum_k A[m][k] (f32 image) * B[n][k] (f64 basis)
 template <bool ALIGNED>
-__global__ __launch_bounds__(THREADS) void dct_rows_f64_kernel(
+__global__ __launch_bounds__(THREADS, 2) void dct_rows_f64_kernel(
     const float* __restrict__ A, const double* __restrict__ B, float* __restrict__ OUT,
-    unsigned M, unsigned N, unsigned K, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
+    unsigned M, unsigned N, unsigned K, unsigned Kb, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
     __shared__ __attribute__((aligned(16))) float ldsA[2][BM * LDK32];
     __shared__ __attribute__((aligned(16))) double ldsB[2][BN * LDK64];
 
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(THREADS) void dct_rows_f64_kernel(
         unsigned ra = m0 + srow + 64 * p; ra = ra < M ? ra : M - 1;
         unsigned rb = n0 + srow + 64 * p; rb = rb < N ? rb : N - 1;
         a_rows[p] = A + (size_t)ra * K;
-        b_rows[p] = B + (size_t)rb * K;
+        b_rows[p] = B + (size_t)rb * Kb;
     }
 
     f64x4 acc[4][4];
@@ -373,13 +376,13 @@ __global__ __launch_bounds__(THREADS) void dct_rows_f64_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-    const unsigned nk = (K + BK64 - 1) / BK64;
+    const unsigned nk = ALIGNED ? Kb / BK64 : (K + BK64 - 1) / BK64;
     f32x4 ra[2];
     double rb[2][4];
     auto gload = [&](unsigned t) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            ra[p] = load_k4<ALIGNED>(a_rows[p], t * BK64 + sk, K);
+            ra[p] = load_img_k4<ALIGNED>(a_rows[p], t * BK64 + sk, K);
             load_k4_f64<ALIGNED>(b_rows[p], t * BK64 + sk, K, rb[p]);
         }
     };
@@ -437,10 +440,10 @@ __global__ __launch_bounds__(THREADS) void dct_rows_f64_kernel(
 
 // Column pass, f64:  OUT[z][m][n] = sum_k A[m][k] (f64 basis) * B[z][k][n] (f32 image)
 template <bool ALIGNED>
-__global__ __launch_bounds__(THREADS) void dct_cols_f64_kernel(
+__global__ __launch_bounds__(THREADS, 2) void dct_cols_f64_kernel(
     const double* __restrict__ A, const float* __restrict__ Bz, float* __restrict__ OUTz,
-    unsigned M, unsigned N, unsigned K, unsigned tiles_m, unsigned tiles_n, unsigned tiles_per_frame,
-    Epilogue ep) {
+    unsigned M, unsigned N, unsigned K, unsigned Kb, unsigned tiles_m, unsigned tiles_n,
+    unsigned tiles_per_frame, Epilogue ep) {
     __shared__ __attribute__((aligned(16))) double ldsA[2][BM * LDK64];
     __shared__ __attribute__((aligned(16))) float ldsB[2][BK64 * LDN64];
 
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(THREADS) void dct_cols_f64_kernel(
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         unsigned ra = m0 + srow + 64 * p; ra = ra < M ? ra : M - 1;
-        a_rows[p] = A + (size_t)ra * K;
+        a_rows[p] = A + (size_t)ra * Kb;
     }
 
     f64x4 acc[4][4];
@@ -471,7 +474,7 @@ __global__ __launch_bounds__(THREADS) void dct_cols_f64_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f64x4){0.0, 0.0, 0.0, 0.0};
 
-    const unsigned nk = (K + BK64 - 1) / BK64;
+    const unsigned nk = ALIGNED ? Kb / BK64 : (K + BK64 - 1) / BK64;
     double ra[2][4];
     f32x4 rb[2];
     auto gload = [&](unsigned t) {
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(THREADS) void dct_cols_f64_kernel(
         for (int p = 0; p < 2; ++p) {
             load_k4_f64<ALIGNED>(a_rows[p], t * BK64 + sk, K, ra[p]);
             const unsigned kk = t * BK64 + bk + 8 * p;
-            rb[p] = load_n4<ALIGNED>(B + (size_t)(kk < K ? kk : 0) * N, n0 + bn, N, kk < K);
+            rb[p] = load_img_n4<ALIGNED>(B, kk, K, n0 + bn, N);
         }
     };
     auto lstore = [&](unsigned buf) {
@@ -542,19 +545,19 @@ int launch_dct_rows(hipStream_t st, int precision, const float* in, float* out, 
                     const void* basis, Epilogue ep) {
     if (rows == 0 || w == 0) return SSW_OK;
     if (rows > 0xFFFFFFFFull || w > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const unsigned M = (unsigned)rows, N = (unsigned)w, K = (unsigned)w;
+    const unsigned M = (unsigned)rows, N = (unsigned)w, K = (unsigned)w, Kb = (unsigned)dense_basis_kpad(w);
     const unsigned tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     const bool al = (K % 4 == 0) && aligned16(in) && aligned16(basis);
     if (precision == SSW_PRECISION_F64) {
         const double* b = static_cast<const double*>(basis);
-        if (al) dct_rows_f64_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(in, b, out, M, N, K, tiles_m, tiles_n, ep);
-        else    dct_rows_f64_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(in, b, out, M, N, K, tiles_m, tiles_n, ep);
+        if (al) dct_rows_f64_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(in, b, out, M, N, K, Kb, tiles_m, tiles_n, ep);
+        else    dct_rows_f64_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(in, b, out, M, N, K, Kb, tiles_m, tiles_n, ep);
     } else {
         const float* b = static_cast<const float*>(basis);
-        if (al) dct_rows_f32_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(in, b, out, M, N, K, tiles_m, tiles_n, ep);
-        else    dct_rows_f32_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(in, b, out, M, N, K, tiles_m, tiles_n, ep);
+        if (al) dct_rows_f32_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(in, b, out, M, N, K, Kb, tiles_m, tiles_n, ep);
+        else    dct_rows_f32_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(in, b, out, M, N, K, Kb, tiles_m, tiles_n, ep);
     }
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
@@ -564,7 +567,7 @@ int launch_dct_cols(hipStream_t st, int precision, const float* in, float* out, 
                     size_t w, size_t h, const void* basis, Epilogue ep) {
     if (n_frames == 0 || w == 0 || h == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const unsigned M = (unsigned)h, N = (unsigned)w, K = (unsigned)h;
+    const unsigned M = (unsigned)h, N = (unsigned)w, K = (unsigned)h, Kb = (unsigned)dense_basis_kpad(h);
     const unsigned tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const unsigned tiles_per_frame = tiles_m * tiles_n;
     const unsigned long long nblk = (unsigned long long)tiles_per_frame * n_frames;
@@ -572,12 +575,12 @@ int launch_dct_cols(hipStream_t st, int precision, const float* in, float* out, 
     const bool al = (K % 4 == 0) && (N % 4 == 0) && aligned16(in) && aligned16(basis);
     if (precision == SSW_PRECISION_F64) {
         const double* b = static_cast<const double*>(basis);
-        if (al) dct_cols_f64_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(b, in, out, M, N, K, tiles_m, tiles_n, tiles_per_frame, ep);
-        else    dct_cols_f64_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(b, in, out, M, N, K, tiles_m, tiles_n, tiles_per_frame, ep);
+        if (al) dct_cols_f64_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(b, in, out, M, N, K, Kb, tiles_m, tiles_n, tiles_per_frame, ep);
+        else    dct_cols_f64_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(b, in, out, M, N, K, Kb, tiles_m, tiles_n, tiles_per_frame, ep);
     } else {
         const float* b = static_cast<const float*>(basis);
-        if (al) dct_cols_f32_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(b, in, out, M, N, K, tiles_m, tiles_n, tiles_per_frame, ep);
-        else    dct_cols_f32_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(b, in, out, M, N, K, tiles_m, tiles_n, tiles_per_frame, ep);
+        if (al) dct_cols_f32_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(b, in, out, M, N, K, Kb, tiles_m, tiles_n, tiles_per_frame, ep);
+        else    dct_cols_f32_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(b, in, out, M, N, K, Kb, tiles_m, tiles_n, tiles_per_frame, ep);
     }
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;

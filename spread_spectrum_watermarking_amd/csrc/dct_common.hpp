@@ -64,6 +64,33 @@ __device__ inline f32x4 load_n4(const float* __restrict__ row, unsigned n, unsig
 }
 
 
+// Image operand, k-contiguous row: aligned instances load unconditionally from a clamped address
+// (what lies past the end of the sum axis multiplies a zero-padded basis entry).
+template <bool ALIGNED>
+__device__ inline f32x4 load_img_k4(const float* __restrict__ row, unsigned k, unsigned K) {
+    if (ALIGNED) {
+        const unsigned kc = k + 4 <= K ? k : K - 4;
+        return *reinterpret_cast<const f32x4*>(row + kc);
+    }
+    return load_k4<false>(row, k, K);
+}
+// Basis operand (f32), rows zero-padded to dense_basis_kpad.
+template <bool ALIGNED>
+__device__ inline f32x4 load_basis_k4(const float* __restrict__ row, unsigned k, unsigned K) {
+    if (ALIGNED) return *reinterpret_cast<const f32x4*>(row + k);
+    return load_k4<false>(row, k, K);
+}
+// Image operand of the column pass: row kk of a K x N plane, 4 columns from n.
+template <bool ALIGNED>
+__device__ inline f32x4 load_img_n4(const float* __restrict__ plane, unsigned kk, unsigned K, unsigned n, unsigned N) {
+    if (ALIGNED) {
+        const unsigned kc = kk < K ? kk : K - 1;
+        const unsigned nc = n + 4 <= N ? n : N - 4;
+        return *reinterpret_cast<const f32x4*>(plane + (size_t)kc * N + nc);
+    }
+    return load_n4<false>(plane + (size_t)(kk < K ? kk : 0) * N, n, N, kk < K);
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace ssw

@@ -46,6 +46,7 @@ int launch_synth(hipStream_t st, uint32_t seed, uint32_t first_frame, size_t n_f
 // Basis matrices, layout [out][sum], N x N:
 //   forward: D[k][n] = 2 cos(pi k (2n+1) / 2N)          (rustdct DCT-II x the reference's x2)
 //   inverse: E[n][k] = k == 0 ? 1/4 : cos(pi k (2n+1) / 2N) / 2   (rustdct DCT-III x 1/2)
+size_t dense_basis_kpad(size_t n);   // row stride of a dense basis: N rounded up to 32, zero padded
 int launch_make_basis_f32(hipStream_t st, size_t n, bool inverse, float* out);
 int launch_make_basis_f64(hipStream_t st, size_t n, bool inverse, double* out);
 
@@ -71,6 +72,13 @@ int launch_dct_rows_folded_f32(hipStream_t st, bool inverse, const float* in, fl
                                size_t w, const float* b_even, const float* b_odd, Epilogue ep);
 int launch_dct_cols_folded_f32(hipStream_t st, bool inverse, const float* in, float* out, size_t n_frames,
                                size_t w, size_t h, const float* b_even, const float* b_odd, Epilogue ep);
+
+// dct_folded_f64.hip: the same folding in f64 (canonical precision), f64 half bases.
+int launch_make_half_basis_f64(hipStream_t st, size_t n, bool inverse, int parity, double* out);
+int launch_dct_rows_folded_f64(hipStream_t st, bool inverse, const float* in, float* out, size_t rows,
+                               size_t w, const double* b_even, const double* b_odd, Epilogue ep);
+int launch_dct_cols_folded_f64(hipStream_t st, bool inverse, const float* in, float* out, size_t n_frames,
+                               size_t w, size_t h, const double* b_even, const double* b_odd, Epilogue ep);
 
 // select.hip
 struct SelectWorkspace {
@@ -105,7 +113,7 @@ struct ssw_ctx {
     // basis cache: (N, inverse, f64, kind) -> device pointer; kind 0 = dense N x N,
     // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded f32 kernels
     std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
-    bool fold = true;             // use the even/odd-folded f32 GEMMs where the shape allows
+    bool fold = true;             // use the even/odd-folded GEMMs where the shape allows
 
     // growable scratch
     struct Buf {

@@ -113,9 +113,10 @@ int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const vo
     auto it = ctx->basis.find(key);
     if (it != ctx->basis.end()) { *out = it->second; return SSW_OK; }
     void* p = nullptr;
-    const size_t elems = kind == 0 ? n * n : (n / 2) * half_basis_kpad(n);
+    const size_t elems = kind == 0 ? n * dense_basis_kpad(n) : (n / 2) * half_basis_kpad(n);
     SSW_HIP_CHECK(hipMalloc(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float))));
-    int rc = kind != 0 ? launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p)
+    int rc = kind != 0 ? (f64 ? launch_make_half_basis_f64(ctx->stream, n, inverse, kind - 1, (double*)p)
+                              : launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p))
              : f64     ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
                        : launch_make_basis_f32(ctx->stream, n, inverse, (float*)p);
     if (rc != SSW_OK) { (void)hipFree(p); return rc; }
@@ -153,24 +154,25 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         const float* src = (pass == 0) ? data : tmp;
         float* dst = (pass == 0) ? tmp : data;
         Epilogue ep = (type == SSW_DCT2_ORTHOGONAL) ? ortho(is_row ? w : h) : (pass == 1 ? last : plain);
-        const bool fold = ctx->fold && !f64 &&
-                          (is_row ? dct_rows_can_fold(w, src, dst) : dct_cols_can_fold(w, h, src, dst));
+        const bool fold = ctx->fold && (is_row ? dct_rows_can_fold(w, src, dst) : dct_cols_can_fold(w, h, src, dst));
         const size_t len = is_row ? w : h;
         const void *b0 = nullptr, *b1 = nullptr;
         if (fold) {
-            SSW_TRY(get_basis(ctx, len, inverse, false, 1, &b0));
-            SSW_TRY(get_basis(ctx, len, inverse, false, 2, &b1));
+            SSW_TRY(get_basis(ctx, len, inverse, f64, 1, &b0));
+            SSW_TRY(get_basis(ctx, len, inverse, f64, 2, &b1));
         } else {
             SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
         }
         if (is_row) {
             StageTimer t(ctx, SSW_STAGE_DCT_ROW);
-            if (fold) SSW_TRY(launch_dct_rows_folded_f32(ctx->stream, inverse, src, dst, n * h, w, (const float*)b0, (const float*)b1, ep));
-            else      SSW_TRY(launch_dct_rows(ctx->stream, precision, src, dst, n * h, w, b0, ep));
+            if (fold && f64) SSW_TRY(launch_dct_rows_folded_f64(ctx->stream, inverse, src, dst, n * h, w, (const double*)b0, (const double*)b1, ep));
+            else if (fold)   SSW_TRY(launch_dct_rows_folded_f32(ctx->stream, inverse, src, dst, n * h, w, (const float*)b0, (const float*)b1, ep));
+            else             SSW_TRY(launch_dct_rows(ctx->stream, precision, src, dst, n * h, w, b0, ep));
         } else {
             StageTimer t(ctx, SSW_STAGE_DCT_COL);
-            if (fold) SSW_TRY(launch_dct_cols_folded_f32(ctx->stream, inverse, src, dst, n, w, h, (const float*)b0, (const float*)b1, ep));
-            else      SSW_TRY(launch_dct_cols(ctx->stream, precision, src, dst, n, w, h, b0, ep));
+            if (fold && f64) SSW_TRY(launch_dct_cols_folded_f64(ctx->stream, inverse, src, dst, n, w, h, (const double*)b0, (const double*)b1, ep));
+            else if (fold)   SSW_TRY(launch_dct_cols_folded_f32(ctx->stream, inverse, src, dst, n, w, h, (const float*)b0, (const float*)b1, ep));
+            else             SSW_TRY(launch_dct_cols(ctx->stream, precision, src, dst, n, w, h, b0, ep));
         }
     }
     return SSW_OK;

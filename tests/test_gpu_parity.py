@@ -120,22 +120,28 @@ def test_dct_f32_mfma_within_tolerance(shape, dct_type):
 
 @pytest.mark.parametrize("shape", [(16, 16), (64, 128), (72, 136), (200, 328), (1080, 1920)])
 @pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
-def test_dct_folded_equals_dense_within_f32_rounding(shape, dct_type):
-    """The even/odd-folded f32 GEMMs (default where W%8 == 0 / H%8 == 0) against the dense ones."""
+@pytest.mark.parametrize("precision", [F32, F64])
+def test_dct_folded_equals_dense(shape, dct_type, precision):
+    """The even/odd-folded GEMMs (default where W%8 == 0 / H%8 == 0) against the dense ones."""
     rng = np.random.default_rng(shape[0] + shape[1])
     x = rng.random((2,) + shape).astype(np.float32)
     if dct_type == L.DCT3:
         x = np.stack([O.dct2d(p, O.DCT2) for p in x])
-    folded = G.dct2d(x, dct_type, F32)
+    folded = G.dct2d(x, dct_type, precision)
     G.ctx().set_dct_folding(False)
     try:
-        dense = G.dct2d(x, dct_type, F32)
+        dense = G.dct2d(x, dct_type, precision)
     finally:
         G.ctx().set_dct_folding(True)
-    assert not np.array_equal(folded, dense)                      # really two different code paths
     ref = np.stack([O.dct2d(p, dct_type) for p in x])
-    tol = (4e-6 if dct_type == L.DCT3 else 1e-6) * np.abs(ref).max()
-    assert np.abs(folded - ref).max() <= tol and np.abs(dense - ref).max() <= tol
+    if precision == F32:
+        assert not np.array_equal(folded, dense)                  # really two different code paths
+        tol = (4e-6 if dct_type == L.DCT3 else 1e-6) * np.abs(ref).max()
+        assert np.abs(folded - ref).max() <= tol and np.abs(dense - ref).max() <= tol
+    else:                                                         # both are the correctly rounded transform
+        assert np.mean(folded == ref) >= 0.999 and np.mean(dense == ref) >= 0.999
+        assert np.mean(folded == dense) >= 0.999
+        assert np.abs(folded.astype(np.float64) - ref).max() <= 2e-7 * max(ac_max(ref), 1.0)
 
 
 @pytest.mark.parametrize("precision", [F32, F64])

@@ -20,7 +20,7 @@ check(lib.ssw_dct2d(ctx.handle, typ, prec, n, W, H, buf.ptr), "warm")
 ctx.enable_timing(True); ctx.reset_timing()
 for _ in range(reps): check(lib.ssw_dct2d(ctx.handle, typ, prec, n, W, H, buf.ptr), "dct")
 t = ctx.timing()
-fold = prec == L.PRECISION_F32 and not os.environ.get("SSW_NO_FOLD")
+fold = not os.environ.get("SSW_NO_FOLD")
 rf = 2.0 * n * H * W * W * reps / (2 if fold else 1); cf = 2.0 * n * W * H * H * reps / (2 if fold else 1)
 print("rows %.2f ms %.1f TF | cols %.2f ms %.1f TF (executed flop)" % (
     t["dct_row"]["ms"] / reps, rf / t["dct_row"]["ms"] / 1e9, t["dct_col"]["ms"] / reps, cf / t["dct_col"]["ms"] / 1e9))
