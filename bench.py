@@ -45,7 +45,9 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--k", type=int, default=1000)
     ap.add_argument("--chunk", type=int, default=16, help="frames per internal pass (workspace = 4 planes x chunk)")
-    ap.add_argument("--precision", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--precision", choices=["f32", "f64"], default="f64",
+                    help="headline precision: f64 = canonical (bit-parity with the CPU path), f32 = fast")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other precision")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="dense basis GEMMs instead of the even/odd-folded ones")
@@ -76,8 +78,6 @@ def main():
     ctx.set_chunk_frames(args.chunk)
     ctx.set_dct_folding(not args.no_fold)
     W, H, K, B = args.width, args.height, args.k, args.batch
-    precision = L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32
-    cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, precision)
 
     # ---- inputs resident in HBM ------------------------------------------------------------------
     first_frame = rank * B                       # global frame index of this rank's shard (weak scaling)
@@ -92,81 +92,118 @@ def main():
     check(lib.ssw_synth_frames(ctx.handle, args.seed, first_frame, B, W, H, rgb.data_ptr()), "ssw_synth_frames")
     ctx.synchronize()
 
-    def step():
-        check(lib.ssw_batch_embed(ctx.handle, C.byref(cfg), rgb.data_ptr(), B, W, H, marks.data_ptr(), K,
-                                  rgb_out.data_ptr(), None, None), "ssw_batch_embed")
-        check(lib.ssw_batch_extract(ctx.handle, C.byref(cfg), rgb.data_ptr(), rgb_out.data_ptr(), B, W, H, K,
-                                    extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
+    def measure(prec_name):
+        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns
+        (seconds [max over ranks], per-stage hipEvent timings, sims of the last step)."""
+        cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, L.PRECISION_F64 if prec_name == "f64" else L.PRECISION_F32)
 
-    def barrier():
+        def step():
+            check(lib.ssw_batch_embed(ctx.handle, C.byref(cfg), rgb.data_ptr(), B, W, H, marks.data_ptr(), K,
+                                      rgb_out.data_ptr(), None, None), "ssw_batch_embed")
+            check(lib.ssw_batch_extract(ctx.handle, C.byref(cfg), rgb.data_ptr(), rgb_out.data_ptr(), B, W, H, K,
+                                        extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
+
+        def barrier():
+            ctx.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        for _ in range(args.warmup):
+            step()
+        ctx.enable_timing(True)                  # hipEvent pairs around every kernel on the ctx stream
+        ctx.reset_timing()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
         ctx.synchronize()
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        stage = ctx.timing()
+        ctx.enable_timing(False)
         if dist is not None:
-            dist.barrier()
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        sims_host = sims.cpu().numpy()
+        norms = marks_host.norm(dim=1).numpy()
+        if not np.all(sims_host > 0.9 * norms):
+            raise SystemExit(f"rank {rank}: similarity check failed ({prec_name}): "
+                             f"min sim/|mark| = {(sims_host / norms).min():.3f}")
+        return elapsed, stage, sims_host
 
-    for _ in range(args.warmup):
-        step()
-    ctx.enable_timing(True)                      # hipEvent pairs around every kernel on the ctx stream
-    ctx.reset_timing()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    stage = ctx.timing()
-    ctx.enable_timing(False)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    sims_host = sims.cpu().numpy()
-    norms = marks_host.norm(dim=1).numpy()
-    if not np.all(sims_host > 0.9 * norms):
-        raise SystemExit(f"rank {rank}: similarity check failed: min sim/|mark| = {(sims_host / norms).min():.3f}")
-
-    # ---- roofline of the dominant kernel (DCT row-pass GEMM) from the live event timers ------------
     steps = args.steps
-    n_chunks = (B + args.chunk - 1) // args.chunk
+    px_total = float(B) * W * H * steps
     transforms_per_step = 4                       # DCT2, DCT3 (embed), DCT2, DCT2 (extract)
-    # dense ("effective") flop of the basis GEMMs; the even/odd-folded f32 kernels EXECUTE half of it.
-    # Utilisation is always executed flop / time; the dense figure / time is reported as "effective".
-    row_dense = 2.0 * B * H * W * W * transforms_per_step * steps
-    col_dense = 2.0 * B * W * H * H * transforms_per_step * steps
     fold_rows = (not args.no_fold) and W % 8 == 0 and W >= 16
     fold_cols = (not args.no_fold) and H % 8 == 0 and H >= 16 and W % 4 == 0
-    row_flops_total = row_dense / (2.0 if fold_rows else 1.0)
-    col_flops_total = col_dense / (2.0 if fold_cols else 1.0)
-    row_ms, row_n = stage["dct_row"]["ms"], max(stage["dct_row"]["launches"], 1)
-    col_ms, col_n = stage["dct_col"]["ms"], max(stage["dct_col"]["launches"], 1)
-    peak = PEAK_F64_MFMA_TFLOPS if args.precision == "f64" else PEAK_F32_MFMA_TFLOPS
-    row_tf = row_flops_total / (row_ms * 1e-3) / 1e12 if row_ms > 0 else 0.0
-    col_tf = col_flops_total / (col_ms * 1e-3) / 1e12 if col_ms > 0 else 0.0
-    px_total = float(B) * W * H * steps
-    def gbs(bytes_per_px, passes, ms):
-        return (bytes_per_px * px_total * passes) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    kernels = {
-        "dct_rows": {"tflops": round(row_tf, 2), "frac_mfma": round(row_tf / peak, 4),
-                     "avg_launch_ms": round(row_ms / row_n, 4), "launches": row_n,
-                     "flop_per_launch": row_flops_total / row_n, "folded": fold_rows,
-                     "effective_dense_tflops": round(row_dense / (row_ms * 1e-3) / 1e12, 2) if row_ms > 0 else 0.0},
-        "dct_cols": {"tflops": round(col_tf, 2), "frac_mfma": round(col_tf / peak, 4),
-                     "avg_launch_ms": round(col_ms / col_n, 4), "launches": col_n,
-                     "flop_per_launch": col_flops_total / col_n, "folded": fold_cols,
-                     "effective_dense_tflops": round(col_dense / (col_ms * 1e-3) / 1e12, 2) if col_ms > 0 else 0.0},
-        # algorithmic bytes: writer rgb->yiq 24 B/px + two reader rgb->y 16 B/px = 56 B/px
-        "rgb_to_yiq": {"gbs": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]), 1),
-                       "frac_hbm": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]) / PEAK_HBM_GBS, 4)},
-        "yiq_to_rgb": {"gbs": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]), 1),
-                       "frac_hbm": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]) / PEAK_HBM_GBS, 4)},
-        # top-k: 4 B/px algorithmic, two selections per step (writer + base reader)
-        "select": {"gbs": round(gbs(4.0, 2, stage["select"]["ms"]), 1),
-                   "frac_hbm": round(gbs(4.0, 2, stage["select"]["ms"]) / PEAK_HBM_GBS, 4)},
-    }
-    stage_ms = {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
+
+    def kernel_report(prec_name, stage):
+        """Per-kernel achieved rates from the live event timers.  GEMMs: EXECUTED flop / time is the
+        utilisation (the even/odd-folded kernels execute half the dense 2*rows*N*N); the dense figure
+        / time is reported separately as "effective"."""
+        peak = PEAK_F64_MFMA_TFLOPS if prec_name == "f64" else PEAK_F32_MFMA_TFLOPS
+        row_dense = 2.0 * B * H * W * W * transforms_per_step * steps
+        col_dense = 2.0 * B * W * H * H * transforms_per_step * steps
+        row_flops = row_dense / (2.0 if fold_rows else 1.0)
+        col_flops = col_dense / (2.0 if fold_cols else 1.0)
+        row_ms, row_n = stage["dct_row"]["ms"], max(stage["dct_row"]["launches"], 1)
+        col_ms, col_n = stage["dct_col"]["ms"], max(stage["dct_col"]["launches"], 1)
+        row_tf = row_flops / (row_ms * 1e-3) / 1e12 if row_ms > 0 else 0.0
+        col_tf = col_flops / (col_ms * 1e-3) / 1e12 if col_ms > 0 else 0.0
+
+        def gbs(bytes_per_px, passes, ms):
+            return (bytes_per_px * px_total * passes) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        kernels = {
+            "dct_rows": {"tflops": round(row_tf, 2), "frac_mfma": round(row_tf / peak, 4),
+                         "avg_launch_ms": round(row_ms / row_n, 4), "launches": row_n,
+                         "flop_per_launch": row_flops / row_n, "folded": fold_rows,
+                         "effective_dense_tflops": round(row_dense / (row_ms * 1e-3) / 1e12, 2) if row_ms > 0 else 0.0},
+            "dct_cols": {"tflops": round(col_tf, 2), "frac_mfma": round(col_tf / peak, 4),
+                         "avg_launch_ms": round(col_ms / col_n, 4), "launches": col_n,
+                         "flop_per_launch": col_flops / col_n, "folded": fold_cols,
+                         "effective_dense_tflops": round(col_dense / (col_ms * 1e-3) / 1e12, 2) if col_ms > 0 else 0.0},
+            # algorithmic bytes (SURVEY 8(d)): writer rgb->yiq 24 B/px + two reader rgb->y 16 B/px = 56 B/px
+            "rgb_to_yiq": {"gbs": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]), 1),
+                           "frac_hbm": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]) / PEAK_HBM_GBS, 4)},
+            "yiq_to_rgb": {"gbs": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]), 1),
+                           "frac_hbm": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]) / PEAK_HBM_GBS, 4)},
+            # top-k: 4 B/px algorithmic, two selections per step (writer + base reader)
+            "select": {"gbs": round(gbs(4.0, 2, stage["select"]["ms"]), 1),
+                       "frac_hbm": round(gbs(4.0, 2, stage["select"]["ms"]) / PEAK_HBM_GBS, 4)},
+        }
+        roofline = {"bound": "mfma",
+                    "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name,
+                    "achieved": round(row_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(row_tf / peak, 4), "traffic": None,
+                    "note": ("executed flop per launch (even/odd-folded basis: half the dense 2*rows*W*W) / average "
+                             "launch time; dense-effective rate in kernels.dct_rows.effective_dense_tflops")
+                    if fold_rows else "dense flop per launch / average launch time"}
+        return kernels, roofline, {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
+
+    elapsed, stage, sims_host = measure(args.precision)
+    kernels, roofline, stage_ms = kernel_report(args.precision, stage)
+    alt = None
+    if not args.no_alt:
+        alt_name = "f32" if args.precision == "f64" else "f64"
+        alt_elapsed, alt_stage, alt_sims = measure(alt_name)
+        alt_kernels, alt_roofline, alt_stage_ms = kernel_report(alt_name, alt_stage)
+        alt = {"dtype": alt_name, "value": round(world * px_total / 1e6 / alt_elapsed, 2), "unit": "Mpix/s",
+               "ms_per_step": round(alt_elapsed / steps * 1e3, 3), "roofline": alt_roofline,
+               "kernels": {k: alt_kernels[k] for k in ("dct_rows", "dct_cols")},
+               "sim_mean": round(float(alt_sims.mean()), 4),
+               "max_abs_sim_diff_vs_headline": float(np.abs(alt_sims - sims_host).max())}
+        # leave the headline precision's outputs in rgb_out / sims for the parity leg below
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            measure_cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1,
+                                   L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32)
+            check(lib.ssw_batch_embed(ctx.handle, C.byref(measure_cfg), rgb.data_ptr(), 1, W, H, marks.data_ptr(), K,
+                                      rgb_out.data_ptr(), None, None), "ssw_batch_embed")
+            check(lib.ssw_batch_extract(ctx.handle, C.byref(measure_cfg), rgb.data_ptr(), rgb_out.data_ptr(), 1, W, H, K,
+                                        extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
+            ctx.synchronize()
 
     result = None
     if rank == 0:
@@ -189,16 +226,13 @@ def main():
                        "frames_per_gpu": B, "width": W, "height": H, "k": K, "alpha": 0.1,
                        "method": "Option2", "ordering": "Energy", "chunk_frames": args.chunk,
                        "parallelism": f"frame-sharded x{world}, no collectives"},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % args.precision,
-                         "achieved": round(row_tf, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(row_tf / peak, 4), "traffic": None,
-                         "note": ("executed flop (even/odd-folded basis: half the dense 2*rows*W*W); dense-effective "
-                                  "rate in kernels.dct_rows.effective_dense_tflops") if fold_rows else "dense flop"},
+            "roofline": roofline,
             "kernels": kernels,
             "stage_ms_per_step": stage_ms,
             "sim_mean": round(float(sims_host.mean()), 4),
         }
+        if alt is not None:
+            result["alt_precision"] = alt
 
     # ---- CPU baseline: the oracle (faithful mode) on a bounded sample, rank 0 at N=1 only ----------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -206,6 +240,7 @@ def main():
         frame0 = rgb[0].cpu().numpy()
         mark0 = marks_host[0].numpy()
         gpu_marked0 = rgb_out[0].cpu().numpy()
+        # timed: what the reference does -- f32 FFT-class DCT + full stable sort of all W*H-1 keys
         t0 = time.perf_counter()
         cpu_marked = O.embed_frame(frame0, mark0, backend=O.BACKEND_F32, full_sort=True)
         cpu_ext, cpu_sim = O.extract_frame(frame0, cpu_marked, mark0, backend=O.BACKEND_F32, full_sort=True)
@@ -215,9 +250,19 @@ def main():
             "sample": f"1 frame {W}x{H} (frame 0 of the batch), embed+extract+similarity, oracle C restatement: "
                       f"f32 FFT DCT + full stable sort like the reference, single thread, {cpu_s:.1f} s",
         }
-        result["parity"] = {"sim_gpu": float(sims_host[0]), "sim_cpu": float(cpu_sim),
-                            "sim_delta": abs(float(sims_host[0]) - float(cpu_sim)),
-                            "marked_frame_max_abs_diff": float(np.abs(gpu_marked0 - cpu_marked).max())}
+        # untimed: the oracle's correctly rounded (f64-backend) pipeline = what the canonical precision must equal
+        ref_marked = O.embed_frame(frame0, mark0, backend=O.BACKEND_F64, full_sort=False)
+        ref_ext, ref_sim = O.extract_frame(frame0, ref_marked, mark0, backend=O.BACKEND_F64, full_sort=False)
+        gpu_ext0 = extracted[0].cpu().numpy()
+        result["parity"] = {
+            "precision": args.precision,
+            "sim_gpu": float(sims_host[0]),
+            "sim_cpu_f32fft": float(cpu_sim), "sim_delta_vs_cpu_f32fft": abs(float(sims_host[0]) - float(cpu_sim)),
+            "sim_cpu_exact": float(ref_sim), "sim_delta_vs_cpu_exact": abs(float(sims_host[0]) - float(ref_sim)),
+            "marked_frame_max_abs_diff_vs_cpu_exact": float(np.abs(gpu_marked0 - ref_marked).max()),
+            "marked_frame_bit_identical_fraction": float(np.mean(gpu_marked0 == ref_marked)),
+        }
+        result["parity"]["extracted_max_abs_diff_vs_cpu_exact"] = float(np.abs(gpu_ext0 - ref_ext).max())
 
     if rank == 0:
         print(json.dumps(result))

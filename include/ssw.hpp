@@ -80,13 +80,13 @@ enum class OrderingMethod : int {
 struct WriteConfig {                                   // algorithm.rs:99-112
     Insertion insertion = Insertion::Option2(0.1f);
     OrderingMethod ordering = OrderingMethod::Energy;
-    ssw_precision precision = SSW_PRECISION_F32;
+    ssw_precision precision = SSW_PRECISION_F64;
     ssw_config c() const { return {static_cast<int32_t>(ordering), insertion.method, insertion.alpha, precision}; }
 };
 struct ReadConfig {                                    // algorithm.rs:127-140
     Extraction extraction = Extraction::Option2(0.1f);
     OrderingMethod ordering = OrderingMethod::Energy;
-    ssw_precision precision = SSW_PRECISION_F32;
+    ssw_precision precision = SSW_PRECISION_F64;
     ssw_config c() const { return {static_cast<int32_t>(ordering), extraction.method, extraction.alpha, precision}; }
 };
 
@@ -194,7 +194,7 @@ private:
 
 class ReaderDerived {                                  // algorithm.rs:448-456
 public:
-    ReaderDerived(Context& ctx, const ImageRgb32F& image, ssw_precision precision = SSW_PRECISION_F32)
+    ReaderDerived(Context& ctx, const ImageRgb32F& image, ssw_precision precision = SSW_PRECISION_F64)
         : r_(ctx, image, false, [&] { ReadConfig c; c.precision = precision; return c; }()) {}
     std::vector<float> coefficients() const { return r_.coefficients(); }
 

@@ -215,7 +215,7 @@ void ssw_config_default(ssw_config* cfg) {
     cfg->ordering = SSW_ORDER_ENERGY;        // src/algorithm.rs:104-111
     cfg->method = SSW_OPTION2;
     cfg->alpha = 0.1f;
-    cfg->precision = SSW_PRECISION_F32;
+    cfg->precision = SSW_PRECISION_F64;      // canonical: bit-parity with the CPU path
 }
 
 int ssw_ctx_create(int device_id, ssw_ctx** out) {

@@ -173,5 +173,5 @@ def batch_extract(base_rgb, derived_rgb, k, marks=None, cfg=None):
     return e, s
 
 
-def default_config(precision=L.PRECISION_F32, ordering=L.ORDER_ENERGY, method=L.OPTION2, alpha=0.1):
+def default_config(precision=L.PRECISION_F64, ordering=L.ORDER_ENERGY, method=L.OPTION2, alpha=0.1):
     return L.Config(ordering, method, alpha, precision)

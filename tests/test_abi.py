@@ -42,7 +42,7 @@ def test_status_strings_and_default_config():
     assert b"exceeds available coefficients" in lib.ssw_status_string(L.SSW_ERR_K_TOO_LARGE)
     cfg = L.Config()
     lib.ssw_config_default(C.byref(cfg))
-    assert (cfg.ordering, cfg.method, cfg.precision) == (L.ORDER_ENERGY, L.OPTION2, L.PRECISION_F32)
+    assert (cfg.ordering, cfg.method, cfg.precision) == (L.ORDER_ENERGY, L.OPTION2, L.PRECISION_F64)
     assert abs(cfg.alpha - 0.1) < 1e-7
     d = wm.WriteConfig.default()._c()
     assert (d.ordering, d.method, d.precision) == (cfg.ordering, cfg.method, cfg.precision)

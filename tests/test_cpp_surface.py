@@ -43,9 +43,9 @@ def test_cpp_doc_test_flow_matches_oracle(tmp_path):
     ext = np.fromfile(p("ext.f32"), np.float32)
     ref_marked = O.embed_frame(rgb, mark)
     ref_ext, ref_sim = O.extract_frame(rgb, ref_marked, mark)
-    assert np.abs(marked - ref_marked).max() <= 5e-6
-    assert np.median(np.abs(ext - ref_ext)) <= 5e-5        # f32 precision, small frame
-    assert abs(float(vals["similarity"]) - ref_sim) < 1e-3 * abs(ref_sim)
+    assert np.abs(marked - ref_marked).max() <= 2e-7       # default = canonical precision
+    assert np.abs(ext - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert abs(float(vals["similarity"]) - ref_sim) < 1e-4
     assert vals["exceeds6"] == "1" and vals["consumed_ok"] == "1" and vals["too_large_ok"] == "1"
     assert abs(float(vals["random"])) < 5.0
     coef = O.dct2d(O.rgb_to_yiq(rgb)[0])

@@ -333,11 +333,11 @@ def test_f32_pipeline_matches_oracle_tie_aware(marks, cat_images):
     """f32 MFMA precision: ordering checked tie-aware against oracle keys, values keyed by index."""
     cat = u8_to_f32(cat_images["cat"])
     mark = marks["seed_1"]
-    writer = wm.Writer(cat)
+    writer = wm.Writer(cat, wm.WriteConfig(precision=F32))
     coef = writer.coefficient_image()
     ref_coef = O.dct2d(O.rgb_to_yiq(cat)[0])
     assert np.abs(coef - ref_coef).max() <= 1e-6 * np.abs(ref_coef).max()
-    reader = wm.Reader.base(cat)
+    reader = wm.Reader.base(cat, wm.ReadConfig(precision=F32))
     idx = reader.indices(1000).astype(np.int64)
     assert len(set(idx.tolist())) == 1000 and idx.min() >= 1
     # (i) the GPU's own coefficients give exactly this order
@@ -347,7 +347,7 @@ def test_f32_pipeline_matches_oracle_tie_aware(marks, cat_images):
     assert np.all(e[1:] <= e[:-1] * (1 + 1e-3))
     # (iii) same index list fed to both sides -> extracted values agree, sims agree
     res = writer.mark([mark])
-    ext = reader.extract(wm.Reader.derived(res), 1000)
+    ext = reader.extract(wm.Reader.derived(res, precision=F32), 1000)
     ref_res = O.embed(ref_coef, idx.astype(np.uint64), [mark])
     ref_y = O.dct2d(ref_res, O.DCT3)
     yiq = O.rgb_to_yiq(cat)
