@@ -181,6 +181,19 @@ def main():
                     "note": ("executed flop per launch (even/odd-folded basis: half the dense 2*rows*W*W) / average "
                              "launch time; dense-effective rate in kernels.dct_rows.effective_dense_tflops")
                     if fold_rows else "dense flop per launch / average launch time"}
+        # HBM-side traffic of the dominant kernel: PMC counters collected offline exactly as
+        # MI355X_MICROARCH.md prescribes (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) and
+        # committed in profiles/r1_pmc_traffic.json; only quoted when this run matches that workload.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            wl = pmc["workload"]
+            if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, min(args.chunk, B)) and roofline["kernel"] in pmc["kernels"]:
+                roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
+                roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
+                roofline["algorithmic_bytes_per_launch"] = int(min(args.chunk, B) * H * W * 8 +
+                                                               2 * (W // 2) ** 2 * (8 if prec_name == "f64" else 4))
+        except (OSError, KeyError, ValueError):
+            pass
         return kernels, roofline, {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
 
     elapsed, stage, sims_host = measure(args.precision)
