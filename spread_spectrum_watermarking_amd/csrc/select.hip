@@ -3,26 +3,40 @@
 // Ordering: obtain_indices_by_function (/root/reference/src/algorithm.rs:200-210) does a full
 // stable descending sort of all W*H-1 non-DC coefficients with a boxed comparator, but only
 // the first k (= mark length) entries are ever consumed (:396, :556-557).  Here the first k
-// entries are produced directly:
-//   1. every coefficient gets a 64-bit composite key  (sortable(key_f32) << 32) | ~index
-//      -- key_f32 as in the comparators (:214-280), sortable() = f32::total_cmp order as an
-//      unsigned integer, ~index so that equal keys rank lower index first (stable sort of an
-//      index-ascending list).  Composite keys are unique, so there are no ties left.
-//   2. MSD radix select (11-bit digits) of the k-th largest composite key per frame: one
-//      histogram pass over the plane per digit, decided on the device (no host round trip);
-//      passes after the one that isolates the k-th key exit immediately.
-//   3. compaction of the exactly-k survivors, bitonic sort of k composites in LDS, emit ~low32.
-// HBM-bound: 4 B/px per pass over the coefficient plane.
+// entries are produced directly.  Every coefficient gets a 64-bit composite key
+//     (sortable(key_f32) << 32) | ~index
+// -- key_f32 exactly as the comparators compute it (:214-280), sortable() = f32::total_cmp order as
+// an unsigned integer, ~index so that equal keys rank lower index first (stable sort of an
+// index-ascending list).  Composite keys are unique: no ties are left, and "the first k of the
+// reference's list" = "the k largest composite keys, descending".
+//
+// Per frame (HBM-bound, ~1.02 reads of the plane, decided entirely on the device):
+//   1. sample pass   -- one pseudo-randomly placed element out of every 64 goes into a 2048-bin
+//                       histogram of the top 11 key bits
+//   2. sample find   -- the digit d whose upper tail holds ~4k/64 samples: a conservative threshold
+//                       (expected 4k survivors, never fewer than k short of a >40-sigma event)
+//   3. compaction    -- the one full pass: every coefficient whose top digit >= d is appended to a
+//                       candidate list (16-B loads, rare atomics)
+//   4. finish        -- one block per frame: exact MSD radix select (11-bit digits, LDS histogram)
+//                       of the k-th largest composite among the candidates, gather of exactly k,
+//                       bitonic sort in LDS, emit ~low32.
+//   Degenerate data (fewer than k candidates, or more than the candidate buffer holds: massive
+//   ties, constant planes) is handled in the same finish kernel by running the exact select over
+//   the whole plane instead of the candidate list -- slow but exact, and never taken by images.
 #include "ssw_internal.hpp"
 
 namespace ssw {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int DIGIT_BITS = 11;
 constexpr int NBINS = 1 << DIGIT_BITS;          // 2048
-constexpr int N_PASSES = 6;                     // 11*5 + 9 = 64 bits
 constexpr size_t MAX_K = 16384;                 // 128 KiB of LDS for the in-block sort
+constexpr unsigned SAMPLE_STRIDE = 64;
+constexpr unsigned FINISH_THREADS = 1024;
 
 size_t select_max_k() { return MAX_K; }
+size_t select_cand_capacity(size_t k) { size_t c = 16 * k; return c < 65536 ? 65536 : c; }
 
 struct KeyParams {
     int ordering;
@@ -36,7 +50,7 @@ __device__ inline uint32_t sortable(float v) {
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-__device__ inline uint64_t composite_key(const KeyParams& kp, uint32_t index, float value) {
+__device__ inline uint32_t key_bits(const KeyParams& kp, uint32_t index, float value) {
     float key;
     if (kp.ordering == SSW_ORDER_ENERGY) {
         key = value * value;                                         // :214-221
@@ -44,44 +58,46 @@ __device__ inline uint64_t composite_key(const KeyParams& kp, uint32_t index, fl
         const float scaled = kp.s[index < kp.w][(index % kp.w) == 0] * value;   // :252-266
         key = (kp.ordering == SSW_ORDER_ENERGY_ORTHOGONAL) ? scaled * scaled : scaled;   // :178-187
     }
-    return ((uint64_t)sortable(key) << 32) | (uint32_t)(~index);
+    return sortable(key);
+}
+__device__ inline uint64_t composite_key(const KeyParams& kp, uint32_t index, float value) {
+    return ((uint64_t)key_bits(kp, index, value) << 32) | (uint32_t)(~index);
 }
 
-// state layout per frame: [0] prefix, [1] bits decided, [2] need, [3] resolved
-__device__ inline int pass_width(int bits_done) { return (64 - bits_done) < DIGIT_BITS ? (64 - bits_done) : DIGIT_BITS; }
-
-__global__ void select_init_kernel(uint64_t* state, uint32_t* hist, uint32_t* cand_count, size_t k) {
-    const size_t f = blockIdx.x;
-    for (int i = threadIdx.x; i < NBINS; i += blockDim.x) hist[f * NBINS + i] = 0;
-    if (threadIdx.x == 0) {
-        state[f * 4 + 0] = 0;
-        state[f * 4 + 1] = 0;
-        state[f * 4 + 2] = k;
-        state[f * 4 + 3] = 0;
-        cand_count[f] = 0;
-    }
+__device__ inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
 }
 
-__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ coef, size_t plane_len,
-                                                          KeyParams kp, const uint64_t* __restrict__ state,
-                                                          uint32_t* __restrict__ hist) {
-    const size_t f = blockIdx.y;
-    if (state[f * 4 + 3]) return;                                    // already isolated
+// per-frame control block: [0] threshold digit, [1] candidate count.  ctrl and the sample
+// histogram are zero when a selection starts: the workspace is zero-filled at allocation and the
+// finish kernel re-zeroes what it consumed.
+
+// 1. sample pass: one pseudo-randomly placed 16-B quad out of every 256 elements (rate 1/64)
+__global__ __launch_bounds__(256) void select_sample_kernel(const float* __restrict__ coef, size_t plane_len,
+                                                            KeyParams kp, uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[NBINS];
+    const size_t f = blockIdx.y;
     for (int i = threadIdx.x; i < NBINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
-    const uint64_t prefix = state[f * 4 + 0];
-    const int bits_done = (int)state[f * 4 + 1];
-    const int width = pass_width(bits_done);
-    const int shift = 64 - bits_done - width;
-    const uint32_t mask = (1u << width) - 1u;
     const float* __restrict__ c = coef + f * plane_len;
+    constexpr unsigned GROUP = SAMPLE_STRIDE * 4;                        // 256 elements = 64 quads
+    const size_t groups = (plane_len + GROUP - 1) / GROUP;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < plane_len; j += stride) {
-        if (j == 0) continue;                                        // DC is skipped (:204)
-        const uint64_t comp = composite_key(kp, (uint32_t)j, c[j]);
-        if (bits_done == 0 || (comp >> (64 - bits_done)) == prefix)
-            atomicAdd(&lh[(uint32_t)(comp >> shift) & mask], 1u);
+    const bool vec = (plane_len % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0);
+    for (size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x; g < groups; g += stride) {
+        const size_t j0 = g * GROUP + 4 * (mix32((uint32_t)g * 0x9E3779B1u + (uint32_t)f) & (GROUP / 4 - 1));
+        if (j0 >= plane_len) continue;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned cnt = 0;
+        if (vec) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(c + j0);
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; cnt = 4;
+        } else {
+            for (; cnt < 4 && j0 + cnt < plane_len; ++cnt) v[cnt] = c[j0 + cnt];
+        }
+        for (unsigned e = 0; e < cnt; ++e)
+            if (j0 + e != 0) atomicAdd(&lh[key_bits(kp, (uint32_t)(j0 + e), v[e]) >> (32 - DIGIT_BITS)], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < NBINS; i += blockDim.x) {
@@ -90,97 +106,196 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const float* __restric
     }
 }
 
-// one block per frame: locate the digit holding the `need`-th largest key, update the state
-__global__ __launch_bounds__(256) void select_find_kernel(uint64_t* __restrict__ state, uint32_t* __restrict__ hist) {
-    const size_t f = blockIdx.x;
-    if (state[f * 4 + 3]) return;
+// 2. threshold digit: smallest upper tail of the sample histogram holding >= m samples
+__global__ __launch_bounds__(256) void select_sample_find_kernel(uint32_t* __restrict__ ctrl,
+                                                                 const uint32_t* __restrict__ hist, uint32_t m) {
     __shared__ uint32_t part[256];
     __shared__ uint32_t chosen[2];
-    uint32_t* h = hist + f * NBINS;
-    const int bits_done = (int)state[f * 4 + 1];
-    const int width = pass_width(bits_done);
-    const uint64_t need = state[f * 4 + 2];
-    // thread t owns the 8 digits [8t, 8t+8) counted from the TOP: digit = NBINS-1 - (8t+e)
+    const size_t f = blockIdx.x;
+    const uint32_t* h = hist + f * NBINS;
     const int t = threadIdx.x;
-    uint32_t local[8];
-    uint32_t sum = 0;
+    uint32_t local[8], sum = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { local[e] = h[NBINS - 1 - (8 * t + e)]; sum += local[e]; }
     part[t] = sum;
     __syncthreads();
-    if (t == 0) {                                                    // serial scan of 256 partials
-        uint64_t run = 0;
-        int owner = 255;
+    if (t == 0) {
+        uint32_t run = 0;
+        int owner = -1;
         for (int i = 0; i < 256; ++i) {
-            if (run + part[i] >= need) { owner = i; break; }
+            if (run + part[i] >= m) { owner = i; break; }
             run += part[i];
         }
         chosen[0] = (uint32_t)owner;
-        chosen[1] = (uint32_t)run;                                   // keys above the owner's digits
+        chosen[1] = run;
+        if (owner < 0) ctrl[f * 2 + 0] = 0;                           // fewer than m samples: keep everything
     }
     __syncthreads();
     if (t == (int)chosen[0]) {
-        uint64_t run = chosen[1];
+        uint32_t run = chosen[1];
         int e = 0;
         for (; e < 7; ++e) {
-            if (run + local[e] >= need) break;
+            if (run + local[e] >= m) break;
             run += local[e];
         }
-        const uint32_t digit = (uint32_t)(NBINS - 1 - (8 * t + e));
-        const uint64_t new_need = need - run;
-        const int new_bits = bits_done + width;
-        state[f * 4 + 0] = (state[f * 4 + 0] << width) | (uint64_t)(digit & ((1u << width) - 1u));
-        state[f * 4 + 1] = (uint64_t)new_bits;
-        state[f * 4 + 2] = new_need;
-        state[f * 4 + 3] = (local[e] == new_need || new_bits >= 64) ? 1 : 0;
+        ctrl[f * 2 + 0] = (uint32_t)(NBINS - 1 - (8 * t + e));
     }
-    __syncthreads();
-#pragma unroll
-    for (int e = 0; e < 8; ++e) h[8 * t + e] = 0;                    // ready for the next pass
 }
 
+// 3. the one full pass over the plane: append every coefficient whose top digit >= threshold
 __global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ coef, size_t plane_len,
-                                                             KeyParams kp, const uint64_t* __restrict__ state,
-                                                             uint64_t* __restrict__ cand, size_t cap,
-                                                             uint32_t* __restrict__ cand_count) {
+                                                             KeyParams kp, uint32_t* __restrict__ ctrl,
+                                                             uint64_t* __restrict__ cand, size_t cap) {
     const size_t f = blockIdx.y;
-    const uint64_t prefix = state[f * 4 + 0];
-    const int bits_done = (int)state[f * 4 + 1];
+    const uint32_t thr = ctrl[f * 2 + 0];
+    uint32_t* count = &ctrl[f * 2 + 1];
     const float* __restrict__ c = coef + f * plane_len;
+    uint64_t* __restrict__ out = cand + f * cap;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < plane_len; j += stride) {
-        if (j == 0) continue;
-        const uint64_t comp = composite_key(kp, (uint32_t)j, c[j]);
-        const uint64_t top = bits_done >= 64 ? comp : (comp >> (64 - bits_done));
-        if (top >= prefix) {
-            const uint32_t pos = atomicAdd(&cand_count[f], 1u);
-            if (pos < cap) cand[f * cap + pos] = comp;
+    auto consider = [&](size_t j, float v) {
+        const uint32_t kb = key_bits(kp, (uint32_t)j, v);
+        if ((kb >> (32 - DIGIT_BITS)) >= thr && j != 0) {
+            const uint32_t pos = atomicAdd(count, 1u);
+            if (pos < cap) out[pos] = ((uint64_t)kb << 32) | (uint32_t)(~(uint32_t)j);
         }
+    };
+    if ((plane_len % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0)) {
+        const size_t nquad = plane_len / 4;
+        for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nquad; q += stride) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(c + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) consider(4 * q + e, v[e]);
+        }
+    } else {
+        for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < plane_len; j += stride) consider(j, c[j]);
     }
 }
 
-// bitonic sort (descending) of the k survivors of one frame in LDS, then emit the indices
-__global__ __launch_bounds__(1024) void select_sort_kernel(const uint64_t* __restrict__ cand, size_t cap,
-                                                           size_t k, unsigned n_pow2,
-                                                           uint32_t* __restrict__ indices) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint64_t* s = reinterpret_cast<uint64_t*>(smem_raw);
-    const size_t f = blockIdx.x;
-    for (unsigned i = threadIdx.x; i < n_pow2; i += blockDim.x) s[i] = (i < k) ? cand[f * cap + i] : 0ull;
+// 4. finish: exact select + sort inside one block.  `Src` yields the composite key of item i.
+struct CandSource {
+    const uint64_t* cand;
+    __device__ uint64_t operator()(size_t i) const { return cand[i]; }
+};
+struct PlaneSource {                    // item i = coefficient i + 1 (DC skipped, :204)
+    const float* c;
+    KeyParams kp;
+    __device__ uint64_t operator()(size_t i) const { return composite_key(kp, (uint32_t)(i + 1), c[i + 1]); }
+};
+
+template <class Src>
+__device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n_pow2, uint32_t* lhist,
+                                  uint32_t* lpart, uint64_t* lbuf, uint64_t* lstate,
+                                  uint32_t* __restrict__ indices) {
+    // lstate: [0] prefix, [1] bits decided, [2] need, [3] resolved, [4] gather counter, [5..6] scan scratch
+    const unsigned tid = threadIdx.x;
+    if (tid == 0) { lstate[0] = 0; lstate[1] = 0; lstate[2] = k; lstate[3] = (n == k) ? 1 : 0; lstate[4] = 0; }
     __syncthreads();
+    while (!lstate[3]) {
+        const uint64_t prefix = lstate[0];
+        const int bits_done = (int)lstate[1];
+        const uint64_t need = lstate[2];
+        const int width = (64 - bits_done) < DIGIT_BITS ? (64 - bits_done) : DIGIT_BITS;
+        const int shift = 64 - bits_done - width;
+        const uint32_t mask = (1u << width) - 1u;
+        for (unsigned i = tid; i < NBINS; i += blockDim.x) lhist[i] = 0;
+        __syncthreads();
+        for (size_t i = tid; i < n; i += blockDim.x) {
+            const uint64_t comp = src(i);
+            if (bits_done == 0 || (comp >> (64 - bits_done)) == prefix)
+                atomicAdd(&lhist[(uint32_t)(comp >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        // digit holding the need-th largest key: 256 threads own 8 digits each (counted from the
+        // top), thread 0 scans the 256 partial sums, the owner resolves inside its 8 digits
+        uint32_t local[8];
+        if (tid < 256) {
+            uint32_t sum = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { local[e] = lhist[NBINS - 1 - (8 * tid + e)]; sum += local[e]; }
+            lpart[tid] = sum;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t run = 0;
+            int owner = 255;
+            for (int i = 0; i < 256; ++i) {
+                if (run + lpart[i] >= need) { owner = i; break; }
+                run += lpart[i];
+            }
+            lstate[5] = (uint64_t)owner;
+            lstate[6] = run;
+        }
+        __syncthreads();
+        if (tid == (unsigned)lstate[5]) {
+            uint64_t run = lstate[6];
+            int e = 0;
+            for (; e < 7; ++e) {
+                if (run + local[e] >= need) break;
+                run += local[e];
+            }
+            const uint32_t d = (uint32_t)(NBINS - 1 - (8 * tid + e));
+            const uint64_t new_need = need - run;
+            lstate[0] = (prefix << width) | (uint64_t)(d & mask);
+            lstate[1] = (uint64_t)(bits_done + width);
+            lstate[2] = new_need;
+            lstate[3] = (local[e] == new_need || bits_done + width >= 64) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+    // gather exactly k survivors
+    {
+        const uint64_t prefix = lstate[0];
+        const int bits_done = (int)lstate[1];
+        for (size_t i = tid; i < n; i += blockDim.x) {
+            const uint64_t comp = src(i);
+            const uint64_t top = (bits_done == 0) ? 1 : (bits_done >= 64 ? comp : (comp >> (64 - bits_done)));
+            if (bits_done == 0 || top >= prefix) {
+                const unsigned pos = (unsigned)atomicAdd((unsigned long long*)&lstate[4], 1ull);
+                if (pos < n_pow2) lbuf[pos] = comp;
+            }
+        }
+        __syncthreads();
+        for (unsigned i = tid; i < n_pow2; i += blockDim.x)
+            if (i >= k) lbuf[i] = 0ull;
+        __syncthreads();
+    }
+    // bitonic sort, descending
     for (unsigned size = 2; size <= n_pow2; size <<= 1) {
         for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
-            for (unsigned i = threadIdx.x; i < n_pow2 / 2; i += blockDim.x) {
+            for (unsigned i = tid; i < n_pow2 / 2; i += blockDim.x) {
                 const unsigned lo = 2 * i - (i & (stride - 1));
                 const unsigned hi = lo + stride;
                 const bool desc = ((lo & size) == 0);
-                const uint64_t a = s[lo], b = s[hi];
-                if ((a < b) == desc) { s[lo] = b; s[hi] = a; }
+                const uint64_t a = lbuf[lo], b = lbuf[hi];
+                if ((a < b) == desc) { lbuf[lo] = b; lbuf[hi] = a; }
             }
             __syncthreads();
         }
     }
-    for (unsigned i = threadIdx.x; i < k; i += blockDim.x) indices[f * k + i] = ~(uint32_t)(s[i] & 0xFFFFFFFFull);
+    for (unsigned i = tid; i < k; i += blockDim.x) indices[i] = ~(uint32_t)(lbuf[i] & 0xFFFFFFFFull);
+}
+
+__global__ __launch_bounds__(FINISH_THREADS) void select_finish_kernel(
+    const float* __restrict__ coef, size_t plane_len, KeyParams kp, uint32_t* __restrict__ ctrl,
+    uint32_t* __restrict__ hist, const uint64_t* __restrict__ cand, size_t cap, size_t k, unsigned n_pow2,
+    uint32_t* __restrict__ indices) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* lbuf = reinterpret_cast<uint64_t*>(smem_raw);                      // n_pow2 entries
+    uint64_t* lstate = lbuf + n_pow2;                                            // 8 entries
+    uint32_t* lhist = reinterpret_cast<uint32_t*>(lstate + 8);                   // NBINS entries
+    uint32_t* lpart = lhist + NBINS;                                             // 256 entries
+    const size_t f = blockIdx.x;
+    const uint32_t n = ctrl[f * 2 + 1];
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < NBINS; i += blockDim.x) hist[f * NBINS + i] = 0;   // ready for the next
+    if (threadIdx.x == 0) { ctrl[f * 2 + 0] = 0; ctrl[f * 2 + 1] = 0; }                      // selection
+    if (n >= k && n <= cap) {
+        CandSource src{cand + f * cap};
+        block_select_sort(src, n, k, n_pow2, lhist, lpart, lbuf, lstate, indices + f * k);
+    } else {                                     // degenerate data: exact select over the whole plane
+        PlaneSource src{coef + f * plane_len, kp};
+        block_select_sort(src, plane_len - 1, k, n_pow2, lhist, lpart, lbuf, lstate, indices + f * k);
+    }
 }
 
 int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, size_t h, int ordering,
@@ -190,7 +305,7 @@ int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, si
     if (plane_len > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     if (k > plane_len - 1) return SSW_ERR_K_TOO_LARGE;
     if (k > MAX_K) return SSW_ERR_UNSUPPORTED;
-    if (ws.frames < n_frames || ws.cap < k) return SSW_ERR_BAD_ARG;
+    if (ws.frames < n_frames || ws.cap < select_cand_capacity(k)) return SSW_ERR_BAD_ARG;
     if (ordering < SSW_ORDER_ENERGY || ordering > SSW_ORDER_LEGACY) return SSW_ERR_UNSUPPORTED;
 
     KeyParams kp;
@@ -209,26 +324,32 @@ int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, si
                 kp.s[fr][fc] = sc;
             }
     }
-    select_init_kernel<<<(unsigned)n_frames, 256, 0, st>>>(ws.state, ws.hist, ws.cand_count, k);
-    size_t bpf = (plane_len + 256 * 16 - 1) / (256 * 16);            // >= 16 elements per thread
+    const size_t groups = (plane_len + SAMPLE_STRIDE * 4 - 1) / (SAMPLE_STRIDE * 4);
+    size_t sb = (groups + 256 * 2 - 1) / (256 * 2);
+    if (sb < 1) sb = 1;
+    if (sb > 256) sb = 256;
+    select_sample_kernel<<<dim3((unsigned)sb, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.hist);
+    // expected survivors ~ 4k (sampling noise at this depth is < 15 %); at least 32 samples deep
+    uint32_t m = (uint32_t)((4 * k + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE);
+    if (m < 32) m = 32;
+    select_sample_find_kernel<<<(unsigned)n_frames, 256, 0, st>>>(ws.ctrl, ws.hist, m);
+    size_t bpf = (plane_len + 256 * 32 - 1) / (256 * 32);             // >= 32 elements per thread
     if (bpf < 1) bpf = 1;
-    if (bpf > 1024) bpf = 1024;
-    const dim3 grid((unsigned)bpf, (unsigned)n_frames);
-    for (int p = 0; p < N_PASSES; ++p) {
-        select_hist_kernel<<<grid, 256, 0, st>>>(coef, plane_len, kp, ws.state, ws.hist);
-        select_find_kernel<<<(unsigned)n_frames, 256, 0, st>>>(ws.state, ws.hist);
-    }
-    select_compact_kernel<<<grid, 256, 0, st>>>(coef, plane_len, kp, ws.state, ws.cand, ws.cap, ws.cand_count);
+    if (bpf > 2048) bpf = 2048;
+    select_compact_kernel<<<dim3((unsigned)bpf, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.ctrl,
+                                                                                  ws.cand, ws.cap);
     unsigned n_pow2 = 2;
     while (n_pow2 < k) n_pow2 <<= 1;
-    const size_t smem = (size_t)n_pow2 * sizeof(uint64_t);
+    const size_t smem = (size_t)n_pow2 * sizeof(uint64_t) + 8 * sizeof(uint64_t) + (NBINS + 256) * sizeof(uint32_t);
     static bool attr_set = false;
     if (!attr_set) {
-        SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_sort_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(MAX_K * sizeof(uint64_t))));
+        SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_finish_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)(MAX_K * sizeof(uint64_t) + 64 + (NBINS + 256) * sizeof(uint32_t))));
         attr_set = true;
     }
-    select_sort_kernel<<<(unsigned)n_frames, 1024, smem, st>>>(ws.cand, ws.cap, k, n_pow2, indices);
+    select_finish_kernel<<<(unsigned)n_frames, FINISH_THREADS, smem, st>>>(coef, plane_len, kp, ws.ctrl, ws.hist,
+                                                                            ws.cand, ws.cap, k, n_pow2, indices);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -82,12 +82,12 @@ int launch_dct_cols_folded_f64(hipStream_t st, bool inverse, const float* in, fl
 
 // select.hip
 struct SelectWorkspace {
-    uint32_t* hist = nullptr;       // [n_frames][2048]
-    uint64_t* state = nullptr;      // [n_frames][4]: prefix, prefix_bits|resolved, need, count
-    uint64_t* cand = nullptr;       // [n_frames][cap]
-    uint32_t* cand_count = nullptr; // [n_frames]
+    uint32_t* hist = nullptr;       // [n_frames][2048] sample histogram
+    uint32_t* ctrl = nullptr;       // [n_frames][2]: threshold digit, candidate count
+    uint64_t* cand = nullptr;       // [n_frames][cap] candidate composite keys
     size_t frames = 0, cap = 0;
 };
+size_t select_cand_capacity(size_t k);   // candidate slots per frame needed for mark length k
 size_t select_max_k();
 int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, size_t h, int ordering,
                 size_t k, const SelectWorkspace& ws, uint32_t* indices);

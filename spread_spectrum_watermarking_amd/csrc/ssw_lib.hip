@@ -55,17 +55,18 @@ int grow(ssw_ctx::Buf& b, size_t bytes) {
 
 int grow_select(ssw_ctx* ctx, size_t frames, size_t k) {
     SelectWorkspace& s = ctx->sel;
-    if (s.frames >= frames && s.cap >= k && s.hist) return SSW_OK;
-    const size_t nf = std::max(frames, s.frames), cap = std::max(k, s.cap);
+    const size_t want = select_cand_capacity(k);
+    if (s.frames >= frames && s.cap >= want && s.hist) return SSW_OK;
+    const size_t nf = std::max(frames, s.frames), cap = std::max(want, s.cap);
     if (s.hist) (void)hipFree(s.hist);
-    if (s.state) (void)hipFree(s.state);
+    if (s.ctrl) (void)hipFree(s.ctrl);
     if (s.cand) (void)hipFree(s.cand);
-    if (s.cand_count) (void)hipFree(s.cand_count);
     s = SelectWorkspace();
     SSW_HIP_CHECK(hipMalloc((void**)&s.hist, nf * 2048 * sizeof(uint32_t)));
-    SSW_HIP_CHECK(hipMalloc((void**)&s.state, nf * 4 * sizeof(uint64_t)));
+    SSW_HIP_CHECK(hipMalloc((void**)&s.ctrl, nf * 2 * sizeof(uint32_t)));
     SSW_HIP_CHECK(hipMalloc((void**)&s.cand, nf * cap * sizeof(uint64_t)));
-    SSW_HIP_CHECK(hipMalloc((void**)&s.cand_count, nf * sizeof(uint32_t)));
+    SSW_HIP_CHECK(hipMemsetAsync(s.hist, 0, nf * 2048 * sizeof(uint32_t), ctx->stream));   // see select.hip:
+    SSW_HIP_CHECK(hipMemsetAsync(s.ctrl, 0, nf * 2 * sizeof(uint32_t), ctx->stream));      // zero between uses
     s.frames = nf;
     s.cap = cap;
     return SSW_OK;
@@ -246,9 +247,8 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     if (ctx->idx.p) (void)hipFree(ctx->idx.p);
     if (ctx->small.p) (void)hipFree(ctx->small.p);
     if (ctx->sel.hist) (void)hipFree(ctx->sel.hist);
-    if (ctx->sel.state) (void)hipFree(ctx->sel.state);
+    if (ctx->sel.ctrl) (void)hipFree(ctx->sel.ctrl);
     if (ctx->sel.cand) (void)hipFree(ctx->sel.cand);
-    if (ctx->sel.cand_count) (void)hipFree(ctx->sel.cand_count);
     for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
