@@ -91,6 +91,10 @@ size_t select_cand_capacity(size_t k);   // candidate slots per frame needed for
 size_t select_max_k();
 int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, size_t h, int ordering,
                 size_t k, const SelectWorkspace& ws, uint32_t* indices);
+// sort_full.hip: all W*H-1 indices of one plane in the reference's order (rocPRIM radix sort; not hot)
+int full_sort_scratch_bytes(size_t plane_len, size_t* bytes);
+int launch_full_sort(hipStream_t st, const float* coef, size_t w, size_t h, int ordering, void* scratch,
+                     size_t scratch_bytes, uint32_t* indices_out, size_t k);
 int launch_embed(hipStream_t st, float* coef, size_t n_frames, size_t plane_len,
                  const uint32_t* indices, size_t idx_stride, const float* marks,
                  const uint32_t* mark_offsets, const uint32_t* mark_lens, size_t n_marks,
@@ -124,6 +128,7 @@ struct ssw_ctx {
     Buf idx;                      // [chunk][k] u32
     ssw::SelectWorkspace sel;
     Buf small;                    // misc (mark offsets, sims, ...)
+    Buf sort_scratch;             // full-order sort (lazy, Reader::indices beyond the top-k limit)
 
     // timing
     bool timing = false;

@@ -180,6 +180,17 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
 }
 
 int topk(ssw_ctx* ctx, const float* coef, size_t n, size_t w, size_t h, int ordering, size_t k, uint32_t* idx) {
+    if (k > select_max_k()) {
+        // beyond the in-LDS top-k limit: full device sort of each plane, first k entries kept
+        size_t bytes = 0;
+        SSW_TRY(full_sort_scratch_bytes(w * h, &bytes));
+        SSW_TRY(grow(ctx->sort_scratch, bytes));
+        StageTimer t(ctx, SSW_STAGE_SELECT);
+        for (size_t f = 0; f < n; ++f)
+            SSW_TRY(launch_full_sort(ctx->stream, coef + f * w * h, w, h, ordering, ctx->sort_scratch.p,
+                                     ctx->sort_scratch.bytes, idx + f * k, k));
+        return SSW_OK;
+    }
     SSW_TRY(grow_select(ctx, n, k));
     StageTimer t(ctx, SSW_STAGE_SELECT);
     return launch_topk(ctx->stream, coef, n, w, h, ordering, k, ctx->sel, idx);
@@ -246,6 +257,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     for (auto& b : ctx->plane) if (b.p) (void)hipFree(b.p);
     if (ctx->idx.p) (void)hipFree(ctx->idx.p);
     if (ctx->small.p) (void)hipFree(ctx->small.p);
+    if (ctx->sort_scratch.p) (void)hipFree(ctx->sort_scratch.p);
     if (ctx->sel.hist) (void)hipFree(ctx->sel.hist);
     if (ctx->sel.ctrl) (void)hipFree(ctx->sel.ctrl);
     if (ctx->sel.cand) (void)hipFree(ctx->sel.cand);
@@ -417,7 +429,6 @@ int ssw_batch_embed(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_rgb, s
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
     const size_t plane = w * h;
     const size_t k_eff = std::min(k, plane - 1);                       // zip() truncation, :396
-    if (k_eff > select_max_k()) return SSW_ERR_UNSUPPORTED;
     DeviceGuard g(ctx->device);
     const size_t chunk = std::min(std::max<size_t>(ctx->chunk_frames, 1), std::max<size_t>(n_frames, 1));
     for (int p = 0; p < 4; ++p) SSW_TRY(grow(ctx->plane[p], chunk * plane * sizeof(float)));
@@ -466,7 +477,6 @@ int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
     const size_t plane = w * h;
     if (k >= plane) return SSW_ERR_K_TOO_LARGE;                        // :553-555
-    if (k > select_max_k()) return SSW_ERR_UNSUPPORTED;
     DeviceGuard g(ctx->device);
     const size_t chunk = std::min(std::max<size_t>(ctx->chunk_frames, 1), std::max<size_t>(n_frames, 1));
     for (int p = 0; p < 3; ++p) SSW_TRY(grow(ctx->plane[p], chunk * plane * sizeof(float)));
@@ -557,7 +567,6 @@ int ssw_writer_embed(ssw_writer* wr, const float* const* marks, const size_t* le
         total += len; max_len = std::max(max_len, len);
     }
     if (max_len == 0) return SSW_OK;
-    if (max_len > select_max_k()) return SSW_ERR_UNSUPPORTED;
     std::vector<float> packed(total);
     for (size_t m = 0; m < n_marks; ++m)
         if (lns[m]) std::memcpy(packed.data() + offs[m], marks[m], lns[m] * sizeof(float));
@@ -659,7 +668,6 @@ static int reader_ensure_indices(ssw_reader* rd, size_t k) {
     if (!rd->is_base) return SSW_ERR_NOT_BASE;                        // base.unwrap(), :507 / :530
     if (k > rd->w * rd->h - 1) return SSW_ERR_K_TOO_LARGE;
     if (k <= rd->idx_k) return SSW_OK;
-    if (k > select_max_k()) return SSW_ERR_UNSUPPORTED;
     ssw_ctx* ctx = rd->ctx;
     if (rd->idx) { SSW_HIP_CHECK(hipFree(rd->idx)); rd->idx = nullptr; rd->idx_k = 0; }
     SSW_HIP_CHECK(hipMalloc((void**)&rd->idx, k * sizeof(uint32_t)));

@@ -202,6 +202,32 @@ def test_topk_matches_oracle_on_real_coefficients(ordering, cat_images):
         assert np.array_equal(G.topk(c, k, ordering), O.indices(c, ordering, k=k))
 
 
+@pytest.mark.parametrize("ordering", ORDERINGS)
+def test_full_index_list_matches_oracle(ordering, cat_images):
+    """Reader::indices() (algorithm.rs:506-508): the whole W*H-1 list, beyond the in-LDS top-k limit."""
+    y = O.rgb_to_yiq(u8_to_f32(cat_images["cat"]))[0]
+    c = O.dct2d(y)[:200, :320].copy()                                  # 64 000 coefficients
+    c[5, 7] = c[9, 11]; c[100, 3] = -c[9, 11]                          # exact energy ties
+    full = O.indices(c, ordering)
+    for k in (20000, c.size - 1):
+        assert np.array_equal(G.topk(c, k, ordering), full[:k])
+
+
+def test_reader_indices_full_list_and_long_mark(cat_images):
+    rgb = O.synth_frame(11, 0, 256, 144)
+    reader = wm.Reader.base(rgb)
+    coef = reader.coefficients().reshape(144, 256)
+    full = reader.indices()                                            # k = None -> all n-1
+    assert full.shape == (256 * 144 - 1,)
+    assert np.array_equal(full, O.indices(coef))
+    assert np.array_equal(reader.indices(1000), full[:1000])           # cached prefix
+    mark = np.random.default_rng(3).standard_normal(20000).astype(np.float32)   # > 16384 coefficients
+    w = wm.Writer(rgb)
+    c0 = w.coefficient_image()
+    w.embed([mark])
+    assert np.array_equal(w.coefficient_image(), O.embed(c0, O.indices(c0, k=20000), [mark]))
+
+
 def test_topk_degenerate_planes():
     z = np.zeros((2, 9, 13), np.float32)                               # every key ties: index order
     assert np.array_equal(G.topk(z, 50)[0], np.arange(1, 51))
