@@ -263,6 +263,23 @@ def main():
             "sample": f"1 frame {W}x{H} (frame 0 of the batch), embed+extract+similarity, oracle C restatement: "
                       f"f32 FFT DCT + full stable sort like the reference, single thread, {cpu_s:.1f} s",
         }
+        # same work, one frame per thread on the host's cores (the reference itself is single-threaded;
+        # this is the frame-parallel upper bound of SURVEY 8(d)).  ctypes releases the GIL in the C calls.
+        import concurrent.futures as cf
+        n_thr = max(1, min(os.cpu_count() or 1, 16))
+
+        def one(_):
+            m = O.embed_frame(frame0, mark0, backend=O.BACKEND_F32, full_sort=True)
+            O.extract_frame(frame0, m, mark0, backend=O.BACKEND_F32, full_sort=True)
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(n_thr) as ex:
+            list(ex.map(one, range(n_thr)))
+        par_s = time.perf_counter() - t0
+        result["cpu_baseline_parallel"] = {
+            "value": round(n_thr * W * H / 1e6 / par_s, 4), "unit": "Mpix/s", "cores": n_thr, "kind": "port",
+            "sample": f"{n_thr} frames {W}x{H}, one per thread ({os.cpu_count()} logical cores on the host), "
+                      f"same faithful pipeline, {par_s:.1f} s",
+        }
         # untimed: the oracle's correctly rounded (f64-backend) pipeline = what the canonical precision must equal
         ref_marked = O.embed_frame(frame0, mark0, backend=O.BACKEND_F64, full_sort=False)
         ref_ext, ref_sim = O.extract_frame(frame0, ref_marked, mark0, backend=O.BACKEND_F64, full_sort=False)
