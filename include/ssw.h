@@ -123,7 +123,9 @@ typedef enum ssw_stage {
     SSW_STAGE_EXTRACT = 5,
     SSW_STAGE_SIMILARITY = 6,
     SSW_STAGE_YIQ_TO_RGB = 7,
-    SSW_STAGE_COUNT = 8
+    SSW_STAGE_RESIZE = 8,         /* CatmullRom resize of the attack harness         */
+    SSW_STAGE_CONVERT = 9,        /* u8 <-> f32 frame conversion                     */
+    SSW_STAGE_COUNT = 10
 } ssw_stage;
 int ssw_ctx_enable_timing(ssw_ctx* ctx, int enable);
 int ssw_ctx_reset_timing(ssw_ctx* ctx);
@@ -189,6 +191,26 @@ int ssw_batch_embed(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_rgb, s
 int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base_rgb,
                       const float* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
                       float* dev_extracted, const float* dev_marks, float* dev_sims);
+
+/* ---- 8-bit frames and the resize attack (device-resident, batched) --------- */
+/* Arithmetic of the third-party `image 0.24.3` crate, restated from its published behaviour
+   (parity unpinned beyond the reference's similarity asserts; identical to the CPU oracle). */
+/* `DynamicImage::into_rgb32f()` for 8-bit input (call sites src/algorithm.rs:308, :476): v / 255. */
+int ssw_convert_rgb8_to_f32(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_values, float* dev_out);
+/* `DynamicImage::into_rgb8()` from Rgb32F (tests/single_simple.rs:28): round(clamp(v,0,1) * 255). */
+int ssw_convert_f32_to_rgb8(ssw_ctx* ctx, const float* dev_in, size_t n_values, uint8_t* dev_out);
+/* `image::imageops::resize(img, nw, nh, FilterType::CatmullRom)` (tests/attack_resize.rs:17-36) on
+   n_frames RGB8 frames [h][w][3] -> [nh][nw][3]. */
+int ssw_resize_rgb8(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_frames, size_t w, size_t h, size_t nw,
+                    size_t nh, uint8_t* dev_out);
+/* ssw_batch_embed / ssw_batch_extract on 8-bit frames: the u8 -> f32 conversion is fused into the
+   colour kernels (3 instead of 12 B/px at the boundary); the embedded frames come back quantised
+   like `into_rgb8()`.  Same reference lines as the f32 forms. */
+int ssw_batch_embed_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* dev_rgb, size_t n_frames,
+                         size_t w, size_t h, const float* dev_marks, size_t k, uint8_t* dev_rgb_out);
+int ssw_batch_extract_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* dev_base_rgb,
+                           const uint8_t* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
+                           float* dev_extracted, const float* dev_marks, float* dev_sims);
 
 /* ---- single-image handles mirroring the crate's types (host buffers) ------- */
 /* Writer::new(image, config), src/algorithm.rs:295-316.  rgb_hwc: host [h][w][3]

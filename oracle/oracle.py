@@ -58,6 +58,15 @@ def _load() -> C.CDLL:
     lib.sswo_similarity.restype = C.c_float
     lib.sswo_synth_frame.argtypes = [C.c_uint32, C.c_uint32, C.c_size_t, C.c_size_t, _f32p]
     lib.sswo_synth_frame.restype = None
+    _u8p = C.POINTER(C.c_uint8)
+    lib.sswo_u8_to_f32.argtypes = [_u8p, C.c_size_t, _f32p]
+    lib.sswo_u8_to_f32.restype = None
+    lib.sswo_f32_to_u8.argtypes = [_f32p, C.c_size_t, _u8p]
+    lib.sswo_f32_to_u8.restype = None
+    lib.sswo_resize_rgb8.argtypes = [_u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _u8p]
+    lib.sswo_resize_rgb8.restype = None
+    lib.sswo_resize_taps.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32), _f32p, C.c_size_t]
+    lib.sswo_resize_taps.restype = C.c_size_t
     lib.sswo_embed_frame.argtypes = [_f32p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                      C.c_float, _f32p, C.c_size_t, C.c_int, _f32p]
     lib.sswo_embed_frame.restype = None
@@ -212,3 +221,43 @@ def extract_frame(base_rgb, derived_rgb, mark, backend=BACKEND_F64, ordering=ORD
     sim = lib().sswo_extract_frame(_p(b), _p(d), w, h, backend, ordering, method, C.c_float(alpha),
                                    _p(mark), mark.size, int(full_sort), _p(ext))
     return ext, float(sim)
+
+
+def u8_to_f32(img_u8):
+    """`into_rgb32f` for 8-bit input: v / 255."""
+    a = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    out = np.empty(a.shape, np.float32)
+    lib().sswo_u8_to_f32(a.ctypes.data_as(C.POINTER(C.c_uint8)), a.size, _p(out))
+    return out
+
+
+def f32_to_u8(img_f32):
+    """`into_rgb8` from Rgb32F: round(clamp(v, 0, 1) * 255)."""
+    a = _f32(img_f32)
+    out = np.empty(a.shape, np.uint8)
+    lib().sswo_f32_to_u8(_p(a), a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def resize_rgb8(img_u8, new_w, new_h):
+    """image::imageops::resize(img, new_w, new_h, CatmullRom) on an [H, W, 3] uint8 image."""
+    a = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = a.shape[:2]
+    out = np.empty((new_h, new_w, 3), np.uint8)
+    u8p = C.POINTER(C.c_uint8)
+    lib().sswo_resize_rgb8(a.ctypes.data_as(u8p), w, h, new_w, new_h, out.ctypes.data_as(u8p))
+    return out
+
+
+def resize_taps(in_len, out_len):
+    """(left[out_len] uint32, ntaps[out_len] uint32, weights[out_len, max_taps] f32) exactly as the
+    oracle computes them (f32 arithmetic); used to check the device's tap tables."""
+    max_t = int(4 * max(1.0, in_len / out_len)) + 4
+    left = np.zeros(out_len, np.uint32); nt = np.zeros(out_len, np.uint32)
+    ws = np.zeros((out_len, max_t), np.float32)
+    l = C.c_uint32()
+    for o in range(out_len):
+        row = np.zeros(max_t, np.float32)
+        n = lib().sswo_resize_taps(in_len, out_len, o, C.byref(l), _p(row), max_t)
+        left[o], nt[o], ws[o] = l.value, n, row
+    return left, nt, ws

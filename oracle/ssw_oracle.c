@@ -429,3 +429,85 @@ float sswo_extract_frame(const float* base_rgb, const float* derived_rgb, size_t
     free(idx); free(yb); free(yd); free(i); free(q);
     return sim;
 }
+
+/* ---- 8-bit boundary and the resize attack (third-party `image 0.24.3`, NOT in the reference tree) --
+ * Semantics restated from the published behaviour of the crate; "parity unpinned" beyond the
+ * reference's own statistical asserts (tests/attack_resize.rs:65-66: sim > 9.5, published 9.85).
+ *   into_rgb32f for 8-bit input : v / 255                      (call sites src/algorithm.rs:308, :476)
+ *   into_rgb8 from Rgb32F       : round(clamp(v, 0, 1) * 255)  (tests/single_simple.rs:28)
+ *   imageops::resize(CatmullRom): vertical pass into f32, then horizontal pass, clamp + round to
+ *                                 u8 (tests/attack_resize.rs:17-36); cubic B = 0, C = 1/2, support 2,
+ *                                 support and kernel argument scaled by max(1, in/out).          */
+void sswo_u8_to_f32(const uint8_t* in, size_t n, float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = (float)in[i] / 255.0f;
+}
+void sswo_f32_to_u8(const float* in, size_t n, uint8_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        const float v = clampf(in[i], 0.0f, 1.0f) * 255.0f;
+        out[i] = (uint8_t)roundf(v);
+    }
+}
+
+static float catmullrom_kernel(float x) {          /* bc_cubic_spline(x, b = 0, c = 0.5) */
+    const float b = 0.0f, c = 0.5f;
+    const float a = fabsf(x);
+    float k;
+    if (a < 1.0f)
+        k = (12.0f - 9.0f * b - 6.0f * c) * (a * a * a) + (-18.0f + 12.0f * b + 6.0f * c) * (a * a) + (6.0f - 2.0f * b);
+    else if (a < 2.0f)
+        k = (-b - 6.0f * c) * (a * a * a) + (6.0f * b + 30.0f * c) * (a * a) + (-12.0f * b - 48.0f * c) * a + (8.0f * b + 24.0f * c);
+    else
+        k = 0.0f;
+    return k / 6.0f;
+}
+
+/* Filter taps of one output line: first input index and normalised weights (<= max_taps). */
+size_t sswo_resize_taps(size_t in_len, size_t out_len, size_t out_idx, uint32_t* left_out, float* ws, size_t max_taps) {
+    const float ratio = (float)in_len / (float)out_len;
+    const float sratio = ratio < 1.0f ? 1.0f : ratio;
+    const float src_support = 2.0f * sratio;
+    float inputc = ((float)out_idx + 0.5f) * ratio;
+    int64_t left = (int64_t)floorf(inputc - src_support);
+    if (left < 0) left = 0;
+    if (left > (int64_t)in_len - 1) left = (int64_t)in_len - 1;
+    int64_t right = (int64_t)ceilf(inputc + src_support);
+    if (right < left + 1) right = left + 1;
+    if (right > (int64_t)in_len) right = (int64_t)in_len;
+    inputc = inputc - 0.5f;
+    size_t n = 0;
+    float sum = 0.0f;
+    for (int64_t i = left; i < right && n < max_taps; ++i) {
+        const float w = catmullrom_kernel(((float)i - inputc) / sratio);
+        ws[n++] = w;
+        sum += w;
+    }
+    for (size_t i = 0; i < n; ++i) ws[i] /= sum;
+    *left_out = (uint32_t)left;
+    return n;
+}
+
+void sswo_resize_rgb8(const uint8_t* in, size_t w, size_t h, size_t nw, size_t nh, uint8_t* out) {
+    if (nw == w && nh == h) { memcpy(out, in, w * h * 3); return; }
+    enum { MAXT = 4096 };
+    float* tmp = (float*)malloc(sizeof(float) * w * nh * 3);
+    float* ws = (float*)malloc(sizeof(float) * MAXT);
+    for (size_t oy = 0; oy < nh; ++oy) {                       /* vertical_sample */
+        uint32_t left; const size_t nt = sswo_resize_taps(h, nh, oy, &left, ws, MAXT);
+        for (size_t x = 0; x < w; ++x)
+            for (int c = 0; c < 3; ++c) {
+                float t = 0.0f;
+                for (size_t i = 0; i < nt; ++i) t += (float)in[((left + i) * w + x) * 3 + c] * ws[i];
+                tmp[(oy * w + x) * 3 + c] = t;
+            }
+    }
+    for (size_t ox = 0; ox < nw; ++ox) {                       /* horizontal_sample */
+        uint32_t left; const size_t nt = sswo_resize_taps(w, nw, ox, &left, ws, MAXT);
+        for (size_t y = 0; y < nh; ++y)
+            for (int c = 0; c < 3; ++c) {
+                float t = 0.0f;
+                for (size_t i = 0; i < nt; ++i) t += tmp[(y * w + left + i) * 3 + c] * ws[i];
+                out[(y * nw + ox) * 3 + c] = (uint8_t)roundf(clampf(t, 0.0f, 255.0f));
+            }
+    }
+    free(ws); free(tmp);
+}

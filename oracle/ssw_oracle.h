@@ -77,6 +77,13 @@ float sswo_similarity(const float* extracted, const float* mark, size_t k);
    the device generator ssw_synth_frames().  Not part of the reference. */
 void sswo_synth_frame(uint32_t seed, uint32_t frame, size_t w, size_t h, float* rgb);
 
+/* 8-bit boundary + CatmullRom resize of the attack harness (third-party `image 0.24.3` semantics,
+   parity unpinned; see the .c file). */
+void sswo_u8_to_f32(const uint8_t* in, size_t n, float* out);
+void sswo_f32_to_u8(const float* in, size_t n, uint8_t* out);
+size_t sswo_resize_taps(size_t in_len, size_t out_len, size_t out_idx, uint32_t* left_out, float* ws, size_t max_taps);
+void sswo_resize_rgb8(const uint8_t* in, size_t w, size_t h, size_t nw, size_t nh, uint8_t* out);
+
 /* Whole-path helpers used by the cpu_baseline leg: Writer::new + mark
    (algorithm.rs:295-379) and Reader::base + derived + extract + similarity
    (:462-562, :696-714) for one frame.  `full_sort` != 0 sorts all n-1

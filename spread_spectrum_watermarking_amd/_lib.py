@@ -24,7 +24,8 @@ ORDER_ENERGY, ORDER_ENERGY_ORTHOGONAL, ORDER_LEGACY, ORDER_CUSTOM = 0, 1, 2, 3
 OPTION1, OPTION2, OPTION3, METHOD_CUSTOM = 1, 2, 3, 4
 DCT2, DCT2_ORTHOGONAL, DCT3 = 0, 1, 2
 PRECISION_F32, PRECISION_F64 = 0, 1
-STAGES = ["rgb_to_yiq", "dct_row", "dct_col", "select", "embed", "extract", "similarity", "yiq_to_rgb"]
+STAGES = ["rgb_to_yiq", "dct_row", "dct_col", "select", "embed", "extract", "similarity", "yiq_to_rgb",
+          "resize", "convert"]
 
 
 class Config(C.Structure):
@@ -62,6 +63,11 @@ SIGNATURES = {
     "ssw_similarity_batch": (C.c_int, [_vp, _f32p, _f32p, _sz, _sz, _f32p]),
     "ssw_batch_embed": (C.c_int, [_vp, _cfgp, _f32p, _sz, _sz, _sz, _f32p, _sz, _f32p, _f32p, _u32p]),
     "ssw_batch_extract": (C.c_int, [_vp, _cfgp, _f32p, _f32p, _sz, _sz, _sz, _sz, _f32p, _f32p, _f32p]),
+    "ssw_convert_rgb8_to_f32": (C.c_int, [_vp, _vp, _sz, _f32p]),
+    "ssw_convert_f32_to_rgb8": (C.c_int, [_vp, _f32p, _sz, _vp]),
+    "ssw_resize_rgb8": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
+    "ssw_batch_embed_rgb8": (C.c_int, [_vp, _cfgp, _vp, _sz, _sz, _sz, _f32p, _sz, _vp]),
+    "ssw_batch_extract_rgb8": (C.c_int, [_vp, _cfgp, _vp, _vp, _sz, _sz, _sz, _sz, _f32p, _f32p, _f32p]),
     "ssw_writer_create": (C.c_int, [_vp, _vp, _sz, _sz, _cfgp, C.POINTER(_vp)]),
     "ssw_writer_coefficients": (C.c_int, [_vp, _vp]),
     "ssw_writer_embed": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz]),

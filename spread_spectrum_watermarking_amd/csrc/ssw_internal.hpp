@@ -9,6 +9,7 @@
 #include <map>
 #include <string>
 #include <tuple>
+#include <utility>
 #include <vector>
 
 #include "../../include/ssw.h"
@@ -91,6 +92,26 @@ size_t select_cand_capacity(size_t k);   // candidate slots per frame needed for
 size_t select_max_k();
 int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, size_t h, int ordering,
                 size_t k, const SelectWorkspace& ws, uint32_t* indices);
+// attack.hip: 8-bit boundary + CatmullRom resize (third-party `image` crate semantics)
+struct ResizeTaps {                 // host side
+    uint32_t max_taps = 0;
+    std::vector<uint32_t> left, count;
+    std::vector<float> weights;     // [out_len][max_taps]
+};
+struct DeviceTaps {
+    uint32_t* left = nullptr;
+    uint32_t* count = nullptr;
+    float* weights = nullptr;
+    uint32_t max_taps = 0;
+};
+void build_resize_taps(size_t in_len, size_t out_len, ResizeTaps& t);
+int launch_u8_to_f32(hipStream_t st, const uint8_t* in, size_t n, float* out);
+int launch_f32_to_u8(hipStream_t st, const float* in, size_t n, uint8_t* out);
+int launch_rgb8_to_yiq(hipStream_t st, const uint8_t* rgb, size_t npix, float* y, float* i, float* q);
+int launch_yiq_to_rgb8(hipStream_t st, const float* y, const float* i, const float* q, size_t npix, uint8_t* rgb);
+int launch_resize_rgb8(hipStream_t st, const uint8_t* in, size_t n_frames, size_t w, size_t h, size_t nw, size_t nh,
+                       const DeviceTaps& vt, const DeviceTaps& ht, float* tmp, uint8_t* out);
+
 // sort_full.hip: all W*H-1 indices of one plane in the reference's order (rocPRIM radix sort; not hot)
 int full_sort_scratch_bytes(size_t plane_len, size_t* bytes);
 int launch_full_sort(hipStream_t st, const float* coef, size_t w, size_t h, int ordering, void* scratch,
@@ -129,6 +150,8 @@ struct ssw_ctx {
     ssw::SelectWorkspace sel;
     Buf small;                    // misc (mark offsets, sims, ...)
     Buf sort_scratch;             // full-order sort (lazy, Reader::indices beyond the top-k limit)
+    Buf resize_tmp;               // f32 intermediate of the resize's vertical pass
+    std::map<std::pair<size_t, size_t>, ssw::DeviceTaps> taps;   // (in_len, out_len) -> filter taps
 
     // timing
     bool timing = false;

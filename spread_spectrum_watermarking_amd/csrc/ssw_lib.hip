@@ -258,6 +258,8 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     if (ctx->idx.p) (void)hipFree(ctx->idx.p);
     if (ctx->small.p) (void)hipFree(ctx->small.p);
     if (ctx->sort_scratch.p) (void)hipFree(ctx->sort_scratch.p);
+    if (ctx->resize_tmp.p) (void)hipFree(ctx->resize_tmp.p);
+    for (auto& kv : ctx->taps) { (void)hipFree(kv.second.left); (void)hipFree(kv.second.count); (void)hipFree(kv.second.weights); }
     if (ctx->sel.hist) (void)hipFree(ctx->sel.hist);
     if (ctx->sel.ctrl) (void)hipFree(ctx->sel.ctrl);
     if (ctx->sel.cand) (void)hipFree(ctx->sel.cand);
@@ -421,14 +423,23 @@ int ssw_similarity_batch(ssw_ctx* ctx, const float* dev_extracted, const float* 
 }
 
 // ---- whole path, batched --------------------------------------------------------------------
-int ssw_batch_embed(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_rgb, size_t n_frames,
-                    size_t w, size_t h, const float* dev_marks, size_t k, float* dev_rgb_out,
-                    float* dev_coef_out, uint32_t* dev_indices_out) {
+namespace {
+
+int rgb_in_to_yiq(ssw_ctx* ctx, const void* rgb, bool u8, size_t first_px, size_t npix, float* y, float* i, float* q) {
+    StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
+    if (u8) return launch_rgb8_to_yiq(ctx->stream, static_cast<const uint8_t*>(rgb) + first_px * 3, npix, y, i, q);
+    return launch_rgb_to_yiq(ctx->stream, static_cast<const float*>(rgb) + first_px * 3, npix, y, i, q);
+}
+
+int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, bool u8_in, size_t n_frames,
+                     size_t w, size_t h, const float* dev_marks, size_t k, void* dev_rgb_out, bool u8_out,
+                     float* dev_coef_out, uint32_t* dev_indices_out) {
     if (!ctx || !dev_rgb || !dev_marks || !dev_rgb_out) return SSW_ERR_BAD_ARG;
     SSW_TRY(check_config(cfg));
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
     const size_t plane = w * h;
     const size_t k_eff = std::min(k, plane - 1);                       // zip() truncation, :396
+    if (k_eff != k) return SSW_ERR_UNSUPPORTED;                        // k > w*h-1 in the batch path: use the Writer handle
     DeviceGuard g(ctx->device);
     const size_t chunk = std::min(std::max<size_t>(ctx->chunk_frames, 1), std::max<size_t>(n_frames, 1));
     for (int p = 0; p < 4; ++p) SSW_TRY(grow(ctx->plane[p], chunk * plane * sizeof(float)));
@@ -439,38 +450,31 @@ int ssw_batch_embed(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_rgb, s
     float* tmp = (float*)ctx->plane[3].p;
     for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const size_t n = std::min(chunk, n_frames - f0);
-        {   // Writer::new: rgb -> yiq (:308), DCT (:313)
-            StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
-            SSW_TRY(launch_rgb_to_yiq(ctx->stream, dev_rgb + f0 * plane * 3, n * plane, y, pi, pq));
-        }
-        SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, y, tmp));
+        SSW_TRY(rgb_in_to_yiq(ctx, dev_rgb, u8_in, f0 * plane, n * plane, y, pi, pq));   // Writer::new :308
+        SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, y, tmp));          // :313
         if (dev_coef_out)
             SSW_HIP_CHECK(hipMemcpyAsync(dev_coef_out + f0 * plane, y, n * plane * sizeof(float),
                                          hipMemcpyDeviceToDevice, ctx->stream));
         uint32_t* idx = dev_indices_out ? dev_indices_out + f0 * k_eff : (uint32_t*)ctx->idx.p;
         if (k_eff > 0) {
-            SSW_TRY(topk(ctx, y, n, w, h, cfg->ordering, k_eff, idx));          // :314 (first k only)
-            StageTimer t(ctx, SSW_STAGE_EMBED);                                 // :356
-            // marks are [frame][k]; only the first k_eff values of each are used
-            if (k_eff == k) {
-                SSW_TRY(launch_embed(ctx->stream, y, n, plane, idx, k_eff, dev_marks + f0 * k, nullptr, nullptr,
-                                     1, k_eff, cfg->method, cfg->alpha));
-            } else {
-                return SSW_ERR_UNSUPPORTED;   // k > w*h-1 in the batch path: use the Writer handle
-            }
+            SSW_TRY(topk(ctx, y, n, w, h, cfg->ordering, k_eff, idx));                  // :314 (first k only)
+            StageTimer t(ctx, SSW_STAGE_EMBED);                                         // :356
+            SSW_TRY(launch_embed(ctx->stream, y, n, plane, idx, k_eff, dev_marks + f0 * k, nullptr, nullptr,
+                                 1, k_eff, cfg->method, cfg->alpha));
         }
-        SSW_TRY(dct2d_planes(ctx, SSW_DCT3, cfg->precision, n, w, h, y, tmp));   // :368-374
+        SSW_TRY(dct2d_planes(ctx, SSW_DCT3, cfg->precision, n, w, h, y, tmp));           // :368-374
         {
-            StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB);                            // :377
-            SSW_TRY(launch_yiq_to_rgb(ctx->stream, y, pi, pq, n * plane, dev_rgb_out + f0 * plane * 3));
+            StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB);                                    // :377 (+ into_rgb8)
+            if (u8_out) SSW_TRY(launch_yiq_to_rgb8(ctx->stream, y, pi, pq, n * plane, static_cast<uint8_t*>(dev_rgb_out) + f0 * plane * 3));
+            else        SSW_TRY(launch_yiq_to_rgb(ctx->stream, y, pi, pq, n * plane, static_cast<float*>(dev_rgb_out) + f0 * plane * 3));
         }
     }
     return SSW_OK;
 }
 
-int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base_rgb,
-                      const float* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
-                      float* dev_extracted, const float* dev_marks, float* dev_sims) {
+int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base_rgb, const void* dev_derived_rgb,
+                       bool u8, size_t n_frames, size_t w, size_t h, size_t k, float* dev_extracted,
+                       const float* dev_marks, float* dev_sims) {
     if (!ctx || !dev_base_rgb || !dev_derived_rgb || !dev_extracted) return SSW_ERR_BAD_ARG;
     if ((dev_marks == nullptr) != (dev_sims == nullptr)) return SSW_ERR_BAD_ARG;
     SSW_TRY(check_config(cfg));
@@ -487,16 +491,11 @@ int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base
     uint32_t* idx = (uint32_t*)ctx->idx.p;
     for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const size_t n = std::min(chunk, n_frames - f0);
-        {   // Reader::base (:474-480): only the Y plane is ever used by a reader
-            StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
-            SSW_TRY(launch_rgb_to_yiq(ctx->stream, dev_base_rgb + f0 * plane * 3, n * plane, yb, nullptr, nullptr));
-        }
+        // Reader::base (:474-480): only the Y plane is ever used by a reader
+        SSW_TRY(rgb_in_to_yiq(ctx, dev_base_rgb, u8, f0 * plane, n * plane, yb, nullptr, nullptr));
         SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, yb, tmp));
         if (k > 0) SSW_TRY(topk(ctx, yb, n, w, h, cfg->ordering, k, idx));      // :493
-        {   // Reader::derived
-            StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
-            SSW_TRY(launch_rgb_to_yiq(ctx->stream, dev_derived_rgb + f0 * plane * 3, n * plane, yd, nullptr, nullptr));
-        }
+        SSW_TRY(rgb_in_to_yiq(ctx, dev_derived_rgb, u8, f0 * plane, n * plane, yd, nullptr, nullptr));   // Reader::derived
         SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, yd, tmp));
         if (k > 0) {
             StageTimer t(ctx, SSW_STAGE_EXTRACT);                               // :529-539
@@ -507,6 +506,91 @@ int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base
             StageTimer t(ctx, SSW_STAGE_SIMILARITY);                            // :696-714
             SSW_TRY(launch_similarity(ctx->stream, dev_extracted + f0 * k, dev_marks + f0 * k, n, k, dev_sims + f0));
         }
+    }
+    return SSW_OK;
+}
+
+int get_taps(ssw_ctx* ctx, size_t in_len, size_t out_len, DeviceTaps* out) {
+    auto key = std::make_pair(in_len, out_len);
+    auto it = ctx->taps.find(key);
+    if (it != ctx->taps.end()) { *out = it->second; return SSW_OK; }
+    ResizeTaps host;
+    build_resize_taps(in_len, out_len, host);
+    DeviceTaps d;
+    d.max_taps = host.max_taps;
+    SSW_HIP_CHECK(hipMalloc((void**)&d.left, out_len * sizeof(uint32_t)));
+    SSW_HIP_CHECK(hipMalloc((void**)&d.count, out_len * sizeof(uint32_t)));
+    SSW_HIP_CHECK(hipMalloc((void**)&d.weights, host.weights.size() * sizeof(float)));
+    SSW_HIP_CHECK(hipMemcpy(d.left, host.left.data(), out_len * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SSW_HIP_CHECK(hipMemcpy(d.count, host.count.data(), out_len * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SSW_HIP_CHECK(hipMemcpy(d.weights, host.weights.data(), host.weights.size() * sizeof(float), hipMemcpyHostToDevice));
+    ctx->taps[key] = d;
+    *out = d;
+    return SSW_OK;
+}
+
+}  // namespace
+
+int ssw_batch_embed(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_rgb, size_t n_frames,
+                    size_t w, size_t h, const float* dev_marks, size_t k, float* dev_rgb_out,
+                    float* dev_coef_out, uint32_t* dev_indices_out) {
+    return batch_embed_impl(ctx, cfg, dev_rgb, false, n_frames, w, h, dev_marks, k, dev_rgb_out, false,
+                            dev_coef_out, dev_indices_out);
+}
+
+int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base_rgb,
+                      const float* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
+                      float* dev_extracted, const float* dev_marks, float* dev_sims) {
+    return batch_extract_impl(ctx, cfg, dev_base_rgb, dev_derived_rgb, false, n_frames, w, h, k, dev_extracted,
+                              dev_marks, dev_sims);
+}
+
+int ssw_batch_embed_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* dev_rgb, size_t n_frames,
+                         size_t w, size_t h, const float* dev_marks, size_t k, uint8_t* dev_rgb_out) {
+    return batch_embed_impl(ctx, cfg, dev_rgb, true, n_frames, w, h, dev_marks, k, dev_rgb_out, true, nullptr, nullptr);
+}
+
+int ssw_batch_extract_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* dev_base_rgb,
+                           const uint8_t* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
+                           float* dev_extracted, const float* dev_marks, float* dev_sims) {
+    return batch_extract_impl(ctx, cfg, dev_base_rgb, dev_derived_rgb, true, n_frames, w, h, k, dev_extracted,
+                              dev_marks, dev_sims);
+}
+
+// ---- 8-bit boundary and the resize attack ---------------------------------------------------------
+int ssw_convert_rgb8_to_f32(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_values, float* dev_out) {
+    if (!ctx || (n_values && (!dev_in || !dev_out))) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    StageTimer t(ctx, SSW_STAGE_CONVERT);
+    return launch_u8_to_f32(ctx->stream, dev_in, n_values, dev_out);
+}
+
+int ssw_convert_f32_to_rgb8(ssw_ctx* ctx, const float* dev_in, size_t n_values, uint8_t* dev_out) {
+    if (!ctx || (n_values && (!dev_in || !dev_out))) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    StageTimer t(ctx, SSW_STAGE_CONVERT);
+    return launch_f32_to_u8(ctx->stream, dev_in, n_values, dev_out);
+}
+
+int ssw_resize_rgb8(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_frames, size_t w, size_t h, size_t nw,
+                    size_t nh, uint8_t* dev_out) {
+    if (!ctx || !dev_in || !dev_out) return SSW_ERR_BAD_ARG;
+    if (w == 0 || h == 0 || nw == 0 || nh == 0) return SSW_ERR_BAD_DIMS;
+    DeviceGuard g(ctx->device);
+    if (nw == w && nh == h) {                         // the crate copies when the size is unchanged
+        SSW_HIP_CHECK(hipMemcpyAsync(dev_out, dev_in, n_frames * w * h * 3, hipMemcpyDeviceToDevice, ctx->stream));
+        return SSW_OK;
+    }
+    DeviceTaps vt, ht;
+    SSW_TRY(get_taps(ctx, h, nh, &vt));
+    SSW_TRY(get_taps(ctx, w, nw, &ht));
+    const size_t chunk = std::min(std::max<size_t>(ctx->chunk_frames, 1), std::max<size_t>(n_frames, 1));
+    SSW_TRY(grow(ctx->resize_tmp, chunk * nh * w * 3 * sizeof(float)));
+    for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
+        const size_t n = std::min(chunk, n_frames - f0);
+        StageTimer t(ctx, SSW_STAGE_RESIZE);
+        SSW_TRY(launch_resize_rgb8(ctx->stream, dev_in + f0 * w * h * 3, n, w, h, nw, nh, vt, ht,
+                                   (float*)ctx->resize_tmp.p, dev_out + f0 * nw * nh * 3));
     }
     return SSW_OK;
 }

@@ -175,3 +175,66 @@ def batch_extract(base_rgb, derived_rgb, k, marks=None, cfg=None):
 
 def default_config(precision=L.PRECISION_F64, ordering=L.ORDER_ENERGY, method=L.OPTION2, alpha=0.1):
     return L.Config(ordering, method, alpha, precision)
+
+
+def convert_u8_to_f32(a_u8):
+    a = np.ascontiguousarray(a_u8, dtype=np.uint8)
+    d = ctx().to_device(a)
+    out = ctx().alloc(a.size * 4)
+    check(lib().ssw_convert_rgb8_to_f32(ctx().handle, d.ptr, a.size, out.ptr), "ssw_convert_rgb8_to_f32")
+    r = out.to_host(np.float32, a.shape)
+    d.free(); out.free()
+    return r
+
+
+def convert_f32_to_u8(a_f32):
+    a = np.ascontiguousarray(a_f32, dtype=np.float32)
+    d = ctx().to_device(a)
+    out = ctx().alloc(max(a.size, 16))
+    check(lib().ssw_convert_f32_to_rgb8(ctx().handle, d.ptr, a.size, out.ptr), "ssw_convert_f32_to_rgb8")
+    r = out.to_host(np.uint8, a.shape)
+    d.free(); out.free()
+    return r
+
+
+def resize_rgb8(frames_u8, nw, nh):
+    a = np.ascontiguousarray(frames_u8, dtype=np.uint8)
+    single = a.ndim == 3
+    if single:
+        a = a[None]
+    n, h, w, _ = a.shape
+    d = ctx().to_device(a)
+    out = ctx().alloc(max(n * nh * nw * 3, 16))
+    check(lib().ssw_resize_rgb8(ctx().handle, d.ptr, n, w, h, nw, nh, out.ptr), "ssw_resize_rgb8")
+    r = out.to_host(np.uint8, (n, nh, nw, 3))
+    d.free(); out.free()
+    return r[0] if single else r
+
+
+def batch_embed_rgb8(rgb_u8, marks, cfg=None):
+    a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+    m = np.ascontiguousarray(marks, dtype=np.float32)
+    n, h, w, _ = a.shape
+    c = cfg or default_config()
+    d, dm = ctx().to_device(a), ctx().to_device(m)
+    out = ctx().alloc(a.nbytes)
+    check(lib().ssw_batch_embed_rgb8(ctx().handle, C.byref(c), d.ptr, n, w, h, dm.ptr, m.shape[1], out.ptr), "ssw_batch_embed_rgb8")
+    r = out.to_host(np.uint8, a.shape)
+    for b in (d, dm, out):
+        b.free()
+    return r
+
+
+def batch_extract_rgb8(base_u8, derived_u8, k, marks, cfg=None):
+    b, dv = np.ascontiguousarray(base_u8, dtype=np.uint8), np.ascontiguousarray(derived_u8, dtype=np.uint8)
+    n, h, w, _ = b.shape
+    c = cfg or default_config()
+    db, dd = ctx().to_device(b), ctx().to_device(dv)
+    dm = ctx().to_device(np.ascontiguousarray(marks, dtype=np.float32))
+    ext, sims = ctx().alloc(n * k * 4), ctx().alloc(n * 4)
+    check(lib().ssw_batch_extract_rgb8(ctx().handle, C.byref(c), db.ptr, dd.ptr, n, w, h, k, ext.ptr, dm.ptr, sims.ptr),
+          "ssw_batch_extract_rgb8")
+    e, s = ext.to_host(np.float32, (n, k)), sims.to_host(np.float32, (n,))
+    for x in (db, dd, dm, ext, sims):
+        x.free()
+    return e, s
