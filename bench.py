@@ -35,6 +35,72 @@ def shard_frames(total_frames: int, world: int, rank: int):
     return lo, hi
 
 
+def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb_out, marks, marks_host,
+                      extracted, sims, B, W, H, K):
+    """SURVEY 8(f) rank 1 / configs[4]: Writer::mark -> into_rgb8 -> resize to 1/8 (CatmullRom) and back
+    -> Reader::extract + similarity, all on 8-bit device-resident frames (tests/attack_resize.rs)."""
+    cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32)
+    n_val = B * H * W * 3
+    frames8 = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+    marked8 = torch.empty_like(frames8)
+    small8 = torch.empty((B, H // 8, W // 8, 3), dtype=torch.uint8, device=dev)
+    back8 = torch.empty_like(frames8)
+    torch.cuda.synchronize()
+    check(lib.ssw_convert_f32_to_rgb8(ctx.handle, rgb.data_ptr(), n_val, frames8.data_ptr()), "to_rgb8")
+    ctx.synchronize()
+
+    def step():
+        check(lib.ssw_batch_embed_rgb8(ctx.handle, C.byref(cfg), frames8.data_ptr(), B, W, H, marks.data_ptr(), K,
+                                       marked8.data_ptr()), "ssw_batch_embed_rgb8")
+        check(lib.ssw_resize_rgb8(ctx.handle, marked8.data_ptr(), B, W, H, W // 8, H // 8, small8.data_ptr()), "resize down")
+        check(lib.ssw_resize_rgb8(ctx.handle, small8.data_ptr(), B, W // 8, H // 8, W, H, back8.data_ptr()), "resize up")
+        check(lib.ssw_batch_extract_rgb8(ctx.handle, C.byref(cfg), frames8.data_ptr(), back8.data_ptr(), B, W, H, K,
+                                         extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract_rgb8")
+
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.enable_timing(True)
+    ctx.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    stage = ctx.timing()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    sims_host = sims.cpu().numpy()
+    if rank == 0:
+        px = float(B) * W * H * args.steps
+        rz_ms = stage["resize"]["ms"]
+        # algorithmic bytes of the two resizes: 3 B/px read + 3/64 written (down), 3/64 read + 3 written (up)
+        rz_gbs = px * (6.0 + 6.0 / 64.0) / (rz_ms * 1e-3) / 1e9 if rz_ms > 0 else 0.0
+        print(json.dumps({
+            "metric": "Mpixels/sec embed + resize attack (12.5 %) + extract", "value": round(world * px / 1e6 / elapsed, 2),
+            "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"batch={B}/GPU {W}x{H} 8-bit frames, {K}-coeff mark, embed -> into_rgb8 -> CatmullRom "
+                                   f"resize to 1/8 and back -> extract + similarity (configs[4] flow)",
+                       "frames_per_gpu": B, "width": W, "height": H, "k": K},
+            "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in stage.items()},
+            "resize": {"gbs_algorithmic": round(rz_gbs, 1), "frac_hbm": round(rz_gbs / PEAK_HBM_GBS, 4)},
+            "sim_mean": round(float(sims_host.mean()), 4), "sim_min": round(float(sims_host.min()), 4),
+            "sim_sigma_threshold_6_passed": bool((sims_host > 6.0).all()),
+        }))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -48,6 +114,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "f64"], default="f64",
                     help="headline precision: f64 = canonical (bit-parity with the CPU path), f32 = fast")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other precision")
+    ap.add_argument("--attack-resize", action="store_true",
+                    help="configs[4] flow on 8-bit frames: embed -> into_rgb8 -> CatmullRom 1/8 down + up -> extract")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="dense basis GEMMs instead of the even/odd-folded ones")
@@ -91,6 +159,14 @@ def main():
     torch.cuda.synchronize()
     check(lib.ssw_synth_frames(ctx.handle, args.seed, first_frame, B, W, H, rgb.data_ptr()), "ssw_synth_frames")
     ctx.synchronize()
+
+    if args.attack_resize:
+        run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb_out, marks, marks_host,
+                          extracted, sims, B, W, H, K)
+        if dist is not None:
+            dist.destroy_process_group()
+        ctx.close()
+        return
 
     def measure(prec_name):
         """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns

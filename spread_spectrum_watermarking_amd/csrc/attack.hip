@@ -146,7 +146,9 @@ void build_resize_taps(size_t in_len, size_t out_len, ResizeTaps& t) {
     }
 }
 
-// vertical pass: tmp[f][oy][e] = sum_i in[f][left+i][e] * w[i], e = x*3 + c (f32, sequential sum)
+// vertical pass: tmp[f][oy][e] = sum_i in[f][left+i][e] * w[i], e = x*3 + c (f32, sequential sum).
+// VEC = 4: four consecutive bytes per thread (one 32-bit load per tap) when the row length allows.
+template <int VEC>
 __global__ __launch_bounds__(256) void resize_vertical_kernel(const uint8_t* __restrict__ in, unsigned row_elems,
                                                               unsigned h, unsigned nh, const uint32_t* __restrict__ left,
                                                               const uint32_t* __restrict__ count,
@@ -157,32 +159,51 @@ __global__ __launch_bounds__(256) void resize_vertical_kernel(const uint8_t* __r
     const float* __restrict__ w = weights + (size_t)oy * max_taps;
     const uint8_t* __restrict__ src = in + ((size_t)f * h + l) * row_elems;
     float* __restrict__ dst = tmp + ((size_t)f * nh + oy) * row_elems;
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < row_elems; e += gridDim.x * blockDim.x) {
-        float t = 0.0f;
-        for (unsigned i = 0; i < n; ++i) t += (float)src[(size_t)i * row_elems + e] * w[i];
-        dst[e] = t;
+    for (unsigned e = (blockIdx.x * blockDim.x + threadIdx.x) * VEC; e < row_elems; e += gridDim.x * blockDim.x * VEC) {
+        if (VEC == 4) {
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+            for (unsigned i = 0; i < n; ++i) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>(src + (size_t)i * row_elems + e);
+                const float wi = w[i];
+                t0 += (float)(v & 0xFF) * wi;
+                t1 += (float)((v >> 8) & 0xFF) * wi;
+                t2 += (float)((v >> 16) & 0xFF) * wi;
+                t3 += (float)(v >> 24) * wi;
+            }
+            *reinterpret_cast<f32x4*>(dst + e) = (f32x4){t0, t1, t2, t3};
+        } else {
+            float t = 0.0f;
+            for (unsigned i = 0; i < n; ++i) t += (float)src[(size_t)i * row_elems + e] * w[i];
+            dst[e] = t;
+        }
     }
 }
 
-// horizontal pass: out[f][y][ox][c] = round(clamp(sum_i tmp[f][y][left+i][c] * w[i], 0, 255))
+// horizontal pass: out[row][ox][c] = round(clamp(sum_i tmp[row][left+i][c] * w[i], 0, 255)).
+// One thread per output pixel (3 channels): the tap table entry is read once per pixel.
 __global__ __launch_bounds__(256) void resize_horizontal_kernel(const float* __restrict__ tmp, unsigned w_in,
                                                                 unsigned nw, unsigned rows,
                                                                 const uint32_t* __restrict__ left,
                                                                 const uint32_t* __restrict__ count,
                                                                 const float* __restrict__ weights, unsigned max_taps,
                                                                 uint8_t* __restrict__ out) {
-    const size_t total = (size_t)rows * nw * 3;
-    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        const unsigned c = (unsigned)(e % 3);
-        const size_t px = e / 3;
-        const unsigned ox = (unsigned)(px % nw);
-        const size_t row = px / nw;
-        const unsigned l = left[ox], n = count[ox];
-        const float* __restrict__ w = weights + (size_t)ox * max_taps;
-        const float* __restrict__ src = tmp + (row * w_in + l) * 3 + c;
-        float t = 0.0f;
-        for (unsigned i = 0; i < n; ++i) t += src[(size_t)i * 3] * w[i];
-        out[e] = (uint8_t)roundf(clampf(t, 0.0f, 255.0f));
+    const unsigned ox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ox >= nw) return;
+    const unsigned l = left[ox], n = count[ox];
+    const float* __restrict__ w = weights + (size_t)ox * max_taps;
+    for (unsigned row = blockIdx.y; row < rows; row += gridDim.y) {
+        const float* __restrict__ src = tmp + ((size_t)row * w_in + l) * 3;
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+        for (unsigned i = 0; i < n; ++i) {
+            const float wi = w[i];
+            t0 += src[3 * i + 0] * wi;
+            t1 += src[3 * i + 1] * wi;
+            t2 += src[3 * i + 2] * wi;
+        }
+        uint8_t* o = out + ((size_t)row * nw + ox) * 3;
+        o[0] = (uint8_t)roundf(clampf(t0, 0.0f, 255.0f));
+        o[1] = (uint8_t)roundf(clampf(t1, 0.0f, 255.0f));
+        o[2] = (uint8_t)roundf(clampf(t2, 0.0f, 255.0f));
     }
 }
 
@@ -190,13 +211,22 @@ int launch_resize_rgb8(hipStream_t st, const uint8_t* in, size_t n_frames, size_
                        const DeviceTaps& vt, const DeviceTaps& ht, float* tmp, uint8_t* out) {
     if (!n_frames) return SSW_OK;
     const unsigned row_elems = (unsigned)(w * 3);
-    dim3 gv((row_elems + 255) / 256, (unsigned)nh, (unsigned)n_frames);
-    resize_vertical_kernel<<<gv, 256, 0, st>>>(in, row_elems, (unsigned)h, (unsigned)nh, vt.left, vt.count, vt.weights,
-                                               vt.max_taps, tmp);
+    const bool vec = (row_elems % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 3) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(tmp) & 15) == 0);
+    if (vec) {
+        dim3 gv((row_elems / 4 + 255) / 256, (unsigned)nh, (unsigned)n_frames);
+        resize_vertical_kernel<4><<<gv, 256, 0, st>>>(in, row_elems, (unsigned)h, (unsigned)nh, vt.left, vt.count,
+                                                      vt.weights, vt.max_taps, tmp);
+    } else {
+        dim3 gv((row_elems + 255) / 256, (unsigned)nh, (unsigned)n_frames);
+        resize_vertical_kernel<1><<<gv, 256, 0, st>>>(in, row_elems, (unsigned)h, (unsigned)nh, vt.left, vt.count,
+                                                      vt.weights, vt.max_taps, tmp);
+    }
     SSW_HIP_CHECK(hipGetLastError());
-    const size_t total = n_frames * nh * nw * 3;
-    resize_horizontal_kernel<<<sgrid(total), 256, 0, st>>>(tmp, (unsigned)w, (unsigned)nw, (unsigned)(n_frames * nh),
-                                                           ht.left, ht.count, ht.weights, ht.max_taps, out);
+    const unsigned rows = (unsigned)(n_frames * nh);
+    dim3 gh((unsigned)((nw + 255) / 256), rows < 16384 ? rows : 16384);
+    resize_horizontal_kernel<<<gh, 256, 0, st>>>(tmp, (unsigned)w, (unsigned)nw, rows, ht.left, ht.count, ht.weights,
+                                                 ht.max_taps, out);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
