@@ -176,6 +176,15 @@ int ssw_extract_coefficients(ssw_ctx* ctx, const float* dev_base, const float* d
 int ssw_similarity_batch(ssw_ctx* ctx, const float* dev_extracted, const float* dev_marks,
                          size_t n_pairs, size_t k, float* dev_sims);
 
+/* One-extraction-many-marks testing (README.md:62; the CLI's loop over stored marks,
+   examples/main.rs:369-415): sims[b][j] = Tester::new(extracted[b]).similarity(marks[j]) for
+   n_extracted extracted marks against a database of n_marks stored marks of length k, as an
+   (n_extracted x k) . (k x n_marks) GEMM on the f32 matrix cores.  Numerators are MFMA fma chains
+   instead of the reference's sequential f32 sums (src/algorithm.rs:702-711): equal to 1e-4
+   relative, not bit for bit; denominators keep the reference's order.  dev_sims: [n_extracted][n_marks]. */
+int ssw_similarity_matrix(ssw_ctx* ctx, const float* dev_extracted, size_t n_extracted, const float* dev_marks,
+                          size_t n_marks, size_t k, float* dev_sims);
+
 /* ---- whole path, batched & device-resident (the bench path) ---------------- */
 /* Writer::new + Writer::mark for n_frames frames (algorithm.rs:295-316, :355-379):
    rgb -> yiq -> DCT2 -> top-k -> embed -> DCT3 -> rgb.  One mark of length k per

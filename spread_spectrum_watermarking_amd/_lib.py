@@ -61,6 +61,7 @@ SIGNATURES = {
     "ssw_embed_coefficients": (C.c_int, [_vp, _f32p, _sz, _sz, _u32p, _sz, C.c_int, C.c_float, _f32p, _sz]),
     "ssw_extract_coefficients": (C.c_int, [_vp, _f32p, _f32p, _sz, _sz, _u32p, _sz, C.c_int, C.c_float, _f32p]),
     "ssw_similarity_batch": (C.c_int, [_vp, _f32p, _f32p, _sz, _sz, _f32p]),
+    "ssw_similarity_matrix": (C.c_int, [_vp, _f32p, _sz, _f32p, _sz, _sz, _f32p]),
     "ssw_batch_embed": (C.c_int, [_vp, _cfgp, _f32p, _sz, _sz, _sz, _f32p, _sz, _f32p, _f32p, _u32p]),
     "ssw_batch_extract": (C.c_int, [_vp, _cfgp, _f32p, _f32p, _sz, _sz, _sz, _sz, _f32p, _f32p, _f32p]),
     "ssw_convert_rgb8_to_f32": (C.c_int, [_vp, _vp, _sz, _f32p]),

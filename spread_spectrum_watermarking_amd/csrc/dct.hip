@@ -563,6 +563,25 @@ int launch_dct_rows(hipStream_t st, int precision, const float* in, float* out, 
     return SSW_OK;
 }
 
+// Plain NT GEMM on the f32 MFMA kernel of the row pass: out[m][n] = sum_k A[m][k] * B[n][k], both
+// operands f32 and k-contiguous with row stride K.  Used by the one-extraction-vs-many-marks
+// similarity (README.md:62 of the reference; examples/main.rs:369-415 loops Tester::similarity).
+int launch_gemm_nt_f32(hipStream_t st, const float* A, size_t M, const float* B, size_t N, size_t K, float* out) {
+    if (M == 0 || N == 0 || K == 0) return SSW_OK;
+    if (M > 0xFFFFFFFFull || N > 0xFFFFFFull || K > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned m = (unsigned)M, n = (unsigned)N, k = (unsigned)K;
+    const unsigned tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
+    const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const Epilogue ep{0, 0.f, 0.f, 0.f};
+    // aligned instance: unpredicated 16-B loads, needs K to be a whole number of k-tiles (row stride = K)
+    const bool al = (k % BK == 0) && aligned16(A) && aligned16(B);
+    if (al) dct_rows_f32_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(A, B, out, m, n, k, k, tiles_m, tiles_n, ep);
+    else    dct_rows_f32_kernel<false><<<(unsigned)nblk, THREADS, 0, st>>>(A, B, out, m, n, k, k, tiles_m, tiles_n, ep);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
 int launch_dct_cols(hipStream_t st, int precision, const float* in, float* out, size_t n_frames,
                     size_t w, size_t h, const void* basis, Epilogue ep) {
     if (n_frames == 0 || w == 0 || h == 0) return SSW_OK;

@@ -472,6 +472,43 @@ int launch_similarity(hipStream_t st, const float* extracted, const float* marks
     return SSW_OK;
 }
 
+// Many-marks similarity: denominators sum(e*e) in the reference's sequential f32 order (one lane per
+// extracted mark), then sims[b][j] = nom[b][j] / sqrt(den[b]) on the GEMM result.
+__global__ __launch_bounds__(256) void sim_den_kernel(const float* __restrict__ extracted, size_t k,
+                                                      float* __restrict__ den) {
+    __shared__ float pd[1024];
+    const size_t f = blockIdx.x;
+    const float* e = extracted + f * k;
+    float denominator = 0.0f;
+    for (size_t base = 0; base < k; base += 1024) {
+        const size_t n = (k - base) < 1024 ? (k - base) : 1024;
+        for (size_t i = threadIdx.x; i < n; i += blockDim.x) { const float ev = e[base + i]; pd[i] = ev * ev; }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (size_t i = 0; i < n; ++i) denominator += pd[i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) den[f] = denominator;
+}
+__global__ void sim_scale_kernel(float* __restrict__ sims, const float* __restrict__ den, size_t n_ext, size_t n_marks) {
+    const size_t total = n_ext * n_marks;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        sims[i] = sims[i] / sqrtf(den[i / n_marks]);
+}
+int launch_sim_den(hipStream_t st, const float* extracted, size_t n_ext, size_t k, float* den) {
+    if (!n_ext) return SSW_OK;
+    sim_den_kernel<<<(unsigned)n_ext, 256, 0, st>>>(extracted, k, den);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+int launch_sim_scale(hipStream_t st, float* sims, const float* den, size_t n_ext, size_t n_marks) {
+    const size_t total = n_ext * n_marks;
+    if (!total) return SSW_OK;
+    sim_scale_kernel<<<(unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096), 256, 0, st>>>(sims, den, n_ext, n_marks);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
 __global__ void widen_kernel(const uint32_t* in, size_t n, uint64_t* out) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = in[i];

@@ -125,6 +125,9 @@ int launch_extract(hipStream_t st, const float* base, const float* derived, size
                    float* out);
 int launch_similarity(hipStream_t st, const float* extracted, const float* marks, size_t n_pairs,
                       size_t k, float* sims);
+int launch_gemm_nt_f32(hipStream_t st, const float* A, size_t M, const float* B, size_t N, size_t K, float* out);
+int launch_sim_den(hipStream_t st, const float* extracted, size_t n_ext, size_t k, float* den);
+int launch_sim_scale(hipStream_t st, float* sims, const float* den, size_t n_ext, size_t n_marks);
 int launch_widen_indices(hipStream_t st, const uint32_t* in, size_t n, uint64_t* out);
 
 }  // namespace ssw

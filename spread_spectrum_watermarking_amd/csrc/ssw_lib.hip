@@ -422,6 +422,18 @@ int ssw_similarity_batch(ssw_ctx* ctx, const float* dev_extracted, const float* 
     return launch_similarity(ctx->stream, dev_extracted, dev_marks, n_pairs, k, dev_sims);
 }
 
+int ssw_similarity_matrix(ssw_ctx* ctx, const float* dev_extracted, size_t n_extracted, const float* dev_marks,
+                          size_t n_marks, size_t k, float* dev_sims) {
+    if (!ctx || !dev_extracted || !dev_marks || !dev_sims) return SSW_ERR_BAD_ARG;
+    if (n_extracted == 0 || n_marks == 0) return SSW_OK;
+    DeviceGuard g(ctx->device);
+    SSW_TRY(grow(ctx->small, n_extracted * sizeof(float)));
+    StageTimer t(ctx, SSW_STAGE_SIMILARITY);
+    SSW_TRY(launch_sim_den(ctx->stream, dev_extracted, n_extracted, k, (float*)ctx->small.p));
+    SSW_TRY(launch_gemm_nt_f32(ctx->stream, dev_extracted, n_extracted, dev_marks, n_marks, k, dev_sims));
+    return launch_sim_scale(ctx->stream, dev_sims, (const float*)ctx->small.p, n_extracted, n_marks);
+}
+
 // ---- whole path, batched --------------------------------------------------------------------
 namespace {
 

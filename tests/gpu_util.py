@@ -238,3 +238,16 @@ def batch_extract_rgb8(base_u8, derived_u8, k, marks, cfg=None):
     for x in (db, dd, dm, ext, sims):
         x.free()
     return e, s
+
+
+def similarity_matrix(extracted, marks_db):
+    e, m = np.ascontiguousarray(extracted, dtype=np.float32), np.ascontiguousarray(marks_db, dtype=np.float32)
+    b, k = e.shape
+    n = m.shape[0]
+    de, dm = ctx().to_device(e), ctx().to_device(m)
+    out = ctx().alloc(b * n * 4)
+    check(lib().ssw_similarity_matrix(ctx().handle, de.ptr, b, dm.ptr, n, k, out.ptr), "ssw_similarity_matrix")
+    r = out.to_host(np.float32, (b, n))
+    for x in (de, dm, out):
+        x.free()
+    return r

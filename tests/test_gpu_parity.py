@@ -296,6 +296,21 @@ def test_similarity_bit_exact(k):
         assert got[f] == np.float32(O.similarity(e[f], m[f]))
 
 
+@pytest.mark.parametrize("shape", [(3, 5, 1000), (130, 257, 1000), (16, 200, 10000), (7, 9, 33)])
+def test_similarity_matrix_matches_pairwise_tester(shape):
+    """One extraction against many stored marks (README.md:62 of the reference) as an MFMA GEMM:
+    every entry equals Tester::similarity of that pair to 1e-4 relative (fma-chain vs sequential sums)."""
+    b, m, k = shape
+    rng = np.random.default_rng(b * m)
+    marks_db = rng.standard_normal((m, k)).astype(np.float32)
+    ext = rng.standard_normal((b, k)).astype(np.float32)
+    ext[0] = marks_db[m // 2] * 0.97 + 0.05 * ext[0]                  # one genuine match
+    got = G.similarity_matrix(ext, marks_db)
+    ref = np.array([[O.similarity(e, mk) for mk in marks_db] for e in ext], np.float32)
+    assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max())
+    assert got[0].argmax() == m // 2 and got[0, m // 2] > 0.9 * np.sqrt(k)
+
+
 def test_extract_error_behaviour():
     c = np.zeros((1, 6), np.float32)
     with pytest.raises(wm.SswError) as e:
