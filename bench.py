@@ -144,7 +144,8 @@ def main():
     lib = L.load()
     ctx = wm.Context(local_rank)
     ctx.set_chunk_frames(args.chunk)
-    ctx.set_dct_folding(not args.no_fold)
+    fold_level = 0 if args.no_fold else int(os.environ.get("SSW_FOLD_LEVEL", "1"))
+    ctx.set_dct_folding(fold_level)
     W, H, K, B = args.width, args.height, args.k, args.batch
 
     # ---- inputs resident in HBM ------------------------------------------------------------------
@@ -224,6 +225,10 @@ def main():
         row_dense = 2.0 * B * H * W * W * transforms_per_step * steps
         col_dense = 2.0 * B * W * H * H * transforms_per_step * steps
         row_flops = row_dense / (2.0 if fold_rows else 1.0)
+        # f64, W % 16 == 0: the three forward row passes of a step use the two-level kernel (3/8 dense)
+        fold2_rows = fold_rows and prec_name == "f64" and W % 16 == 0 and W >= 64 and fold_level >= 2
+        if fold2_rows:
+            row_flops = row_dense * (3 * 0.375 + 1 * 0.5) / 4.0
         col_flops = col_dense / (2.0 if fold_cols else 1.0)
         row_ms, row_n = stage["dct_row"]["ms"], max(stage["dct_row"]["launches"], 1)
         col_ms, col_n = stage["dct_col"]["ms"], max(stage["dct_col"]["launches"], 1)
@@ -251,7 +256,8 @@ def main():
                        "frac_hbm": round(gbs(4.0, 2, stage["select"]["ms"]) / PEAK_HBM_GBS, 4)},
         }
         roofline = {"bound": "mfma",
-                    "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name,
+                    "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name
+                              + (" + dct_rows_fold2_fwd_f64_kernel (forward passes)" if fold2_rows else ""),
                     "achieved": round(row_tf, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(row_tf / peak, 4), "traffic": None,
                     "note": ("executed flop per launch (even/odd-folded basis: half the dense 2*rows*W*W) / average "

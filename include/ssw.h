@@ -108,10 +108,12 @@ void* ssw_ctx_stream(ssw_ctx* ctx);
    workspace: 4 planes * chunk).  Default 16. */
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
 
-/* f32 precision only: use the even/odd-folded basis GEMMs (half the multiply-adds; one extra f32
-   rounding per input pair) where the frame shape allows (W % 8 == 0 / H % 8 == 0).  Default on;
-   0 selects the dense GEMMs. */
-int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int enable);
+/* Even/odd folding of the basis GEMMs (fewer multiply-adds for the same transform; exact in f64,
+   one extra rounding per input pair in f32) where the frame shape allows (W % 8 == 0 / H % 8 == 0):
+   0 = dense GEMMs, 1 = default: one folding level (1/2 of the dense MACs), 2 = opt-in: a second
+   level (3/8 of the dense MACs) where a kernel exists (r1: the f64 forward row pass, +3.5 % end to
+   end at a lower MFMA utilisation). */
+int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int level);
 
 /* Per-stage device timers (hipEvent pairs on the context's stream). */
 typedef enum ssw_stage {

@@ -54,8 +54,11 @@ class Context:
     def set_chunk_frames(self, n: int):
         check(self._lib.ssw_ctx_set_chunk_frames(self.handle, n), "ssw_ctx_set_chunk_frames")
 
-    def set_dct_folding(self, on: bool = True):
-        check(self._lib.ssw_ctx_set_dct_folding(self.handle, int(on)), "ssw_ctx_set_dct_folding")
+    def set_dct_folding(self, level=True):
+        """False / 0: dense basis GEMMs; True / 1: one even/odd folding level (default); 2: a second
+        level where a kernel exists (f64 forward row pass)."""
+        lvl = (1 if level else 0) if isinstance(level, bool) else int(level)
+        check(self._lib.ssw_ctx_set_dct_folding(self.handle, lvl), "ssw_ctx_set_dct_folding")
 
     def enable_timing(self, on: bool = True):
         check(self._lib.ssw_ctx_enable_timing(self.handle, int(on)), "ssw_ctx_enable_timing")

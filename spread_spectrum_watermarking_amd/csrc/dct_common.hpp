@@ -7,6 +7,7 @@ namespace ssw {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 // XCD-aware, L2-friendly block -> tile map.  Blocks b, b+8, b+16, ... share an XCD (observed

@@ -81,6 +81,11 @@ int launch_dct_rows_folded_f64(hipStream_t st, bool inverse, const float* in, fl
 int launch_dct_cols_folded_f64(hipStream_t st, bool inverse, const float* in, float* out, size_t n_frames,
                                size_t w, size_t h, const double* b_even, const double* b_odd, Epilogue ep);
 
+// dct_fold2_f64.hip: two-level folding (3/8 of the dense MACs), f64
+bool dct_rows_can_fold2(size_t w, const float* in, const float* out);
+int launch_dct_rows_fold2_fwd_f64(hipStream_t st, const float* in, float* out, size_t rows, size_t w,
+                                  const double* b_odd, const double* b_even_even, const double* b_even_odd, Epilogue ep);
+
 // select.hip
 struct SelectWorkspace {
     uint32_t* hist = nullptr;       // [n_frames][2048] sample histogram
@@ -142,6 +147,7 @@ struct ssw_ctx {
     // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded f32 kernels
     std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
     bool fold = true;             // use the even/odd-folded GEMMs where the shape allows
+    int fold_level = 1;           // 2 (opt-in): also fold the even half once more where a kernel exists (f64 forward rows)
 
     // growable scratch
     struct Buf {

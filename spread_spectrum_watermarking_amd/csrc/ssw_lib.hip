@@ -164,7 +164,14 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         } else {
             SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
         }
-        if (is_row) {
+        if (is_row && fold && f64 && !inverse && ctx->fold_level >= 2 && dct_rows_can_fold2(w, src, dst)) {
+            const void *bee = nullptr, *beo = nullptr;
+            SSW_TRY(get_basis(ctx, w / 2, false, true, 1, &bee));       // even / odd half bases of W/2
+            SSW_TRY(get_basis(ctx, w / 2, false, true, 2, &beo));
+            StageTimer t(ctx, SSW_STAGE_DCT_ROW);
+            SSW_TRY(launch_dct_rows_fold2_fwd_f64(ctx->stream, src, dst, n * h, w, (const double*)b1,
+                                                  (const double*)bee, (const double*)beo, ep));
+        } else if (is_row) {
             StageTimer t(ctx, SSW_STAGE_DCT_ROW);
             if (fold && f64) SSW_TRY(launch_dct_rows_folded_f64(ctx->stream, inverse, src, dst, n * h, w, (const double*)b0, (const double*)b1, ep));
             else if (fold)   SSW_TRY(launch_dct_rows_folded_f32(ctx->stream, inverse, src, dst, n * h, w, (const float*)b0, (const float*)b1, ep));
@@ -288,6 +295,7 @@ int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames) {
 int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int enable) {
     if (!ctx) return SSW_ERR_BAD_ARG;
     ctx->fold = enable != 0;
+    ctx->fold_level = enable;                 // 1: one folding level (default); >= 2: two where a kernel exists
     return SSW_OK;
 }
 

@@ -15,6 +15,7 @@ prec = L.PRECISION_F64 if (len(a) > 4 and a[4] == "f64") else L.PRECISION_F32
 typ = int(a[5]) if len(a) > 5 else 0
 ctx = wm.Context(0); lib = L.load(); ctx.set_chunk_frames(n)
 if os.environ.get("SSW_NO_FOLD"): ctx.set_dct_folding(False)
+if os.environ.get("SSW_FOLD_LEVEL"): lib.ssw_ctx_set_dct_folding(ctx.handle, int(os.environ["SSW_FOLD_LEVEL"]))
 buf = ctx.to_device(np.random.default_rng(0).random((n, H, W), dtype=np.float32))
 check(lib.ssw_dct2d(ctx.handle, typ, prec, n, W, H, buf.ptr), "warm")
 ctx.enable_timing(True); ctx.reset_timing()
