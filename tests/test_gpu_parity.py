@@ -510,3 +510,49 @@ def test_batch_path_equals_handles_and_oracle(precision):
             assert np.abs(res["rgb"][f] - o_res).max() <= 2e-7
             o_ext, o_sim = O.extract_frame(rgb[f], o_res, marks[f])
             assert abs(sims[f] - o_sim) < 1e-4 * abs(o_sim) + 1e-4
+
+
+# ---- BASELINE.json sizes and degenerate inputs ---------------------------------------------------
+def test_full_hd_pipeline_parity_with_oracle():
+    """configs[2] frame size (1920x1080), canonical precision: the whole embed -> extract -> similarity
+    path of one frame against the oracle's exact pipeline."""
+    w, h, k = 1920, 1080, 1000
+    rgb = G.synth(4, 17, 1, w, h)
+    assert np.array_equal(rgb[0], O.synth_frame(4, 17, w, h))
+    mark = np.random.default_rng(17).standard_normal((1, k)).astype(np.float32)
+    res = G.batch_embed(rgb, mark, want_coef=True, want_idx=True)
+    ref_coef = O.dct2d(O.rgb_to_yiq(rgb[0])[0])
+    assert np.mean(res["coef"][0] == ref_coef) > 0.9995
+    assert np.array_equal(res["idx"][0], O.indices(ref_coef, k=k).astype(np.uint32))
+    ref_marked = O.embed_frame(rgb[0], mark[0])
+    assert np.abs(res["rgb"][0] - ref_marked).max() <= 2e-7 and np.mean(res["rgb"][0] == ref_marked) > 0.999
+    ext, sims = G.batch_extract(rgb, res["rgb"], k, mark)
+    ref_ext, ref_sim = O.extract_frame(rgb[0], ref_marked, mark[0])
+    assert np.abs(ext[0] - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert abs(float(sims[0]) - ref_sim) < 1e-4
+
+
+def test_empty_and_degenerate_calls():
+    lib, ctx = G.lib(), G.ctx()
+    cfg = G.default_config()
+    buf = ctx.alloc(64)
+    import ctypes as C
+    # zero frames / zero-length marks are no-ops, not errors
+    assert lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 0, 16, 16, buf.ptr) == L.SSW_OK
+    assert lib.ssw_rgb_to_yiq(ctx.handle, buf.ptr, 0, 4, 4, buf.ptr, None, None) == L.SSW_OK
+    assert lib.ssw_batch_embed(ctx.handle, C.byref(cfg), buf.ptr, 0, 16, 16, buf.ptr, 10, buf.ptr, None, None) == L.SSW_OK
+    assert lib.ssw_batch_extract(ctx.handle, C.byref(cfg), buf.ptr, buf.ptr, 0, 16, 16, 10, buf.ptr, None, None) == L.SSW_OK
+    assert lib.ssw_topk_indices(ctx.handle, buf.ptr, 1, 4, 4, L.ORDER_ENERGY, 0, buf.ptr) == L.SSW_OK
+    # bad arguments are reported, never crash
+    assert lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 1, 0, 16, buf.ptr) == L.SSW_ERR_BAD_DIMS
+    assert lib.ssw_dct2d(ctx.handle, 7, F64, 1, 4, 4, buf.ptr) == L.SSW_ERR_BAD_ARG
+    assert lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 1, 4, 4, None) == L.SSW_ERR_BAD_ARG
+    bad = L.Config(L.ORDER_ENERGY, 9, 0.1, F64)
+    assert lib.ssw_batch_embed(ctx.handle, C.byref(bad), buf.ptr, 1, 4, 4, buf.ptr, 1, buf.ptr, None, None) == L.SSW_ERR_BAD_ARG
+    buf.free()
+    # a mark of length 0 leaves the image untouched up to the transform round trip
+    small = O.synth_frame(1, 1, 32, 24)
+    out = wm.Writer(small).mark([np.zeros(0, np.float32)])
+    assert np.abs(out - small).max() < 1e-6
+    ext = wm.Reader.base(small).extract(wm.Reader.derived(small), 0)
+    assert ext.shape == (0,)
