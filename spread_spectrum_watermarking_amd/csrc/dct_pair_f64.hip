@@ -1,0 +1,408 @@
+// Operand-ready even/odd-folded basis GEMMs in f64 (canonical precision).
+//
+// Measured on MI355X (tools/mfma_peak.hip): v_mfma_f64_16x16x4_f64 sustains 77.6 TFLOP/s when the
+// wave issues nothing else, but every VALU instruction issued next to it takes MFMA pipe time --
+// ~6 cycles for a 32-bit op, ~11.5 cycles for v_cvt_f64_f32 / v_add_f64 -- even from another wave
+// of the same SIMD.  The in-kernel folding of dct_folded_f64.hip spends one f64 VALU op per MFMA
+// (widen + add/subtract after the LDS read) and tops out at 81 % of peak for that reason.
+//
+// Here the GEMM main loop contains no VALU instruction at all: global_load -> ds_write ->
+// ds_read -> MFMA, with scalar address arithmetic.  Its operands are produced once per pass by
+// HBM-bound pre-passes (this file) in exactly the form the MFMA consumes:
+//   forward:  S[s] = (double)x[s] + (double)x[N-1-s],  D[s] = (double)x[s] - (double)x[N-1-s]
+//   inverse:  E[s] = (double)c[2s],                    O[s] = (double)c[2s+1]
+// stored k-contiguous ([line][Kp] doubles, zero padded to the half basis' row stride).  For the
+// column pass the pre-pass also transposes, so that one "NT" kernel serves all four passes:
+//   acc1[x][y] = sum_k X1[x][k] Y1[y][k],   acc2[x][y] = sum_k X2[x][k] Y2[y][k]
+// with X = image operand (lines), Y = half basis (pairs).  Epilogues as in dct_folded_f64.hip:
+// forward interleaves (even, odd) frequencies; inverse forms acc1 +/- acc2 for the mirrored
+// positions; results are rounded once to f32 (then the reference's f32 scale factor, if any).
+//
+// Block: 256 threads = 4 waves as 2 x 2; block tile 128 lines x 64 pairs x 2 products; k-step 8;
+// per wave 16 MFMA 16x16 tiles = 128 accumulator registers; LDS 48 KB double-buffered (XOR-swizzled
+// 64-byte rows, conflict-free ds_read_b128), one barrier per k-step, 2 blocks per CU.
+// Lane l: li = l & 15 (line / pair inside a 16x16 tile), lq = l >> 4: MFMA step s sums
+// k = 2 lq + s over the 4 lane groups (any assignment of k to MFMA slots is a valid summation
+// order; A and B use the same one).
+#include "dct_common.hpp"
+
+#include <type_traits>
+#include <cstdlib>
+
+namespace ssw {
+
+constexpr int PT = 256;
+constexpr int PBK = 8;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+enum { PAIR_ROWS_FWD = 0, PAIR_ROWS_INV = 1, PAIR_COLS_FWD = 2, PAIR_COLS_INV = 3 };
+
+template <int MODE>
+__global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
+    const double* __restrict__ X1g, const double* __restrict__ X2g, const double* __restrict__ Y1g,
+    const double* __restrict__ Y2g, float* __restrict__ OUT, unsigned L /*lines*/, unsigned NP /*pairs*/,
+    unsigned Kp, unsigned W, unsigned H, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
+    constexpr bool COLS = (MODE == PAIR_COLS_FWD || MODE == PAIR_COLS_INV);
+    constexpr bool INVERSE = (MODE == PAIR_ROWS_INV || MODE == PAIR_COLS_INV);
+    __shared__ __attribute__((aligned(16))) double sX[2][2][128 * PBK];   // [buffer][product]
+    __shared__ __attribute__((aligned(16))) double sY[2][2][64 * PBK];
+
+    unsigned tm, tn;
+    tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+    const unsigned m0 = tm * 128, p0 = tn * 64;
+    const unsigned tid = threadIdx.x;
+    const unsigned lane = tid & 63, wave = tid >> 6;
+    const unsigned wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
+    const unsigned li = lane & 15, lq = lane >> 4;
+
+    // LDS tile rows hold 8 consecutive k (64 bytes); double k of row r sits at position
+    // k ^ ((r >> 1) & 7): conflict-free for the ds_read_b64 / ds_read2_b64 fragment reads (16 lanes
+    // cover a 128-byte bank window exactly) and for the staging ds_write_b64.
+    // staging: line = tid / 4 (+ 64 q), k-pair = tid % 4
+    const unsigned srow = tid >> 2, sc = tid & 3;
+    const unsigned ssw = (srow >> 1) & 7;
+    unsigned xoff[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        unsigned r = m0 + srow + 64 * q;
+        r = r < L ? r : L - 1;
+        xoff[q] = ((r - m0) * Kp + 2 * sc) * 8u;
+    }
+    unsigned yr = p0 + srow;
+    yr = yr < NP ? yr : NP - 1;
+    const unsigned yoff = ((yr - p0) * Kp + 2 * sc) * 8u;
+    // block-uniform buffer resources (scalar registers); the k-step advances a scalar byte offset
+    const unsigned xbytes = 128u * Kp * 8u, ybytes = 64u * Kp * 8u;     // never read past: rows are clamped
+    const __amdgpu_buffer_rsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc((void*)(X1g + (size_t)m0 * Kp), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void*)(X2g + (size_t)m0 * Kp), 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y1r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y1g + (size_t)p0 * Kp), 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y2g + (size_t)p0 * Kp), 0, ybytes, 0x00020000);
+
+    f64x4 acc1[4][2], acc2[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc1[i][j] = (f64x4){0, 0, 0, 0}; acc2[i][j] = (f64x4){0, 0, 0, 0}; }
+
+    u32x4 rx1[2], rx2[2], ry1, ry2;
+    auto gload = [&](unsigned t) {
+        const unsigned adv = t * (PBK * 8);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            rx1[q] = __builtin_amdgcn_raw_buffer_load_b128(x1r, xoff[q], adv, 0);
+            rx2[q] = __builtin_amdgcn_raw_buffer_load_b128(x2r, xoff[q], adv, 0);
+        }
+        ry1 = __builtin_amdgcn_raw_buffer_load_b128(y1r, yoff, adv, 0);
+        ry2 = __builtin_amdgcn_raw_buffer_load_b128(y2r, yoff, adv, 0);
+    };
+    const unsigned st0 = srow * PBK + ((2 * sc) ^ ssw), st1 = srow * PBK + ((2 * sc + 1) ^ ssw);
+    auto put = [&](double* tile, const u32x4& v) {
+        *reinterpret_cast<u32x2*>(tile + st0) = (u32x2){v[0], v[1]};
+        *reinterpret_cast<u32x2*>(tile + st1) = (u32x2){v[2], v[3]};
+    };
+    auto lstore = [&](auto bufc) {
+        constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            put(&sX[buf][0][64 * q * PBK], rx1[q]);
+            put(&sX[buf][1][64 * q * PBK], rx2[q]);
+        }
+        put(&sY[buf][0][0], ry1);
+        put(&sY[buf][1][0], ry2);
+    };
+    // fragment of half-step s: lane group lq supplies k = 4 s + lq
+    const unsigned fsw = (li >> 1) & 7;
+    unsigned rdx[2], rdy[2];
+#pragma unroll
+    for (int sh = 0; sh < 2; ++sh) {
+        rdx[sh] = (wm + li) * PBK + ((4 * sh + lq) ^ fsw);
+        rdy[sh] = (wn + li) * PBK + ((4 * sh + lq) ^ fsw);
+    }
+    struct Frag { double x1[4], x2[4], y1[2], y2[2]; };
+    auto fread = [&](auto bufc, auto shc, Frag& f) {
+        constexpr int cur = decltype(bufc)::value;
+        constexpr int sh = decltype(shc)::value;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            f.y1[jn] = sY[cur][0][rdy[sh] + 16 * jn * PBK];
+            f.y2[jn] = sY[cur][1][rdy[sh] + 16 * jn * PBK];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f.x1[i] = sX[cur][0][rdx[sh] + 16 * i * PBK];
+            f.x2[i] = sX[cur][1][rdx[sh] + 16 * i * PBK];
+        }
+    };
+    auto fmma = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                if (!COLS) {      // D[row = line][col = pair]
+                    acc1[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.x1[i], f.y1[jn], acc1[i][jn], 0, 0, 0);
+                    acc2[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.x2[i], f.y2[jn], acc2[i][jn], 0, 0, 0);
+                } else {          // D[row = pair][col = line]: image columns along the lanes
+                    acc1[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y1[jn], f.x1[i], acc1[i][jn], 0, 0, 0);
+                    acc2[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y2[jn], f.x2[i], acc2[i][jn], 0, 0, 0);
+                }
+            }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+
+    // Software pipeline, shifted by half a k-step: the fragments of a half-step are read from LDS
+    // while the MFMAs of the previous half-step run; the tile of step t+1 is written (and the
+    // barrier taken) in the middle of step t, its global loads having been issued a step earlier.
+    const unsigned nk = Kp / PBK;          // even and >= 2: Kp is a multiple of 16
+    Frag fa, fb;
+    gload(0);
+    lstore(B0{});
+    __syncthreads();
+    gload(1);
+    fread(B0{}, B0{}, fa);
+    // full step t on buffer CUR: needs t + 2 < nk
+    // one LDS read behind each of the first MFMAs of a half-step (a burst of reads would stall the
+    // wave at the LDS queue with its MFMAs behind it), then the staging writes two per MFMA
+    auto interleave = [&](auto storec) {
+        constexpr bool STORE = decltype(storec)::value != 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (STORE) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto step = [&](auto curc, auto nxtc, unsigned t) {
+        fread(curc, B1{}, fb);
+        fmma(fa);
+        lstore(nxtc);                          // loaded a whole step ago
+        gload(t + 2);
+        interleave(B1{});
+        __syncthreads();
+        fread(nxtc, B0{}, fa);
+        fmma(fb);
+        interleave(B0{});
+    };
+    unsigned t = 0;
+    for (; t + 2 < nk; t += 2) {
+        step(B0{}, B1{}, t);
+        step(B1{}, B0{}, t + 1);
+    }
+    // steps nk - 2 (buffer 0) and nk - 1 (buffer 1)
+    fread(B0{}, B1{}, fb);
+    fmma(fa);
+    interleave(B0{});
+    lstore(B1{});
+    __syncthreads();
+    fread(B1{}, B0{}, fa);
+    fmma(fb);
+    interleave(B0{});
+    fread(B1{}, B1{}, fb);
+    fmma(fa);
+    interleave(B0{});
+    fmma(fb);
+
+    // D map of 16x16x4 f64: col = lane & 15, row = (lane >> 4) + 4 reg
+    if (!COLS) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const unsigned pair = p0 + wn + 16 * jn + li;
+            if (pair >= NP) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned row = m0 + wm + 16 * i + lq + 4 * r;
+                    if (row >= L) continue;
+                    float* o = OUT + (size_t)row * W;
+                    if (!INVERSE) {
+                        const f32x2 v = {apply_epilogue(ep, (float)acc1[i][jn][r], 2 * pair),
+                                         apply_epilogue(ep, (float)acc2[i][jn][r], 2 * pair + 1)};
+                        *reinterpret_cast<f32x2*>(o + 2 * pair) = v;
+                    } else {
+                        o[pair] = apply_epilogue(ep, (float)(acc1[i][jn][r] + acc2[i][jn][r]), pair);
+                        o[W - 1 - pair] = apply_epilogue(ep, (float)(acc1[i][jn][r] - acc2[i][jn][r]), W - 1 - pair);
+                    }
+                }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned line = m0 + wm + 16 * i + li;       // = frame * W + column
+            if (line >= L) continue;
+            const unsigned z = line / W, col = line - z * W;
+            float* o = OUT + (size_t)z * H * W + col;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
+                    if (pair >= NP) continue;
+                    if (!INVERSE) {
+                        o[(size_t)(2 * pair) * W] = apply_epilogue(ep, (float)acc1[i][jn][r], 2 * pair);
+                        o[(size_t)(2 * pair + 1) * W] = apply_epilogue(ep, (float)acc2[i][jn][r], 2 * pair + 1);
+                    } else {
+                        o[(size_t)pair * W] = apply_epilogue(ep, (float)(acc1[i][jn][r] + acc2[i][jn][r]), pair);
+                        o[(size_t)(H - 1 - pair) * W] =
+                            apply_epilogue(ep, (float)(acc1[i][jn][r] - acc2[i][jn][r]), H - 1 - pair);
+                    }
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-passes (HBM-bound): f32 plane -> the two f64 operand planes of the pass.
+// ---------------------------------------------------------------------------------------------
+// Row pass: line = image row, k along the row.  One thread = 4 consecutive k of one line.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep_rows_kernel(const float* __restrict__ X, double* __restrict__ O1,
+                                                            double* __restrict__ O2, size_t rows, unsigned W, unsigned Kp) {
+    const unsigned Nh = W / 2, qpl = Kp / 4;                      // quads per line
+    const size_t total = rows * qpl;
+    for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = id / qpl;
+        const unsigned s = (unsigned)(id % qpl) * 4;
+        f64x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (s < Nh) {                                             // Nh % 4 == 0
+            const float* x = X + row * W;
+            if (!INVERSE) {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(x + s);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (W - 4 - s));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = (double)u[e] + (double)v[3 - e];
+                    b[e] = (double)u[e] - (double)v[3 - e];
+                }
+            } else {
+                const f32x4 u = *reinterpret_cast<const f32x4*>(x + 2 * s);
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + 2 * s + 4);
+                a = (f64x4){(double)u[0], (double)u[2], (double)v[0], (double)v[2]};
+                b = (f64x4){(double)u[1], (double)u[3], (double)v[1], (double)v[3]};
+            }
+        }
+        *reinterpret_cast<f64x4*>(O1 + row * Kp + s) = a;
+        *reinterpret_cast<f64x4*>(O2 + row * Kp + s) = b;
+    }
+}
+
+// Column pass: line = (frame, column), k along the image rows: fold / split + transpose through LDS.
+// Block tile: 32 k x 64 columns.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep_cols_kernel(const float* __restrict__ IN, double* __restrict__ O1,
+                                                            double* __restrict__ O2, unsigned W, unsigned H, unsigned Kp,
+                                                            unsigned tiles_k, unsigned tiles_c) {
+    __shared__ double s1[64][33];
+    __shared__ double s2[64][33];
+    const unsigned Hh = H / 2;
+    const unsigned z = blockIdx.x / (tiles_k * tiles_c);
+    const unsigned tt = blockIdx.x % (tiles_k * tiles_c);
+    const unsigned k0 = (tt % tiles_k) * 32, c0 = (tt / tiles_k) * 64;
+    const float* __restrict__ P = IN + (size_t)z * H * W;
+    const unsigned tid = threadIdx.x;
+    {
+        const unsigned kr = tid >> 4, cq = (tid & 15) * 4;       // 16 k-rows per sweep, 4 columns per thread
+        unsigned c = c0 + cq;
+        c = c + 4 <= W ? c : W - 4;                               // W % 4 == 0; duplicates are never written out
+#pragma unroll
+        for (int sw = 0; sw < 2; ++sw) {
+            const unsigned kl = kr + 16 * sw, k = k0 + kl;
+            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+            if (k < Hh) {
+                const unsigned ra = INVERSE ? 2 * k : k, rb = INVERSE ? 2 * k + 1 : H - 1 - k;
+                u = *reinterpret_cast<const f32x4*>(P + (size_t)ra * W + c);
+                v = *reinterpret_cast<const f32x4*>(P + (size_t)rb * W + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[cq + e][kl] = INVERSE ? (double)u[e] : (double)u[e] + (double)v[e];
+                s2[cq + e][kl] = INVERSE ? (double)v[e] : (double)u[e] - (double)v[e];
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned cl = tid >> 2, kq = (tid & 3) * 8;         // 8 consecutive k of one column per thread
+        const unsigned c = c0 + cl;
+        if (c < W && k0 + kq < Kp) {                              // Kp % 8 == 0
+            double* o1 = O1 + ((size_t)z * W + c) * Kp + k0 + kq;
+            double* o2 = O2 + ((size_t)z * W + c) * Kp + k0 + kq;
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                *reinterpret_cast<f64x2*>(o1 + e) = (f64x2){s1[cl][kq + e], s1[cl][kq + e + 1]};
+                *reinterpret_cast<f64x2*>(o2 + e) = (f64x2){s2[cl][kq + e], s2[cl][kq + e + 1]};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------------
+bool dct_pair_can_run(size_t w, size_t h, const float* in, const float* out) {
+    return dct_rows_can_fold(w, in, out) && dct_cols_can_fold(w, h, in, out) && w % 8 == 0 && h % 8 == 0;
+}
+
+size_t dct_pair_operand_elems(size_t n_frames, size_t w, size_t h) {
+    const size_t a = n_frames * h * half_basis_kpad(w), b = n_frames * w * half_basis_kpad(h);
+    return a > b ? a : b;
+}
+
+int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
+                             size_t h, double* o1, double* o2) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if (is_row) {
+        const unsigned Kp = (unsigned)half_basis_kpad(w);
+        const size_t rows = n_frames * h, total = rows * (Kp / 4);
+        const size_t want = (total + 255) / 256;
+        const unsigned blocks = (unsigned)(want < 65536 ? (want ? want : 1) : 65536);
+        if (inverse) pair_prep_rows_kernel<true><<<blocks, 256, 0, st>>>(in, o1, o2, rows, (unsigned)w, Kp);
+        else         pair_prep_rows_kernel<false><<<blocks, 256, 0, st>>>(in, o1, o2, rows, (unsigned)w, Kp);
+    } else {
+        const unsigned Kp = (unsigned)half_basis_kpad(h);
+        const unsigned tiles_k = Kp / 32 + (Kp % 32 ? 1 : 0), tiles_c = (unsigned)((w + 63) / 64);
+        const unsigned long long nblk = (unsigned long long)tiles_k * tiles_c * n_frames;
+        if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+        if (inverse) pair_prep_cols_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)w, (unsigned)h, Kp, tiles_k, tiles_c);
+        else         pair_prep_cols_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)w, (unsigned)h, Kp, tiles_k, tiles_c);
+    }
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, const double* x1, const double* x2,
+                             const double* y1, const double* y2, float* out, size_t n_frames, size_t w, size_t h,
+                             Epilogue ep) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const size_t lines = is_row ? n_frames * h : n_frames * w;
+    const size_t len = is_row ? w : h;
+    if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned L = (unsigned)lines, NP = (unsigned)(len / 2), Kp = (unsigned)half_basis_kpad(len);
+    if ((unsigned long long)128 * Kp * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned tiles_m = (L + 127) / 128, tiles_n = (NP + 63) / 64;
+    const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+#define SSW_LAUNCH_PAIR(MODE) pair_gemm_f64_kernel<MODE><<<(unsigned)nblk, PT, 0, st>>>( \
+        x1, x2, y1, y2, out, L, NP, Kp, (unsigned)w, (unsigned)h, tiles_m, tiles_n, ep)
+    if (is_row) { if (inverse) SSW_LAUNCH_PAIR(PAIR_ROWS_INV); else SSW_LAUNCH_PAIR(PAIR_ROWS_FWD); }
+    else        { if (inverse) SSW_LAUNCH_PAIR(PAIR_COLS_INV); else SSW_LAUNCH_PAIR(PAIR_COLS_FWD); }
+#undef SSW_LAUNCH_PAIR
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+}  // namespace ssw

@@ -86,6 +86,15 @@ bool dct_rows_can_fold2(size_t w, const float* in, const float* out);
 int launch_dct_rows_fold2_fwd_f64(hipStream_t st, const float* in, float* out, size_t rows, size_t w,
                                   const double* b_odd, const double* b_even_even, const double* b_even_odd, Epilogue ep);
 
+// dct_pair_f64.hip: operand-ready folded f64 GEMMs (no VALU work in the MFMA loop) + their pre-passes
+bool dct_pair_can_run(size_t w, size_t h, const float* in, const float* out);
+size_t dct_pair_operand_elems(size_t n_frames, size_t w, size_t h);   // doubles per operand plane
+int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
+                             size_t h, double* o1, double* o2);
+int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, const double* x1, const double* x2,
+                             const double* y1, const double* y2, float* out, size_t n_frames, size_t w, size_t h,
+                             Epilogue ep);
+
 // select.hip
 struct SelectWorkspace {
     uint32_t* hist = nullptr;       // [n_frames][2048] sample histogram
@@ -148,6 +157,7 @@ struct ssw_ctx {
     std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
     bool fold = true;             // use the even/odd-folded GEMMs where the shape allows
     int fold_level = 1;           // 2 (opt-in): also fold the even half once more where a kernel exists (f64 forward rows)
+                                  // 3: f64 passes read pre-folded f64 operand planes (dct_pair_f64.hip)
 
     // growable scratch
     struct Buf {
@@ -155,6 +165,7 @@ struct ssw_ctx {
         size_t bytes = 0;
     };
     Buf plane[4];                 // y / i / q / t planes of the current chunk
+    Buf operand[2];               // f64 operand planes of the operand-ready GEMMs (fold_level 3)
     Buf idx;                      // [chunk][k] u32
     ssw::SelectWorkspace sel;
     Buf small;                    // misc (mark offsets, sims, ...)

@@ -164,7 +164,17 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         } else {
             SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
         }
-        if (is_row && fold && f64 && !inverse && ctx->fold_level >= 2 && dct_rows_can_fold2(w, src, dst)) {
+        if (fold && f64 && ctx->fold_level == 3 && dct_pair_can_run(w, h, src, dst)) {
+            const size_t elems = dct_pair_operand_elems(n, w, h);
+            SSW_TRY(grow(ctx->operand[0], elems * sizeof(double)));
+            SSW_TRY(grow(ctx->operand[1], elems * sizeof(double)));
+            double* x1 = (double*)ctx->operand[0].p;
+            double* x2 = (double*)ctx->operand[1].p;
+            StageTimer t(ctx, is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL);
+            SSW_TRY(launch_dct_pair_prep_f64(ctx->stream, is_row, inverse, src, n, w, h, x1, x2));
+            SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, x1, x2, (const double*)b0, (const double*)b1,
+                                             dst, n, w, h, ep));
+        } else if (is_row && fold && f64 && !inverse && ctx->fold_level == 2 && dct_rows_can_fold2(w, src, dst)) {
             const void *bee = nullptr, *beo = nullptr;
             SSW_TRY(get_basis(ctx, w / 2, false, true, 1, &bee));       // even / odd half bases of W/2
             SSW_TRY(get_basis(ctx, w / 2, false, true, 2, &beo));
