@@ -144,7 +144,7 @@ def main():
     lib = L.load()
     ctx = wm.Context(local_rank)
     ctx.set_chunk_frames(args.chunk)
-    fold_level = 0 if args.no_fold else int(os.environ.get("SSW_FOLD_LEVEL", "1"))
+    fold_level = 0 if args.no_fold else int(os.environ.get("SSW_FOLD_LEVEL", str(L.DCT_FOLDING_DEFAULT)))
     ctx.set_dct_folding(fold_level)
     W, H, K, B = args.width, args.height, args.k, args.batch
 
@@ -219,32 +219,36 @@ def main():
 
     def kernel_report(prec_name, stage):
         """Per-kernel achieved rates from the live event timers.  GEMMs: EXECUTED flop / time is the
-        utilisation (the even/odd-folded kernels execute half the dense 2*rows*N*N); the dense figure
-        / time is reported separately as "effective"."""
+        utilisation (folding executes 1/2 or 3/8 of the dense 2*lines*N*N); the dense figure / time
+        is reported separately as "effective"."""
         peak = PEAK_F64_MFMA_TFLOPS if prec_name == "f64" else PEAK_F32_MFMA_TFLOPS
-        row_dense = 2.0 * B * H * W * W * transforms_per_step * steps
-        col_dense = 2.0 * B * W * H * H * transforms_per_step * steps
-        row_flops = row_dense / (2.0 if fold_rows else 1.0)
-        # f64, W % 16 == 0: the three forward row passes of a step use the two-level kernel (3/8 dense)
-        fold2_rows = fold_rows and prec_name == "f64" and W % 16 == 0 and W >= 64 and fold_level >= 2
-        if fold2_rows:
-            row_flops = row_dense * (3 * 0.375 + 1 * 0.5) / 4.0
-        col_flops = col_dense / (2.0 if fold_cols else 1.0)
+        passes = transforms_per_step * steps
+        row_dense = 2.0 * B * H * W * W * passes
+        col_dense = 2.0 * B * W * H * H * passes
+        # which strategy each pass runs (mirrors dct2d_planes in csrc/ssw_lib.hip)
+        operand = prec_name == "f64" and fold_level >= 3 and fold_rows and fold_cols
+        two_rows = operand and fold_level >= 4 and W % 16 == 0 and W >= 64
+        two_cols = operand and fold_level >= 4 and H % 16 == 0 and H >= 64
+        row_frac = 0.375 if two_rows else (0.5 if fold_rows else 1.0)
+        col_frac = 0.375 if two_cols else (0.5 if fold_cols else 1.0)
+        if not operand and fold_rows and prec_name == "f64" and fold_level == 2 and W % 16 == 0 and W >= 64:
+            row_frac = (3 * 0.375 + 1 * 0.5) / 4.0   # in-kernel second level: the three forward row passes of a step
+        row_flops, col_flops = row_dense * row_frac, col_dense * col_frac
         row_ms, row_n = stage["dct_row"]["ms"], max(stage["dct_row"]["launches"], 1)
         col_ms, col_n = stage["dct_col"]["ms"], max(stage["dct_col"]["launches"], 1)
         row_tf = row_flops / (row_ms * 1e-3) / 1e12 if row_ms > 0 else 0.0
         col_tf = col_flops / (col_ms * 1e-3) / 1e12 if col_ms > 0 else 0.0
 
-        def gbs(bytes_per_px, passes, ms):
-            return (bytes_per_px * px_total * passes) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        def gbs(bytes_per_px, passes_, ms):
+            return (bytes_per_px * px_total * passes_) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         kernels = {
             "dct_rows": {"tflops": round(row_tf, 2), "frac_mfma": round(row_tf / peak, 4),
-                         "avg_launch_ms": round(row_ms / row_n, 4), "launches": row_n,
-                         "flop_per_launch": row_flops / row_n, "folded": fold_rows,
+                         "pass_ms": round(row_ms / passes, 4),
+                         "timed_passes": row_n, "executed_fraction_of_dense": row_frac,
                          "effective_dense_tflops": round(row_dense / (row_ms * 1e-3) / 1e12, 2) if row_ms > 0 else 0.0},
             "dct_cols": {"tflops": round(col_tf, 2), "frac_mfma": round(col_tf / peak, 4),
-                         "avg_launch_ms": round(col_ms / col_n, 4), "launches": col_n,
-                         "flop_per_launch": col_flops / col_n, "folded": fold_cols,
+                         "pass_ms": round(col_ms / passes, 4),
+                         "timed_passes": col_n, "executed_fraction_of_dense": col_frac,
                          "effective_dense_tflops": round(col_dense / (col_ms * 1e-3) / 1e12, 2) if col_ms > 0 else 0.0},
             # algorithmic bytes (SURVEY 8(d)): writer rgb->yiq 24 B/px + two reader rgb->y 16 B/px = 56 B/px
             "rgb_to_yiq": {"gbs": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]), 1),
@@ -255,14 +259,42 @@ def main():
             "select": {"gbs": round(gbs(4.0, 2, stage["select"]["ms"]), 1),
                        "frac_hbm": round(gbs(4.0, 2, stage["select"]["ms"]) / PEAK_HBM_GBS, 4)},
         }
-        roofline = {"bound": "mfma",
-                    "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name
-                              + (" + dct_rows_fold2_fwd_f64_kernel (forward passes)" if fold2_rows else ""),
-                    "achieved": round(row_tf, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(row_tf / peak, 4), "traffic": None,
-                    "note": ("executed flop per launch (even/odd-folded basis: half the dense 2*rows*W*W) / average "
-                             "launch time; dense-effective rate in kernels.dct_rows.effective_dense_tflops")
-                    if fold_rows else "dense flop per launch / average launch time"}
+        if operand:
+            # operand pre-passes: f32 plane in (4 B/px), f64 operand planes out (8 B/px); the second level
+            # re-reads and re-writes the even half (4 + 4 B/px); 2 passes per transform
+            per_px = (12.0 + (8.0 if two_rows else 0.0)) + (12.0 + (8.0 if two_cols else 0.0))
+            prep_gbs = gbs(per_px, transforms_per_step, stage["dct_prep"]["ms"])
+            kernels["dct_prep"] = {"gbs": round(prep_gbs, 1), "frac_hbm": round(prep_gbs / PEAK_HBM_GBS, 4),
+                                   "ms_per_step": round(stage["dct_prep"]["ms"] / steps, 3)}
+        lines_per_launch = min(args.chunk, B) * H
+        if operand:
+            # dominant launch: the row GEMM over the odd frequencies (all W/2 of them, K = W/2)
+            main_ms, main_n = stage["dct_row_main"]["ms"], max(stage["dct_row_main"]["launches"], 1)
+            main_flop = 2.0 * lines_per_launch * (W / 2.0) * (W / 2.0)
+            main_tf = main_flop * main_n / (main_ms * 1e-3) / 1e12 if main_ms > 0 else 0.0
+            kernels["dct_rows"]["main_launch"] = {"avg_ms": round(main_ms / main_n, 4), "launches": main_n,
+                                                  "flop_per_launch": main_flop, "tflops": round(main_tf, 2)}
+            cm_ms, cm_n = stage["dct_col_main"]["ms"], max(stage["dct_col_main"]["launches"], 1)
+            cm_flop = 2.0 * min(args.chunk, B) * W * (H / 2.0) * (H / 2.0)
+            kernels["dct_cols"]["main_launch"] = {"avg_ms": round(cm_ms / cm_n, 4), "launches": cm_n,
+                                                  "flop_per_launch": cm_flop,
+                                                  "tflops": round(cm_flop * cm_n / (cm_ms * 1e-3) / 1e12, 2) if cm_ms > 0 else 0.0}
+            roofline = {"bound": "mfma",
+                        "kernel": "pair_gemm_f64_kernel<rows, odd half>" if two_rows else "pair_gemm_f64_kernel<rows>",
+                        "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(main_tf / peak, 4), "traffic": None,
+                        "note": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency "
+                                 "half of the even/odd-folded basis GEMM) / its average duration; whole-pass rates incl. "
+                                 "the even-half launch in kernels.dct_rows")}
+        else:
+            roofline = {"bound": "mfma",
+                        "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name
+                                  + (" + dct_rows_fold2_fwd_f64_kernel (forward passes)" if row_frac not in (0.5, 1.0) else ""),
+                        "achieved": round(row_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(row_tf / peak, 4), "traffic": None,
+                        "note": ("executed flop per launch (even/odd-folded basis: half the dense 2*rows*W*W) / average "
+                                 "launch time; dense-effective rate in kernels.dct_rows.effective_dense_tflops")
+                        if fold_rows else "dense flop per launch / average launch time"}
         # HBM-side traffic of the dominant kernel: PMC counters collected offline exactly as
         # MI355X_MICROARCH.md prescribes (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) and
         # committed in profiles/r1_pmc_traffic.json; only quoted when this run matches that workload.
@@ -272,8 +304,12 @@ def main():
             if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, min(args.chunk, B)) and roofline["kernel"] in pmc["kernels"]:
                 roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
                 roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
-                roofline["algorithmic_bytes_per_launch"] = int(min(args.chunk, B) * H * W * 8 +
-                                                               2 * (W // 2) ** 2 * (8 if prec_name == "f64" else 4))
+                if operand:   # D operand plane in (8 B x W/2 per line), odd half basis (f64), f32 odd outputs
+                    roofline["algorithmic_bytes_per_launch"] = int(lines_per_launch * (W // 2) * 8 + (W // 2) ** 2 * 8 +
+                                                                   lines_per_launch * (W // 2) * 4)
+                else:
+                    roofline["algorithmic_bytes_per_launch"] = int(min(args.chunk, B) * H * W * 8 +
+                                                                   2 * (W // 2) ** 2 * (8 if prec_name == "f64" else 4))
         except (OSError, KeyError, ValueError):
             pass
         return kernels, roofline, {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
@@ -320,6 +356,7 @@ def main():
                                    f"(per-GPU shard of configs[3]: batch=2048 3840x2160 across 8 GPUs)",
                        "frames_per_gpu": B, "width": W, "height": H, "k": K, "alpha": 0.1,
                        "method": "Option2", "ordering": "Energy", "chunk_frames": args.chunk,
+                       "dct_folding_level": fold_level,
                        "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
             "kernels": kernels,

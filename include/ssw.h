@@ -109,13 +109,22 @@ void* ssw_ctx_stream(ssw_ctx* ctx);
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
 
 /* Even/odd folding of the basis GEMMs (fewer multiply-adds for the same transform; exact in f64,
-   one extra rounding per input pair in f32) where the frame shape allows (W % 8 == 0 / H % 8 == 0):
-   0 = dense GEMMs, 1 = default: one folding level (1/2 of the dense MACs), 2 = opt-in: a second
-   level (3/8 of the dense MACs) where a kernel exists (r1: the f64 forward row pass, +3.5 % end to
-   end at a lower MFMA utilisation). */
+   one extra rounding per input pair in f32) where the frame shape allows (W % 8 == 0 / H % 8 == 0).
+   Strategy levels:
+     0  dense GEMMs
+     1  one folding level inside the GEMM kernel (1/2 of the dense MACs); what f32 precision uses
+        for every level >= 1
+     2  level 1 + a second in-kernel level for the f64 forward row pass (3/8 of the dense MACs)
+     3  f64: "operand-ready" GEMMs -- HBM-bound pre-passes write the folded operands as f64 planes
+        and the MFMA loop issues no VALU instruction (see csrc/dct_pair_f64.hip); one level
+     4  default.  Level 3 with the even half folded once more wherever the axis length is a
+        multiple of 16 (3/8 of the dense MACs on that axis)
+   All levels produce the same f64-accurate result rounded once to f32 (tests/test_gpu_parity.py). */
+#define SSW_DCT_FOLDING_DEFAULT 4
 int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int level);
 
-/* Per-stage device timers (hipEvent pairs on the context's stream). */
+/* Per-stage device timers (hipEvent pairs on the context's stream).  DCT_ROW / DCT_COL cover the
+   GEMM launches of a pass; at folding levels 3 / 4 the pre-passes are timed separately (DCT_PREP). */
 typedef enum ssw_stage {
     SSW_STAGE_RGB_TO_YIQ = 0,     /* rgb -> y,i,q (24 B/px) or rgb -> y (16 B/px)   */
     SSW_STAGE_DCT_ROW = 1,        /* basis GEMM along the width                     */
@@ -127,7 +136,10 @@ typedef enum ssw_stage {
     SSW_STAGE_YIQ_TO_RGB = 7,
     SSW_STAGE_RESIZE = 8,         /* CatmullRom resize of the attack harness         */
     SSW_STAGE_CONVERT = 9,        /* u8 <-> f32 frame conversion                     */
-    SSW_STAGE_COUNT = 10
+    SSW_STAGE_DCT_PREP = 10,      /* f64 operand pre-passes of folding levels 3 / 4 (HBM-bound) */
+    SSW_STAGE_DCT_ROW_MAIN = 11,  /* the largest GEMM launch of a row pass alone (nested in DCT_ROW) */
+    SSW_STAGE_DCT_COL_MAIN = 12,  /* the largest GEMM launch of a column pass alone (nested in DCT_COL) */
+    SSW_STAGE_COUNT = 13
 } ssw_stage;
 int ssw_ctx_enable_timing(ssw_ctx* ctx, int enable);
 int ssw_ctx_reset_timing(ssw_ctx* ctx);

@@ -55,9 +55,10 @@ class Context:
         check(self._lib.ssw_ctx_set_chunk_frames(self.handle, n), "ssw_ctx_set_chunk_frames")
 
     def set_dct_folding(self, level=True):
-        """False / 0: dense basis GEMMs; True / 1: one even/odd folding level (default); 2: a second
-        level where a kernel exists (f64 forward row pass)."""
-        lvl = (1 if level else 0) if isinstance(level, bool) else int(level)
+        """Basis-GEMM strategy (include/ssw.h): False / 0 dense; 1 / 2 folding inside the GEMM kernel
+        (one level / a second one for the f64 forward row pass); 3 / 4 f64 operand-ready GEMMs with
+        one / two folding levels.  True selects the default (4)."""
+        lvl = (L.DCT_FOLDING_DEFAULT if level else 0) if isinstance(level, bool) else int(level)
         check(self._lib.ssw_ctx_set_dct_folding(self.handle, lvl), "ssw_ctx_set_dct_folding")
 
     def enable_timing(self, on: bool = True):

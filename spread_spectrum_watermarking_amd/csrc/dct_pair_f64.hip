@@ -36,16 +36,32 @@ constexpr int PBK = 8;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-enum { PAIR_ROWS_FWD = 0, PAIR_ROWS_INV = 1, PAIR_COLS_FWD = 2, PAIR_COLS_INV = 3 };
+// Epilogues.  n = transform length, idx = output index along the transformed axis:
+//   EPI_FWD    out[c1 + cs pair] = acc1, out[c2 + cs pair] = acc2          (forward, any folding level)
+//   EPI_FWD_ADJ  the same with c1 = 0, c2 = 1, cs = 2 on a row pass: one 8-byte store
+//   EPI_INV    out[pair] = acc1 + acc2, out[n-1-pair] = acc1 - acc2        (inverse, one level)
+//   EPI_INV_E  T[pair] = acc1 + acc2, T[n/2-1-pair] = acc1 - acc2  in f64  (inverse level 2: the even half E)
+//   EPI_INV_O  with n1 = pair, n2 = pair + n/4:  out[n1] = T[n1] + acc1, out[n-1-n1] = T[n1] - acc1,
+//              out[n2] = T[n2] + acc2, out[n-1-n2] = T[n2] - acc2          (inverse level 2: odd part + combine)
+enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4 };
 
-template <int MODE>
+struct PairOut {
+    float* out;          // f32 plane(s)
+    double* tmp;         // f64 E planes (EPI_INV_E / EPI_INV_O)
+    unsigned W, H;       // plane dims
+    unsigned n;          // transform length (W for a row pass, H for a column pass)
+    unsigned c1, c2, cs; // EPI_FWD
+};
+
+// COLS: lines are (frame, column) and the transformed axis runs down the rows.  SAMEX: X2 == X1
+// (one product's image operand feeds both basis operands; it is staged and read once).
+template <bool COLS, int EPI, bool SAMEX>
 __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     const double* __restrict__ X1g, const double* __restrict__ X2g, const double* __restrict__ Y1g,
-    const double* __restrict__ Y2g, float* __restrict__ OUT, unsigned L /*lines*/, unsigned NP /*pairs*/,
-    unsigned Kp, unsigned W, unsigned H, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
-    constexpr bool COLS = (MODE == PAIR_COLS_FWD || MODE == PAIR_COLS_INV);
-    constexpr bool INVERSE = (MODE == PAIR_ROWS_INV || MODE == PAIR_COLS_INV);
-    __shared__ __attribute__((aligned(16))) double sX[2][2][128 * PBK];   // [buffer][product]
+    const double* __restrict__ Y2g, PairOut po, unsigned L /*lines*/, unsigned NP /*pairs*/,
+    unsigned Kp, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
+    constexpr int NX = SAMEX ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) double sX[2][NX][128 * PBK];   // [buffer][product]
     __shared__ __attribute__((aligned(16))) double sY[2][2][64 * PBK];
 
     unsigned tm, tn;
@@ -91,7 +107,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             rx1[q] = __builtin_amdgcn_raw_buffer_load_b128(x1r, xoff[q], adv, 0);
-            rx2[q] = __builtin_amdgcn_raw_buffer_load_b128(x2r, xoff[q], adv, 0);
+            if (!SAMEX) rx2[q] = __builtin_amdgcn_raw_buffer_load_b128(x2r, xoff[q], adv, 0);
         }
         ry1 = __builtin_amdgcn_raw_buffer_load_b128(y1r, yoff, adv, 0);
         ry2 = __builtin_amdgcn_raw_buffer_load_b128(y2r, yoff, adv, 0);
@@ -106,7 +122,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             put(&sX[buf][0][64 * q * PBK], rx1[q]);
-            put(&sX[buf][1][64 * q * PBK], rx2[q]);
+            if (!SAMEX) put(&sX[buf][NX - 1][64 * q * PBK], rx2[q]);
         }
         put(&sY[buf][0][0], ry1);
         put(&sY[buf][1][0], ry2);
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f.x1[i] = sX[cur][0][rdx[sh] + 16 * i * PBK];
-            f.x2[i] = sX[cur][1][rdx[sh] + 16 * i * PBK];
+            if (!SAMEX) f.x2[i] = sX[cur][NX - 1][rdx[sh] + 16 * i * PBK];
         }
     };
     auto fmma = [&](const Frag& f) {
@@ -139,12 +155,13 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) {
+                const double xb = SAMEX ? f.x1[i] : f.x2[i];
                 if (!COLS) {      // D[row = line][col = pair]
                     acc1[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.x1[i], f.y1[jn], acc1[i][jn], 0, 0, 0);
-                    acc2[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.x2[i], f.y2[jn], acc2[i][jn], 0, 0, 0);
+                    acc2[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb, f.y2[jn], acc2[i][jn], 0, 0, 0);
                 } else {          // D[row = pair][col = line]: image columns along the lanes
                     acc1[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y1[jn], f.x1[i], acc1[i][jn], 0, 0, 0);
-                    acc2[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y2[jn], f.x2[i], acc2[i][jn], 0, 0, 0);
+                    acc2[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y2[jn], xb, acc2[i][jn], 0, 0, 0);
                 }
             }
     };
@@ -215,6 +232,33 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     fmma(fb);
 
     // D map of 16x16x4 f64: col = lane & 15, row = (lane >> 4) + 4 reg
+    const unsigned n = po.n, W = po.W, H = po.H;
+    // one output line: element idx of the transformed axis lives at lp[idx * es] (and tp[idx * es] in T)
+    auto emit = [&](float* lp, double* tp, size_t es, unsigned pair, double a1, double a2) {
+        if (EPI == EPI_FWD || EPI == EPI_FWD_ADJ) {
+            const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
+            if (EPI == EPI_FWD_ADJ) {
+                const f32x2 v = {apply_epilogue(ep, (float)a1, i1), apply_epilogue(ep, (float)a2, i2)};
+                *reinterpret_cast<f32x2*>(lp + i1) = v;
+            } else {
+                lp[i1 * es] = apply_epilogue(ep, (float)a1, i1);
+                lp[i2 * es] = apply_epilogue(ep, (float)a2, i2);
+            }
+        } else if (EPI == EPI_INV) {
+            lp[pair * es] = apply_epilogue(ep, (float)(a1 + a2), pair);
+            lp[(n - 1 - pair) * es] = apply_epilogue(ep, (float)(a1 - a2), n - 1 - pair);
+        } else if (EPI == EPI_INV_E) {
+            tp[pair * es] = a1 + a2;
+            tp[(n / 2 - 1 - pair) * es] = a1 - a2;
+        } else {
+            const unsigned n1 = pair, n2 = pair + n / 4;
+            const double e1 = tp[n1 * es], e2 = tp[n2 * es];
+            lp[n1 * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
+            lp[(n - 1 - n1) * es] = apply_epilogue(ep, (float)(e1 - a1), n - 1 - n1);
+            lp[n2 * es] = apply_epilogue(ep, (float)(e2 + a2), n2);
+            lp[(n - 1 - n2) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
+        }
+    };
     if (!COLS) {
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
@@ -226,15 +270,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const unsigned row = m0 + wm + 16 * i + lq + 4 * r;
                     if (row >= L) continue;
-                    float* o = OUT + (size_t)row * W;
-                    if (!INVERSE) {
-                        const f32x2 v = {apply_epilogue(ep, (float)acc1[i][jn][r], 2 * pair),
-                                         apply_epilogue(ep, (float)acc2[i][jn][r], 2 * pair + 1)};
-                        *reinterpret_cast<f32x2*>(o + 2 * pair) = v;
-                    } else {
-                        o[pair] = apply_epilogue(ep, (float)(acc1[i][jn][r] + acc2[i][jn][r]), pair);
-                        o[W - 1 - pair] = apply_epilogue(ep, (float)(acc1[i][jn][r] - acc2[i][jn][r]), W - 1 - pair);
-                    }
+                    emit(po.out + (size_t)row * W, po.tmp + (size_t)row * (n / 2), 1, pair, acc1[i][jn][r], acc2[i][jn][r]);
                 }
         }
     } else {
@@ -243,23 +279,50 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             const unsigned line = m0 + wm + 16 * i + li;       // = frame * W + column
             if (line >= L) continue;
             const unsigned z = line / W, col = line - z * W;
-            float* o = OUT + (size_t)z * H * W + col;
+            float* lp = po.out + (size_t)z * H * W + col;
+            double* tp = po.tmp + (size_t)z * (n / 2) * W + col;
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
                     if (pair >= NP) continue;
-                    if (!INVERSE) {
-                        o[(size_t)(2 * pair) * W] = apply_epilogue(ep, (float)acc1[i][jn][r], 2 * pair);
-                        o[(size_t)(2 * pair + 1) * W] = apply_epilogue(ep, (float)acc2[i][jn][r], 2 * pair + 1);
-                    } else {
-                        o[(size_t)pair * W] = apply_epilogue(ep, (float)(acc1[i][jn][r] + acc2[i][jn][r]), pair);
-                        o[(size_t)(H - 1 - pair) * W] =
-                            apply_epilogue(ep, (float)(acc1[i][jn][r] - acc2[i][jn][r]), H - 1 - pair);
-                    }
+                    emit(lp, tp, W, pair, acc1[i][jn][r], acc2[i][jn][r]);
                 }
         }
+    }
+}
+
+// Second folding level of the operand planes (f64 -> f64, k-contiguous lines; exact):
+//   forward:  SS[s] = S[s] + S[nh-1-s],  SD[s] = S[s] - S[nh-1-s]     s < nh/2
+//   inverse:  EE[s] = E[2s],             EO[s] = E[2s+1]
+// in: [lines][kp_in], nh valid entries per line; out: [lines][kp_out], zero padded.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep2_kernel(const double* __restrict__ IN, double* __restrict__ O1,
+                                                        double* __restrict__ O2, size_t lines, unsigned nh,
+                                                        unsigned kp_in, unsigned kp_out) {
+    const unsigned nq = nh / 2, dpl = kp_out / 2;                 // doubles pairs per output line
+    const size_t total = lines * dpl;
+    for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        const size_t line = id / dpl;
+        const unsigned s = (unsigned)(id % dpl) * 2;
+        f64x2 a = {0, 0}, b = {0, 0};
+        if (s < nq) {                                             // nq % 2 == 0
+            const double* x = IN + line * kp_in;
+            if (!INVERSE) {
+                const f64x2 u = *reinterpret_cast<const f64x2*>(x + s);
+                const f64x2 v = *reinterpret_cast<const f64x2*>(x + (nh - 2 - s));
+                a = (f64x2){u[0] + v[1], u[1] + v[0]};
+                b = (f64x2){u[0] - v[1], u[1] - v[0]};
+            } else {
+                const f64x2 u = *reinterpret_cast<const f64x2*>(x + 2 * s);
+                const f64x2 v = *reinterpret_cast<const f64x2*>(x + 2 * s + 2);
+                a = (f64x2){u[0], v[0]};
+                b = (f64x2){u[1], v[1]};
+            }
+        }
+        *reinterpret_cast<f64x2*>(O1 + line * kp_out + s) = a;
+        *reinterpret_cast<f64x2*>(O2 + line * kp_out + s) = b;
     }
 }
 
@@ -354,6 +417,8 @@ __global__ __launch_bounds__(256) void pair_prep_cols_kernel(const float* __rest
 bool dct_pair_can_run(size_t w, size_t h, const float* in, const float* out) {
     return dct_rows_can_fold(w, in, out) && dct_cols_can_fold(w, h, in, out) && w % 8 == 0 && h % 8 == 0;
 }
+// second level along an axis of length len: quarter length a multiple of 4, at least one k-step pair
+bool dct_pair_can_fold2(size_t len) { return len % 16 == 0 && len >= 64; }
 
 size_t dct_pair_operand_elems(size_t n_frames, size_t w, size_t h) {
     const size_t a = n_frames * h * half_basis_kpad(w), b = n_frames * w * half_basis_kpad(h);
@@ -383,23 +448,51 @@ int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const fl
     return SSW_OK;
 }
 
-int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, const double* x1, const double* x2,
-                             const double* y1, const double* y2, float* out, size_t n_frames, size_t w, size_t h,
-                             Epilogue ep) {
+int launch_dct_pair_prep2_f64(hipStream_t st, bool inverse, const double* in, size_t lines, size_t len,
+                              double* o1, double* o2) {
+    if (lines == 0) return SSW_OK;
+    const unsigned nh = (unsigned)(len / 2), kp_in = (unsigned)half_basis_kpad(len), kp_out = (unsigned)half_basis_kpad(len / 2);
+    const size_t total = lines * (kp_out / 2), want = (total + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 65536 ? (want ? want : 1) : 65536);
+    if (inverse) pair_prep2_kernel<true><<<blocks, 256, 0, st>>>(in, o1, o2, lines, nh, kp_in, kp_out);
+    else         pair_prep2_kernel<false><<<blocks, 256, 0, st>>>(in, o1, o2, lines, nh, kp_in, kp_out);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// One launch of the operand-ready GEMM.  `kind` selects the epilogue:
+//   0  one folding level (forward: interleave even/odd; inverse: mirror)            pairs = len/2, K = len/2
+//   1  level 2, even half: X = (SS, SD) | (EE, EO), Y = half bases of len/2          pairs = len/4, K = len/4
+//   2  level 2, odd half:  X = D | O (shared), Y = the two halves of the odd basis   pairs = len/4, K = len/2
+int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, const double* x1, const double* x2,
+                             const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
+                             size_t h, Epilogue ep) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t lines = is_row ? n_frames * h : n_frames * w;
     const size_t len = is_row ? w : h;
     if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const unsigned L = (unsigned)lines, NP = (unsigned)(len / 2), Kp = (unsigned)half_basis_kpad(len);
+    const unsigned L = (unsigned)lines;
+    const unsigned NP = (unsigned)(kind == 0 ? len / 2 : len / 4);
+    const unsigned Kp = (unsigned)(kind == 1 ? half_basis_kpad(len / 2) : half_basis_kpad(len));
     if ((unsigned long long)128 * Kp * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned tiles_m = (L + 127) / 128, tiles_n = (NP + 63) / 64;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-#define SSW_LAUNCH_PAIR(MODE) pair_gemm_f64_kernel<MODE><<<(unsigned)nblk, PT, 0, st>>>( \
-        x1, x2, y1, y2, out, L, NP, Kp, (unsigned)w, (unsigned)h, tiles_m, tiles_n, ep)
-    if (is_row) { if (inverse) SSW_LAUNCH_PAIR(PAIR_ROWS_INV); else SSW_LAUNCH_PAIR(PAIR_ROWS_FWD); }
-    else        { if (inverse) SSW_LAUNCH_PAIR(PAIR_COLS_INV); else SSW_LAUNCH_PAIR(PAIR_COLS_FWD); }
+    PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)len, 0, 1, 2};
+    if (kind == 1) { po.c1 = 0; po.c2 = 2; po.cs = 4; }
+    if (kind == 2) { po.c1 = 1; po.c2 = 1 + 2 * NP; po.cs = 2; }
+#define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) pair_gemm_f64_kernel<COLS, EPI, SAMEX><<<(unsigned)nblk, PT, 0, st>>>( \
+        x1, x2, y1, y2, po, L, NP, Kp, tiles_m, tiles_n, ep)
+    if (!inverse) {
+        if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD_ADJ, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
+        else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
+        else { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, true); else SSW_LAUNCH_PAIR(true, EPI_FWD, true); }
+    } else {
+        if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV, false); else SSW_LAUNCH_PAIR(true, EPI_INV, false); }
+        else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_E, false); else SSW_LAUNCH_PAIR(true, EPI_INV_E, false); }
+        else { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, true); else SSW_LAUNCH_PAIR(true, EPI_INV_O, true); }
+    }
 #undef SSW_LAUNCH_PAIR
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;

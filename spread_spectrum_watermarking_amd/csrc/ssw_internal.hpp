@@ -91,9 +91,13 @@ bool dct_pair_can_run(size_t w, size_t h, const float* in, const float* out);
 size_t dct_pair_operand_elems(size_t n_frames, size_t w, size_t h);   // doubles per operand plane
 int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
                              size_t h, double* o1, double* o2);
-int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, const double* x1, const double* x2,
-                             const double* y1, const double* y2, float* out, size_t n_frames, size_t w, size_t h,
-                             Epilogue ep);
+bool dct_pair_can_fold2(size_t len);
+int launch_dct_pair_prep2_f64(hipStream_t st, bool inverse, const double* in, size_t lines, size_t len,
+                              double* o1, double* o2);
+// kind 0: one folding level; 1 / 2: the even / odd half of two levels (see dct_pair_f64.hip)
+int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, const double* x1, const double* x2,
+                             const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
+                             size_t h, Epilogue ep);
 
 // select.hip
 struct SelectWorkspace {
@@ -156,8 +160,8 @@ struct ssw_ctx {
     // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded f32 kernels
     std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
     bool fold = true;             // use the even/odd-folded GEMMs where the shape allows
-    int fold_level = 1;           // 2 (opt-in): also fold the even half once more where a kernel exists (f64 forward rows)
-                                  // 3: f64 passes read pre-folded f64 operand planes (dct_pair_f64.hip)
+    int fold_level = SSW_DCT_FOLDING_DEFAULT;           // 2 (opt-in): also fold the even half once more where a kernel exists (f64 forward rows)
+                                  // 3: f64 passes read pre-folded f64 operand planes (dct_pair_f64.hip); 4: the same, two levels
 
     // growable scratch
     struct Buf {
@@ -165,7 +169,7 @@ struct ssw_ctx {
         size_t bytes = 0;
     };
     Buf plane[4];                 // y / i / q / t planes of the current chunk
-    Buf operand[2];               // f64 operand planes of the operand-ready GEMMs (fold_level 3)
+    Buf operand[5];               // f64 operand planes of the operand-ready GEMMs (fold_level 3 / 4): S|E, D|O, SS|EE, SD|EO, T
     Buf idx;                      // [chunk][k] u32
     ssw::SelectWorkspace sel;
     Buf small;                    // misc (mark offsets, sims, ...)

@@ -164,16 +164,45 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         } else {
             SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
         }
-        if (fold && f64 && ctx->fold_level == 3 && dct_pair_can_run(w, h, src, dst)) {
+        if (fold && f64 && ctx->fold_level >= 3 && dct_pair_can_run(w, h, src, dst)) {
             const size_t elems = dct_pair_operand_elems(n, w, h);
-            SSW_TRY(grow(ctx->operand[0], elems * sizeof(double)));
-            SSW_TRY(grow(ctx->operand[1], elems * sizeof(double)));
+            const bool two = ctx->fold_level >= 4 && dct_pair_can_fold2(len);
+            for (int b = 0; b < (two ? 5 : 2); ++b) SSW_TRY(grow(ctx->operand[b], elems * sizeof(double)));
             double* x1 = (double*)ctx->operand[0].p;
             double* x2 = (double*)ctx->operand[1].p;
-            StageTimer t(ctx, is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL);
-            SSW_TRY(launch_dct_pair_prep_f64(ctx->stream, is_row, inverse, src, n, w, h, x1, x2));
-            SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, x1, x2, (const double*)b0, (const double*)b1,
-                                             dst, n, w, h, ep));
+            const int st_pass = is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL;
+            const int st_main = is_row ? SSW_STAGE_DCT_ROW_MAIN : SSW_STAGE_DCT_COL_MAIN;
+            {
+                StageTimer t(ctx, SSW_STAGE_DCT_PREP);
+                SSW_TRY(launch_dct_pair_prep_f64(ctx->stream, is_row, inverse, src, n, w, h, x1, x2));
+            }
+            if (!two) {
+                StageTimer t(ctx, st_pass);
+                StageTimer tm(ctx, st_main);
+                SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 0, x1, x2, (const double*)b0, (const double*)b1,
+                                                 dst, nullptr, n, w, h, ep));
+            } else {
+                // even half: a half-length transform of S (forward) / of the even coefficients (inverse), folded again
+                const void *q0 = nullptr, *q1 = nullptr;
+                SSW_TRY(get_basis(ctx, len / 2, inverse, true, 1, &q0));
+                SSW_TRY(get_basis(ctx, len / 2, inverse, true, 2, &q1));
+                double* xx1 = (double*)ctx->operand[2].p;
+                double* xx2 = (double*)ctx->operand[3].p;
+                double* tmpE = (double*)ctx->operand[4].p;
+                const size_t lines = is_row ? n * h : n * w;
+                {
+                    StageTimer t(ctx, SSW_STAGE_DCT_PREP);
+                    SSW_TRY(launch_dct_pair_prep2_f64(ctx->stream, inverse, x1, lines, len, xx1, xx2));
+                }
+                StageTimer t(ctx, st_pass);
+                SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 1, xx1, xx2, (const double*)q0, (const double*)q1,
+                                                 dst, tmpE, n, w, h, ep));
+                // odd half: full half-length sum, the odd basis split into two row blocks
+                const double* bo = (const double*)b1;
+                StageTimer tm(ctx, st_main);
+                SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 2, x2, x2, bo, bo + (len / 4) * half_basis_kpad(len),
+                                                 dst, tmpE, n, w, h, ep));
+            }
         } else if (is_row && fold && f64 && !inverse && ctx->fold_level == 2 && dct_rows_can_fold2(w, src, dst)) {
             const void *bee = nullptr, *beo = nullptr;
             SSW_TRY(get_basis(ctx, w / 2, false, true, 1, &bee));       // even / odd half bases of W/2
@@ -304,8 +333,9 @@ int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames) {
 
 int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int enable) {
     if (!ctx) return SSW_ERR_BAD_ARG;
+    if (enable < 0 || enable > 4) return SSW_ERR_BAD_ARG;
     ctx->fold = enable != 0;
-    ctx->fold_level = enable;                 // 1: one folding level (default); >= 2: two where a kernel exists
+    ctx->fold_level = enable;                 // strategy levels: include/ssw.h
     return SSW_OK;
 }
 

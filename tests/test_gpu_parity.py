@@ -162,18 +162,21 @@ def test_dct_second_folding_level_is_bit_identical(shape, dct_type):
     assert np.abs(two.astype(np.float64) - ref).max() <= 2e-7 * max(ac_max(ref), 1.0)
 
 
-@pytest.mark.parametrize("shape", [(16, 16), (24, 40), (40, 128), (72, 136), (136, 72), (200, 328), (264, 8), (1080, 1920)])
+@pytest.mark.parametrize("shape", [(16, 16), (24, 40), (40, 128), (72, 136), (136, 72), (200, 328), (264, 8),
+                                   (64, 64), (80, 208), (208, 80), (144, 1040), (1080, 1920)])
 @pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
-def test_dct_operand_ready_path_matches(shape, dct_type):
-    """Pre-folded f64 operand planes + VALU-free GEMM loop (folding level 3): same exact operands
-    and f64 products as the in-kernel folding, only the summation order differs, so the rounded
-    result must agree with it and with the oracle."""
+@pytest.mark.parametrize("level", [3, 4])
+def test_dct_operand_ready_path_matches(shape, dct_type, level):
+    """Pre-folded f64 operand planes + VALU-free GEMM loop (folding level 3; level 4 folds the even
+    half once more wherever the axis length is a multiple of 16): same exact operands and f64
+    products as the in-kernel folding, only the summation order differs, so the rounded result
+    must agree with it and with the oracle."""
     rng = np.random.default_rng(shape[0] * 5 + shape[1])
     x = rng.random((3,) + shape).astype(np.float32)
     if dct_type == L.DCT3:
         x = np.stack([O.dct2d(p, O.DCT2) for p in x])
     one = G.dct2d(x, dct_type, F64)
-    G.ctx().set_dct_folding(3)
+    G.ctx().set_dct_folding(level)
     try:
         three = G.dct2d(x, dct_type, F64)
     finally:
