@@ -260,9 +260,8 @@ def main():
                        "frac_hbm": round(gbs(4.0, 2, stage["select"]["ms"]) / PEAK_HBM_GBS, 4)},
         }
         if operand:
-            # operand pre-passes: f32 plane in (4 B/px), f64 operand planes out (8 B/px); the second level
-            # re-reads and re-writes the even half (4 + 4 B/px); 2 passes per transform
-            per_px = (12.0 + (8.0 if two_rows else 0.0)) + (12.0 + (8.0 if two_cols else 0.0))
+            # operand pre-passes: f32 plane in (4 B/px), f64 operand planes out (8 B/px), once per pass
+            per_px = 24.0
             prep_gbs = gbs(per_px, transforms_per_step, stage["dct_prep"]["ms"])
             kernels["dct_prep"] = {"gbs": round(prep_gbs, 1), "frac_hbm": round(prep_gbs / PEAK_HBM_GBS, 4),
                                    "ms_per_step": round(stage["dct_prep"]["ms"] / steps, 3)}

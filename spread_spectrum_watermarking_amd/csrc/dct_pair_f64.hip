@@ -27,7 +27,6 @@
 #include "dct_common.hpp"
 
 #include <type_traits>
-#include <cstdlib>
 
 namespace ssw {
 
@@ -55,18 +54,21 @@ struct PairOut {
 
 // COLS: lines are (frame, column) and the transformed axis runs down the rows.  SAMEX: X2 == X1
 // (one product's image operand feeds both basis operands; it is staged and read once).
+// (A 256-line x 32-pair block tile for pair counts that 64 divides badly -- 540 at 4K -- was measured:
+// equal on the shared-X launches, 10 % slower on the two-operand ones; not kept.)
 template <bool COLS, int EPI, bool SAMEX>
 __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     const double* __restrict__ X1g, const double* __restrict__ X2g, const double* __restrict__ Y1g,
     const double* __restrict__ Y2g, PairOut po, unsigned L /*lines*/, unsigned NP /*pairs*/,
     unsigned Kp, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
     constexpr int NX = SAMEX ? 1 : 2;
-    __shared__ __attribute__((aligned(16))) double sX[2][NX][128 * PBK];   // [buffer][product]
-    __shared__ __attribute__((aligned(16))) double sY[2][2][64 * PBK];
+    constexpr int BM = 128, BN = 64, XQ = 2;                               // XQ: X lines per staging thread
+    __shared__ __attribute__((aligned(16))) double sX[2][NX][BM * PBK];    // [buffer][product]
+    __shared__ __attribute__((aligned(16))) double sY[2][2][BN * PBK];
 
     unsigned tm, tn;
     tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
-    const unsigned m0 = tm * 128, p0 = tn * 64;
+    const unsigned m0 = tm * BM, p0 = tn * BN;
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
     const unsigned wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
@@ -78,9 +80,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     // staging: line = tid / 4 (+ 64 q), k-pair = tid % 4
     const unsigned srow = tid >> 2, sc = tid & 3;
     const unsigned ssw = (srow >> 1) & 7;
-    unsigned xoff[2];
+    unsigned xoff[XQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < XQ; ++q) {
         unsigned r = m0 + srow + 64 * q;
         r = r < L ? r : L - 1;
         xoff[q] = ((r - m0) * Kp + 2 * sc) * 8u;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     yr = yr < NP ? yr : NP - 1;
     const unsigned yoff = ((yr - p0) * Kp + 2 * sc) * 8u;
     // block-uniform buffer resources (scalar registers); the k-step advances a scalar byte offset
-    const unsigned xbytes = 128u * Kp * 8u, ybytes = 64u * Kp * 8u;     // never read past: rows are clamped
+    const unsigned xbytes = (unsigned)BM * Kp * 8u, ybytes = (unsigned)BN * Kp * 8u;   // never read past: rows are clamped
     const __amdgpu_buffer_rsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc((void*)(X1g + (size_t)m0 * Kp), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void*)(X2g + (size_t)m0 * Kp), 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t y1r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y1g + (size_t)p0 * Kp), 0, ybytes, 0x00020000);
@@ -101,11 +103,11 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #pragma unroll
         for (int j = 0; j < 2; ++j) { acc1[i][j] = (f64x4){0, 0, 0, 0}; acc2[i][j] = (f64x4){0, 0, 0, 0}; }
 
-    u32x4 rx1[2], rx2[2], ry1, ry2;
+    u32x4 rx1[XQ], rx2[XQ], ry1, ry2;
     auto gload = [&](unsigned t) {
         const unsigned adv = t * (PBK * 8);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < XQ; ++q) {
             rx1[q] = __builtin_amdgcn_raw_buffer_load_b128(x1r, xoff[q], adv, 0);
             if (!SAMEX) rx2[q] = __builtin_amdgcn_raw_buffer_load_b128(x2r, xoff[q], adv, 0);
         }
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     auto lstore = [&](auto bufc) {
         constexpr int buf = decltype(bufc)::value;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < XQ; ++q) {
             put(&sX[buf][0][64 * q * PBK], rx1[q]);
             if (!SAMEX) put(&sX[buf][NX - 1][64 * q * PBK], rx2[q]);
         }
@@ -189,13 +191,14 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         if (STORE) {
+            constexpr int NLD = XQ * NX + 2;                    // staged 16-byte loads per thread (2 LDS writes each)
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < NLD; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 10 - NLD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);
         } else {
             __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
         }
@@ -293,39 +296,6 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     }
 }
 
-// Second folding level of the operand planes (f64 -> f64, k-contiguous lines; exact):
-//   forward:  SS[s] = S[s] + S[nh-1-s],  SD[s] = S[s] - S[nh-1-s]     s < nh/2
-//   inverse:  EE[s] = E[2s],             EO[s] = E[2s+1]
-// in: [lines][kp_in], nh valid entries per line; out: [lines][kp_out], zero padded.
-template <bool INVERSE>
-__global__ __launch_bounds__(256) void pair_prep2_kernel(const double* __restrict__ IN, double* __restrict__ O1,
-                                                        double* __restrict__ O2, size_t lines, unsigned nh,
-                                                        unsigned kp_in, unsigned kp_out) {
-    const unsigned nq = nh / 2, dpl = kp_out / 2;                 // doubles pairs per output line
-    const size_t total = lines * dpl;
-    for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
-        const size_t line = id / dpl;
-        const unsigned s = (unsigned)(id % dpl) * 2;
-        f64x2 a = {0, 0}, b = {0, 0};
-        if (s < nq) {                                             // nq % 2 == 0
-            const double* x = IN + line * kp_in;
-            if (!INVERSE) {
-                const f64x2 u = *reinterpret_cast<const f64x2*>(x + s);
-                const f64x2 v = *reinterpret_cast<const f64x2*>(x + (nh - 2 - s));
-                a = (f64x2){u[0] + v[1], u[1] + v[0]};
-                b = (f64x2){u[0] - v[1], u[1] - v[0]};
-            } else {
-                const f64x2 u = *reinterpret_cast<const f64x2*>(x + 2 * s);
-                const f64x2 v = *reinterpret_cast<const f64x2*>(x + 2 * s + 2);
-                a = (f64x2){u[0], v[0]};
-                b = (f64x2){u[1], v[1]};
-            }
-        }
-        *reinterpret_cast<f64x2*>(O1 + line * kp_out + s) = a;
-        *reinterpret_cast<f64x2*>(O2 + line * kp_out + s) = b;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Pre-passes (HBM-bound): f32 plane -> the two f64 operand planes of the pass.
 // ---------------------------------------------------------------------------------------------
@@ -412,6 +382,126 @@ __global__ __launch_bounds__(256) void pair_prep_cols_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Two-level pre-passes: f32 plane -> (SS, SD, D) forward / (EE, EO, O) inverse in one sweep
+// (12 B/px of HBM traffic instead of the 20 B/px of pre-pass + second-level pre-pass).
+//   forward, q < n/4:  S[q] = x[q] + x[n-1-q],  S' = x[n/2-1-q] + x[n/2+q];  SS = S + S',  SD = S - S'
+//                      D[q] = x[q] - x[n-1-q],  D[n/2-1-q] = x[n/2-1-q] - x[n/2+q]
+//   inverse, q < n/4:  EE[q] = c[4q],  EO[q] = c[4q+2],  O[2q] = c[4q+1],  O[2q+1] = c[4q+3]
+// Q1, Q2: [lines][kq] (kq = half_basis_kpad(n/2)); P: [lines][kp] (kp = half_basis_kpad(n)); zero padded.
+// ---------------------------------------------------------------------------------------------
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep4_rows_kernel(const float* __restrict__ X, double* __restrict__ Q1,
+                                                             double* __restrict__ Q2, double* __restrict__ P,
+                                                             size_t rows, unsigned W, unsigned Kq, unsigned Kp) {
+    const unsigned Nh = W / 2, Nq = W / 4, qpl = Kq / 4;
+    const size_t total = rows * qpl;
+    for (size_t id = blockIdx.x * (size_t)blockDim.x + threadIdx.x; id < total; id += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = id / qpl;
+        const unsigned q = (unsigned)(id % qpl) * 4;
+        f64x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+        double* p = P + row * Kp;
+        if (q < Nq) {                                             // Nq % 4 == 0
+            const float* x = X + row * W;
+            if (!INVERSE) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(x + q);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(x + (Nh - 4 - q));
+                const f32x4 c = *reinterpret_cast<const f32x4*>(x + (Nh + q));
+                const f32x4 d = *reinterpret_cast<const f32x4*>(x + (W - 4 - q));
+                f64x4 dn, dm;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const double s1 = (double)a[e] + (double)d[3 - e], s2 = (double)b[3 - e] + (double)c[e];
+                    a1[e] = s1 + s2;
+                    a2[e] = s1 - s2;
+                    dn[e] = (double)a[e] - (double)d[3 - e];
+                    dm[3 - e] = (double)b[3 - e] - (double)c[e];
+                }
+                *reinterpret_cast<f64x4*>(p + q) = dn;
+                *reinterpret_cast<f64x4*>(p + (Nh - 4 - q)) = dm;
+            } else {
+                f32x4 c[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) c[e] = *reinterpret_cast<const f32x4*>(x + 4 * (q + e));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a1[e] = (double)c[e][0]; a2[e] = (double)c[e][2]; }
+                *reinterpret_cast<f64x4*>(p + 2 * q) = (f64x4){(double)c[0][1], (double)c[0][3], (double)c[1][1], (double)c[1][3]};
+                *reinterpret_cast<f64x4*>(p + 2 * q + 4) = (f64x4){(double)c[2][1], (double)c[2][3], (double)c[3][1], (double)c[3][3]};
+            }
+        }
+        *reinterpret_cast<f64x4*>(Q1 + row * Kq + q) = a1;
+        *reinterpret_cast<f64x4*>(Q2 + row * Kq + q) = a2;
+        if (q == 0)
+            for (unsigned z = Nh; z < Kp; z += 4) *reinterpret_cast<f64x4*>(p + z) = (f64x4){0, 0, 0, 0};
+    }
+}
+
+// Column pass: lines = (frame, column); block tile 32 q x 32 columns, transposed through LDS.
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep4_cols_kernel(const float* __restrict__ IN, double* __restrict__ Q1,
+                                                             double* __restrict__ Q2, double* __restrict__ P,
+                                                             unsigned W, unsigned H, unsigned Kq, unsigned Kp,
+                                                             unsigned tiles_q, unsigned tiles_c) {
+    __shared__ double sA[32][33], sB[32][33], sC[32][33], sD[32][33];
+    const unsigned Hh = H / 2, Hq = H / 4;
+    const unsigned z = blockIdx.x / (tiles_q * tiles_c);
+    const unsigned tt = blockIdx.x % (tiles_q * tiles_c);
+    const unsigned q0 = (tt % tiles_q) * 32, c0 = (tt / tiles_q) * 32;
+    const float* __restrict__ Pz = IN + (size_t)z * H * W;
+    const unsigned tid = threadIdx.x;
+    {
+        const unsigned qr = tid >> 3, cq = (tid & 7) * 4, q = q0 + qr;
+        unsigned c = c0 + cq;
+        c = c + 4 <= W ? c : W - 4;                               // W % 4 == 0; duplicates are never written out
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, cc = a, d = a;
+        if (q < Hq) {
+            const unsigned ra = INVERSE ? 4 * q : q, rb = INVERSE ? 4 * q + 2 : Hh - 1 - q;
+            const unsigned rc = INVERSE ? 4 * q + 1 : Hh + q, rd = INVERSE ? 4 * q + 3 : H - 1 - q;
+            a = *reinterpret_cast<const f32x4*>(Pz + (size_t)ra * W + c);
+            b = *reinterpret_cast<const f32x4*>(Pz + (size_t)rb * W + c);
+            cc = *reinterpret_cast<const f32x4*>(Pz + (size_t)rc * W + c);
+            d = *reinterpret_cast<const f32x4*>(Pz + (size_t)rd * W + c);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!INVERSE) {
+                const double s1 = (double)a[e] + (double)d[e], s2 = (double)b[e] + (double)cc[e];
+                sA[cq + e][qr] = s1 + s2;
+                sB[cq + e][qr] = s1 - s2;
+                sC[cq + e][qr] = (double)a[e] - (double)d[e];        // D[q]
+                sD[cq + e][qr] = (double)b[e] - (double)cc[e];       // D[H/2-1-q]
+            } else {
+                sA[cq + e][qr] = (double)a[e];                        // EE[q]
+                sB[cq + e][qr] = (double)b[e];                        // EO[q]
+                sC[cq + e][qr] = (double)cc[e];                       // O[2q]
+                sD[cq + e][qr] = (double)d[e];                        // O[2q+1]
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned cl = tid >> 3, kq = (tid & 7) * 4;          // 4 consecutive q of one column per thread
+        const unsigned c = c0 + cl, q = q0 + kq;
+        if (c < W && q < Kq) {
+            const size_t line = (size_t)z * W + c;
+            *reinterpret_cast<f64x4*>(Q1 + line * Kq + q) = (f64x4){sA[cl][kq], sA[cl][kq + 1], sA[cl][kq + 2], sA[cl][kq + 3]};
+            *reinterpret_cast<f64x4*>(Q2 + line * Kq + q) = (f64x4){sB[cl][kq], sB[cl][kq + 1], sB[cl][kq + 2], sB[cl][kq + 3]};
+            double* p = P + line * Kp;
+            if (q < Hq) {
+                if (!INVERSE) {
+                    *reinterpret_cast<f64x4*>(p + q) = (f64x4){sC[cl][kq], sC[cl][kq + 1], sC[cl][kq + 2], sC[cl][kq + 3]};
+                    *reinterpret_cast<f64x4*>(p + (Hh - 4 - q)) = (f64x4){sD[cl][kq + 3], sD[cl][kq + 2], sD[cl][kq + 1], sD[cl][kq]};
+                } else {
+                    *reinterpret_cast<f64x4*>(p + 2 * q) = (f64x4){sC[cl][kq], sD[cl][kq], sC[cl][kq + 1], sD[cl][kq + 1]};
+                    *reinterpret_cast<f64x4*>(p + 2 * q + 4) = (f64x4){sC[cl][kq + 2], sD[cl][kq + 2], sC[cl][kq + 3], sD[cl][kq + 3]};
+                }
+            }
+            if (q == 0)
+                for (unsigned zz = Hh; zz < Kp; zz += 4) *reinterpret_cast<f64x4*>(p + zz) = (f64x4){0, 0, 0, 0};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
 bool dct_pair_can_run(size_t w, size_t h, const float* in, const float* out) {
@@ -448,14 +538,25 @@ int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const fl
     return SSW_OK;
 }
 
-int launch_dct_pair_prep2_f64(hipStream_t st, bool inverse, const double* in, size_t lines, size_t len,
-                              double* o1, double* o2) {
-    if (lines == 0) return SSW_OK;
-    const unsigned nh = (unsigned)(len / 2), kp_in = (unsigned)half_basis_kpad(len), kp_out = (unsigned)half_basis_kpad(len / 2);
-    const size_t total = lines * (kp_out / 2), want = (total + 255) / 256;
-    const unsigned blocks = (unsigned)(want < 65536 ? (want ? want : 1) : 65536);
-    if (inverse) pair_prep2_kernel<true><<<blocks, 256, 0, st>>>(in, o1, o2, lines, nh, kp_in, kp_out);
-    else         pair_prep2_kernel<false><<<blocks, 256, 0, st>>>(in, o1, o2, lines, nh, kp_in, kp_out);
+int launch_dct_pair_prep4_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
+                              size_t h, double* q1, double* q2, double* p) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const size_t len = is_row ? w : h;
+    const unsigned Kp = (unsigned)half_basis_kpad(len), Kq = (unsigned)half_basis_kpad(len / 2);
+    if (is_row) {
+        const size_t rows = n_frames * h, total = rows * (Kq / 4);
+        const size_t want = (total + 255) / 256;
+        const unsigned blocks = (unsigned)(want < 65536 ? (want ? want : 1) : 65536);
+        if (inverse) pair_prep4_rows_kernel<true><<<blocks, 256, 0, st>>>(in, q1, q2, p, rows, (unsigned)w, Kq, Kp);
+        else         pair_prep4_rows_kernel<false><<<blocks, 256, 0, st>>>(in, q1, q2, p, rows, (unsigned)w, Kq, Kp);
+    } else {
+        const unsigned tiles_q = (Kq + 31) / 32, tiles_c = (unsigned)((w + 31) / 32);
+        const unsigned long long nblk = (unsigned long long)tiles_q * tiles_c * n_frames;
+        if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+        if (inverse) pair_prep4_cols_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)w, (unsigned)h, Kq, Kp, tiles_q, tiles_c);
+        else         pair_prep4_cols_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)w, (unsigned)h, Kq, Kp, tiles_q, tiles_c);
+    }
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
@@ -475,8 +576,9 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     const unsigned L = (unsigned)lines;
     const unsigned NP = (unsigned)(kind == 0 ? len / 2 : len / 4);
     const unsigned Kp = (unsigned)(kind == 1 ? half_basis_kpad(len / 2) : half_basis_kpad(len));
-    if ((unsigned long long)128 * Kp * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const unsigned tiles_m = (L + 127) / 128, tiles_n = (NP + 63) / 64;
+    const unsigned BM = 128, BN = 64;
+    if ((unsigned long long)BM * Kp * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned tiles_m = (L + BM - 1) / BM, tiles_n = (NP + BN - 1) / BN;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)len, 0, 1, 2};

@@ -92,8 +92,9 @@ size_t dct_pair_operand_elems(size_t n_frames, size_t w, size_t h);   // doubles
 int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
                              size_t h, double* o1, double* o2);
 bool dct_pair_can_fold2(size_t len);
-int launch_dct_pair_prep2_f64(hipStream_t st, bool inverse, const double* in, size_t lines, size_t len,
-                              double* o1, double* o2);
+// f32 plane -> (SS, SD | EE, EO) [lines][kpad(len/2)] and (D | O) [lines][kpad(len)] in one sweep
+int launch_dct_pair_prep4_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
+                              size_t h, double* q1, double* q2, double* p);
 // kind 0: one folding level; 1 / 2: the even / odd half of two levels (see dct_pair_f64.hip)
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,

@@ -167,34 +167,35 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         if (fold && f64 && ctx->fold_level >= 3 && dct_pair_can_run(w, h, src, dst)) {
             const size_t elems = dct_pair_operand_elems(n, w, h);
             const bool two = ctx->fold_level >= 4 && dct_pair_can_fold2(len);
-            for (int b = 0; b < (two ? 5 : 2); ++b) SSW_TRY(grow(ctx->operand[b], elems * sizeof(double)));
-            double* x1 = (double*)ctx->operand[0].p;
-            double* x2 = (double*)ctx->operand[1].p;
             const int st_pass = is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL;
             const int st_main = is_row ? SSW_STAGE_DCT_ROW_MAIN : SSW_STAGE_DCT_COL_MAIN;
-            {
-                StageTimer t(ctx, SSW_STAGE_DCT_PREP);
-                SSW_TRY(launch_dct_pair_prep_f64(ctx->stream, is_row, inverse, src, n, w, h, x1, x2));
-            }
             if (!two) {
+                for (int b = 0; b < 2; ++b) SSW_TRY(grow(ctx->operand[b], elems * sizeof(double)));
+                double* x1 = (double*)ctx->operand[0].p;
+                double* x2 = (double*)ctx->operand[1].p;
+                {
+                    StageTimer t(ctx, SSW_STAGE_DCT_PREP);
+                    SSW_TRY(launch_dct_pair_prep_f64(ctx->stream, is_row, inverse, src, n, w, h, x1, x2));
+                }
                 StageTimer t(ctx, st_pass);
                 StageTimer tm(ctx, st_main);
                 SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 0, x1, x2, (const double*)b0, (const double*)b1,
                                                  dst, nullptr, n, w, h, ep));
             } else {
-                // even half: a half-length transform of S (forward) / of the even coefficients (inverse), folded again
+                for (int b = 1; b < (inverse ? 5 : 4); ++b) SSW_TRY(grow(ctx->operand[b], elems * sizeof(double)));
+                double* x2 = (double*)ctx->operand[1].p;      // D | O
+                double* xx1 = (double*)ctx->operand[2].p;     // SS | EE
+                double* xx2 = (double*)ctx->operand[3].p;     // SD | EO
+                double* tmpE = (double*)ctx->operand[4].p;    // inverse: the even half E in f64
                 const void *q0 = nullptr, *q1 = nullptr;
                 SSW_TRY(get_basis(ctx, len / 2, inverse, true, 1, &q0));
                 SSW_TRY(get_basis(ctx, len / 2, inverse, true, 2, &q1));
-                double* xx1 = (double*)ctx->operand[2].p;
-                double* xx2 = (double*)ctx->operand[3].p;
-                double* tmpE = (double*)ctx->operand[4].p;
-                const size_t lines = is_row ? n * h : n * w;
                 {
                     StageTimer t(ctx, SSW_STAGE_DCT_PREP);
-                    SSW_TRY(launch_dct_pair_prep2_f64(ctx->stream, inverse, x1, lines, len, xx1, xx2));
+                    SSW_TRY(launch_dct_pair_prep4_f64(ctx->stream, is_row, inverse, src, n, w, h, xx1, xx2, x2));
                 }
                 StageTimer t(ctx, st_pass);
+                // even half: a half-length transform of S (forward) / of the even coefficients (inverse), folded again
                 SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 1, xx1, xx2, (const double*)q0, (const double*)q1,
                                                  dst, tmpE, n, w, h, ep));
                 // odd half: full half-length sum, the odd basis split into two row blocks
