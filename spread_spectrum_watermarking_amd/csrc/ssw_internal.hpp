@@ -87,7 +87,8 @@ int launch_dct_rows_fold2_fwd_f64(hipStream_t st, const float* in, float* out, s
                                   const double* b_odd, const double* b_even_even, const double* b_even_odd, Epilogue ep);
 
 // dct_pair_f64.hip: operand-ready folded f64 GEMMs (no VALU work in the MFMA loop) + their pre-passes
-bool dct_pair_can_run(size_t w, size_t h, const float* in, const float* out);
+bool dct_pair_can_run(size_t n_frames, size_t w, size_t h, const float* in, const float* out);
+int launch_make_half_basis_blocked_f64(hipStream_t st, size_t n, bool inverse, int parity, double* out);   // [Kp/8][n/2][8]
 size_t dct_pair_operand_elems(size_t n_frames, size_t w, size_t h);   // doubles per operand plane
 int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
                              size_t h, double* o1, double* o2);
@@ -158,7 +159,7 @@ struct ssw_ctx {
     size_t chunk_frames = 16;
 
     // basis cache: (N, inverse, f64, kind) -> device pointer; kind 0 = dense N x N,
-    // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded f32 kernels
+    // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded kernels; 3 / 4 = the same, k-blocked (f64 operand-ready GEMMs)
     std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
     bool fold = true;             // use the even/odd-folded GEMMs where the shape allows
     int fold_level = SSW_DCT_FOLDING_DEFAULT;           // 2 (opt-in): also fold the even half once more where a kernel exists (f64 forward rows)

@@ -116,7 +116,8 @@ int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const vo
     void* p = nullptr;
     const size_t elems = kind == 0 ? n * dense_basis_kpad(n) : (n / 2) * half_basis_kpad(n);
     SSW_HIP_CHECK(hipMalloc(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float))));
-    int rc = kind != 0 ? (f64 ? launch_make_half_basis_f64(ctx->stream, n, inverse, kind - 1, (double*)p)
+    int rc = kind >= 3 ? launch_make_half_basis_blocked_f64(ctx->stream, n, inverse, kind - 3, (double*)p)
+             : kind != 0 ? (f64 ? launch_make_half_basis_f64(ctx->stream, n, inverse, kind - 1, (double*)p)
                               : launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p))
              : f64     ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
                        : launch_make_basis_f32(ctx->stream, n, inverse, (float*)p);
@@ -158,13 +159,17 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         const bool fold = ctx->fold && (is_row ? dct_rows_can_fold(w, src, dst) : dct_cols_can_fold(w, h, src, dst));
         const size_t len = is_row ? w : h;
         const void *b0 = nullptr, *b1 = nullptr;
-        if (fold) {
+        const bool operand = fold && f64 && ctx->fold_level >= 3 && dct_pair_can_run(n, w, h, src, dst);
+        if (operand) {
+            SSW_TRY(get_basis(ctx, len, inverse, true, 3, &b0));       // k-blocked half bases
+            SSW_TRY(get_basis(ctx, len, inverse, true, 4, &b1));
+        } else if (fold) {
             SSW_TRY(get_basis(ctx, len, inverse, f64, 1, &b0));
             SSW_TRY(get_basis(ctx, len, inverse, f64, 2, &b1));
         } else {
             SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
         }
-        if (fold && f64 && ctx->fold_level >= 3 && dct_pair_can_run(w, h, src, dst)) {
+        if (operand) {
             const size_t elems = dct_pair_operand_elems(n, w, h);
             const bool two = ctx->fold_level >= 4 && dct_pair_can_fold2(len);
             const int st_pass = is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL;
@@ -188,8 +193,8 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
                 double* xx2 = (double*)ctx->operand[3].p;     // SD | EO
                 double* tmpE = (double*)ctx->operand[4].p;    // inverse: the even half E in f64
                 const void *q0 = nullptr, *q1 = nullptr;
-                SSW_TRY(get_basis(ctx, len / 2, inverse, true, 1, &q0));
-                SSW_TRY(get_basis(ctx, len / 2, inverse, true, 2, &q1));
+                SSW_TRY(get_basis(ctx, len / 2, inverse, true, 3, &q0));
+                SSW_TRY(get_basis(ctx, len / 2, inverse, true, 4, &q1));
                 {
                     StageTimer t(ctx, SSW_STAGE_DCT_PREP);
                     SSW_TRY(launch_dct_pair_prep4_f64(ctx->stream, is_row, inverse, src, n, w, h, xx1, xx2, x2));
@@ -201,7 +206,7 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
                 // odd half: full half-length sum, the odd basis split into two row blocks
                 const double* bo = (const double*)b1;
                 StageTimer tm(ctx, st_main);
-                SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 2, x2, x2, bo, bo + (len / 4) * half_basis_kpad(len),
+                SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 2, x2, x2, bo, bo + (len / 4) * 8,
                                                  dst, tmpE, n, w, h, ep));
             }
         } else if (is_row && fold && f64 && !inverse && ctx->fold_level == 2 && dct_rows_can_fold2(w, src, dst)) {
