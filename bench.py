@@ -226,7 +226,7 @@ def main():
         row_dense = 2.0 * B * H * W * W * passes
         col_dense = 2.0 * B * W * H * H * passes
         # which strategy each pass runs (mirrors dct2d_planes in csrc/ssw_lib.hip)
-        operand = prec_name == "f64" and fold_level >= 3 and fold_rows and fold_cols
+        operand = fold_level >= 3 and fold_rows and fold_cols
         two_rows = operand and fold_level >= 4 and W % 16 == 0 and W >= 64
         two_cols = operand and fold_level >= 4 and H % 16 == 0 and H >= 64
         row_frac = 0.375 if two_rows else (0.5 if fold_rows else 1.0)
@@ -260,8 +260,8 @@ def main():
                        "frac_hbm": round(gbs(4.0, 2, stage["select"]["ms"]) / PEAK_HBM_GBS, 4)},
         }
         if operand:
-            # operand pre-passes: f32 plane in (4 B/px), f64 operand planes out (8 B/px), once per pass
-            per_px = 24.0
+            # operand pre-passes: f32 plane in (4 B/px), operand planes out (8 B/px in f64, 4 in f32), once per pass
+            per_px = 24.0 if prec_name == "f64" else 16.0
             prep_gbs = gbs(per_px, transforms_per_step, stage["dct_prep"]["ms"])
             kernels["dct_prep"] = {"gbs": round(prep_gbs, 1), "frac_hbm": round(prep_gbs / PEAK_HBM_GBS, 4),
                                    "ms_per_step": round(stage["dct_prep"]["ms"] / steps, 3)}
@@ -279,7 +279,7 @@ def main():
                                                   "flop_per_launch": cm_flop,
                                                   "tflops": round(cm_flop * cm_n / (cm_ms * 1e-3) / 1e12, 2) if cm_ms > 0 else 0.0}
             roofline = {"bound": "mfma",
-                        "kernel": "pair_gemm_f64_kernel<rows, odd half>" if two_rows else "pair_gemm_f64_kernel<rows>",
+                        "kernel": ("pair_gemm_%s_kernel<rows, odd half>" if two_rows else "pair_gemm_%s_kernel<rows>") % prec_name,
                         "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(main_tf / peak, 4), "traffic": None,
                         "note": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency "
@@ -303,8 +303,9 @@ def main():
             if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, min(args.chunk, B)) and roofline["kernel"] in pmc["kernels"]:
                 roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
                 roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
-                if operand:   # D operand plane in (8 B x W/2 per line), odd half basis (f64), f32 odd outputs
-                    roofline["algorithmic_bytes_per_launch"] = int(lines_per_launch * (W // 2) * 8 + (W // 2) ** 2 * 8 +
+                if operand:   # D operand plane in (W/2 elements per line), odd half basis, f32 odd outputs
+                    esz = 8 if prec_name == "f64" else 4
+                    roofline["algorithmic_bytes_per_launch"] = int(lines_per_launch * (W // 2) * esz + (W // 2) ** 2 * esz +
                                                                    lines_per_launch * (W // 2) * 4)
                 else:
                     roofline["algorithmic_bytes_per_launch"] = int(min(args.chunk, B) * H * W * 8 +

@@ -112,14 +112,15 @@ int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
    one extra rounding per input pair in f32) where the frame shape allows (W % 8 == 0 / H % 8 == 0).
    Strategy levels:
      0  dense GEMMs
-     1  one folding level inside the GEMM kernel (1/2 of the dense MACs); what f32 precision uses
-        for every level >= 1
+     1  one folding level inside the GEMM kernel (1/2 of the dense MACs)
      2  level 1 + a second in-kernel level for the f64 forward row pass (3/8 of the dense MACs)
-     3  f64: "operand-ready" GEMMs -- HBM-bound pre-passes write the folded operands as f64 planes
-        and the MFMA loop issues no VALU instruction (see csrc/dct_pair_f64.hip); one level
+     3  "operand-ready" GEMMs -- HBM-bound pre-passes write the folded operands once per pass as
+        k-blocked planes in the GEMM's precision and the MFMA loop issues no VALU instruction
+        (csrc/dct_pair_f64.hip, dct_pair_f32.hip, dct_pair_prep.hip); one level
      4  default.  Level 3 with the even half folded once more wherever the axis length is a
         multiple of 16 (3/8 of the dense MACs on that axis)
-   All levels produce the same f64-accurate result rounded once to f32 (tests/test_gpu_parity.py). */
+   In f64 all levels produce the same f64-accurate result rounded once to f32; in f32 each folding
+   level adds one rounding per operand sum (tests/test_gpu_parity.py holds both to their bars). */
 #define SSW_DCT_FOLDING_DEFAULT 4
 int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int level);
 

@@ -24,10 +24,7 @@
 // Block: 256 threads = 4 waves as 2 x 2; block tile 128 lines x 64 pairs x 2 products; k-step 8;
 // per wave 16 MFMA 16x16 tiles = 128 accumulator registers; LDS 48 KB double-buffered (XOR-swizzled
 // 64-byte rows, conflict-free ds_read_b128), one barrier per k-step, 2 blocks per CU.
-// Lane l: li = l & 15 (line / pair inside a 16x16 tile), lq = l >> 4: MFMA step s sums
-// k = 2 lq + s over the 4 lane groups (any assignment of k to MFMA slots is a valid summation
-// order; A and B use the same one).
-#include "dct_common.hpp"
+#include "dct_pair_common.hpp"
 
 #include <type_traits>
 
@@ -35,30 +32,8 @@ namespace ssw {
 
 constexpr int PT = 256;
 constexpr int PBK = 8;
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef PairOutT<double> PairOut;
 
-// Epilogues.  n = transform length, idx = output index along the transformed axis:
-//   EPI_FWD    out[c1 + cs pair] = acc1, out[c2 + cs pair] = acc2          (forward, any folding level)
-//   EPI_FWD_ADJ  the same with c1 = 0, c2 = 1, cs = 2 on a row pass: one 8-byte store
-//   EPI_INV    out[pair] = acc1 + acc2, out[n-1-pair] = acc1 - acc2        (inverse, one level)
-//   EPI_INV_E  T[pair] = acc1 + acc2, T[n/2-1-pair] = acc1 - acc2  in f64  (inverse level 2: the even half E)
-//   EPI_INV_O  with n1 = pair, n2 = pair + n/4:  out[n1] = T[n1] + acc1, out[n-1-n1] = T[n1] - acc1,
-//              out[n2] = T[n2] + acc2, out[n-1-n2] = T[n2] - acc2          (inverse level 2: odd part + combine)
-// element (line, k) of a k-blocked operand plane with `rows` lines
-__host__ __device__ inline size_t blk_index(size_t line, unsigned k, size_t rows) {
-    return ((size_t)(k >> 3) * rows + line) * 8 + (k & 7);
-}
-
-enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4 };
-
-struct PairOut {
-    float* out;          // f32 plane(s)
-    double* tmp;         // f64 E planes (EPI_INV_E / EPI_INV_O)
-    unsigned W, H;       // plane dims
-    unsigned n;          // transform length (W for a row pass, H for a column pass)
-    unsigned c1, c2, cs; // EPI_FWD
-};
 
 // COLS: lines are (frame, column) and the transformed axis runs down the rows.  SAMEX: X2 == X1
 // (one product's image operand feeds both basis operands; it is staged and read once).
@@ -305,302 +280,6 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Half bases in the k-blocked layout: [Kp / 8][n / 2][8], same values as make_half_basis_f64_kernel.
-// ---------------------------------------------------------------------------------------------
-__global__ void make_half_basis_blocked_f64_kernel(size_t n, bool inverse, int parity, size_t kpad, double* out) {
-    const size_t nh = n / 2, total = nh * kpad;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t o = i / kpad, s = i % kpad;
-        double v = 0.0;
-        if (s < nh) {
-            const size_t freq = inverse ? 2 * s + parity : 2 * o + parity;
-            const size_t pos = inverse ? o : s;
-            unsigned long long a = (unsigned long long)freq * (2ull * pos + 1ull);
-            a %= 4ull * n;
-            const double c = cospi((double)a / (double)(2ull * n));
-            v = !inverse ? 2.0 * c : (freq == 0 ? 0.25 : 0.5 * c);
-        }
-        out[blk_index(o, (unsigned)s, nh)] = v;
-    }
-}
-
-int launch_make_half_basis_blocked_f64(hipStream_t st, size_t n, bool inverse, int parity, double* out) {
-    const size_t total = (n / 2) * half_basis_kpad(n);
-    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    make_half_basis_blocked_f64_kernel<<<blocks ? blocks : 1, 256, 0, st>>>(n, inverse, parity, half_basis_kpad(n), out);
-    SSW_HIP_CHECK(hipGetLastError());
-    return SSW_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Pre-passes (HBM-bound): f32 plane -> the f64 operand planes of the pass, k-blocked.
-// One folding level:   forward  O1 = S, O2 = D;   inverse  O1 = E (even coefficients), O2 = O (odd)
-// ---------------------------------------------------------------------------------------------
-// Row pass: line = image row, k along the row.  Block = 32 lines x 32 k; thread = 4 consecutive k of
-// one line: 128-byte read runs per line, 512-byte write runs per k-block.
-template <bool INVERSE>
-__global__ __launch_bounds__(256) void pair_prep_rows_kernel(const float* __restrict__ X, double* __restrict__ O1,
-                                                            double* __restrict__ O2, unsigned rows, unsigned W, unsigned Kp,
-                                                            unsigned tiles_k) {
-    const unsigned Nh = W / 2;
-    const unsigned s = (blockIdx.x % tiles_k) * 32 + (threadIdx.x & 7) * 4;
-    const unsigned row = (blockIdx.x / tiles_k) * 32 + (threadIdx.x >> 3);
-    if (row >= rows || s >= Kp) return;
-    f64x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-    if (s < Nh) {                                                 // Nh % 4 == 0
-        const float* x = X + (size_t)row * W;
-        if (!INVERSE) {
-            const f32x4 u = *reinterpret_cast<const f32x4*>(x + s);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (W - 4 - s));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                a[e] = (double)u[e] + (double)v[3 - e];
-                b[e] = (double)u[e] - (double)v[3 - e];
-            }
-        } else {
-            const f32x4 u = *reinterpret_cast<const f32x4*>(x + 2 * s);
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + 2 * s + 4);
-            a = (f64x4){(double)u[0], (double)u[2], (double)v[0], (double)v[2]};
-            b = (f64x4){(double)u[1], (double)u[3], (double)v[1], (double)v[3]};
-        }
-    }
-    *reinterpret_cast<f64x4*>(O1 + blk_index(row, s, rows)) = a;
-    *reinterpret_cast<f64x4*>(O2 + blk_index(row, s, rows)) = b;
-}
-
-// Column pass: line = (frame, column), k along the image rows: fold / split + transpose through LDS.
-// Block tile: 32 k x 64 columns; written as 4 KB runs (64 lines x one 64-byte k-block piece).
-template <bool INVERSE>
-__global__ __launch_bounds__(256) void pair_prep_cols_kernel(const float* __restrict__ IN, double* __restrict__ O1,
-                                                            double* __restrict__ O2, unsigned W, unsigned H, unsigned Kp,
-                                                            unsigned n_frames, unsigned tiles_k, unsigned tiles_c) {
-    __shared__ double s1[64][33];
-    __shared__ double s2[64][33];
-    const unsigned Hh = H / 2;
-    const unsigned z = blockIdx.x / (tiles_k * tiles_c);
-    const unsigned tt = blockIdx.x % (tiles_k * tiles_c);
-    const unsigned k0 = (tt % tiles_k) * 32, c0 = (tt / tiles_k) * 64;
-    const float* __restrict__ P = IN + (size_t)z * H * W;
-    const unsigned tid = threadIdx.x;
-    {
-        const unsigned kr = tid >> 4, cq = (tid & 15) * 4;       // 16 k-rows per sweep, 4 columns per thread
-        unsigned c = c0 + cq;
-        c = c + 4 <= W ? c : W - 4;                               // W % 4 == 0; duplicates are never written out
-#pragma unroll
-        for (int sw = 0; sw < 2; ++sw) {
-            const unsigned kl = kr + 16 * sw, k = k0 + kl;
-            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
-            if (k < Hh) {
-                const unsigned ra = INVERSE ? 2 * k : k, rb = INVERSE ? 2 * k + 1 : H - 1 - k;
-                u = *reinterpret_cast<const f32x4*>(P + (size_t)ra * W + c);
-                v = *reinterpret_cast<const f32x4*>(P + (size_t)rb * W + c);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s1[cq + e][kl] = INVERSE ? (double)u[e] : (double)u[e] + (double)v[e];
-                s2[cq + e][kl] = INVERSE ? (double)v[e] : (double)u[e] - (double)v[e];
-            }
-        }
-    }
-    __syncthreads();
-    {
-        const unsigned cl = tid & 63, kq = (tid >> 6) * 8;        // one 64-byte k-block piece of one column per thread
-        const unsigned c = c0 + cl;
-        if (c < W && k0 + kq < Kp) {                              // Kp % 8 == 0
-            const size_t at = blk_index((size_t)z * W + c, k0 + kq, (size_t)n_frames * W);
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                *reinterpret_cast<f64x2*>(O1 + at + e) = (f64x2){s1[cl][kq + e], s1[cl][kq + e + 1]};
-                *reinterpret_cast<f64x2*>(O2 + at + e) = (f64x2){s2[cl][kq + e], s2[cl][kq + e + 1]};
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Two-level pre-passes: f32 plane -> (SS, SD, D) forward / (EE, EO, O) inverse in one sweep
-// (12 B/px of HBM traffic; a separate second-level pass over S would make it 20).
-//   forward, q < n/4:  S[q] = x[q] + x[n-1-q],  S' = x[n/2-1-q] + x[n/2+q];  SS = S + S',  SD = S - S'
-//                      D[q] = x[q] - x[n-1-q],  D[n/2-1-q] = x[n/2-1-q] - x[n/2+q]
-//   inverse, q < n/4:  EE[q] = c[4q],  EO[q] = c[4q+2],  O[2q] = c[4q+1],  O[2q+1] = c[4q+3]
-// Q1, Q2: kq = half_basis_kpad(n/2) wide; P: kp = half_basis_kpad(n) wide; k-blocked, zero padded.
-// ---------------------------------------------------------------------------------------------
-template <bool INVERSE>
-__global__ __launch_bounds__(256) void pair_prep4_rows_kernel(const float* __restrict__ X, double* __restrict__ Q1,
-                                                             double* __restrict__ Q2, double* __restrict__ P,
-                                                             unsigned rows, unsigned W, unsigned Kq, unsigned Kp,
-                                                             unsigned tiles_q) {
-    const unsigned Nh = W / 2, Nq = W / 4;
-    const unsigned q = (blockIdx.x % tiles_q) * 32 + (threadIdx.x & 7) * 4;
-    const unsigned row = (blockIdx.x / tiles_q) * 32 + (threadIdx.x >> 3);
-    if (row >= rows || q >= Kq) return;
-    f64x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
-    if (q < Nq) {                                                 // Nq % 4 == 0
-        const float* x = X + (size_t)row * W;
-        if (!INVERSE) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(x + q);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(x + (Nh - 4 - q));
-            const f32x4 c = *reinterpret_cast<const f32x4*>(x + (Nh + q));
-            const f32x4 d = *reinterpret_cast<const f32x4*>(x + (W - 4 - q));
-            f64x4 dn, dm;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const double s1 = (double)a[e] + (double)d[3 - e], s2 = (double)b[3 - e] + (double)c[e];
-                a1[e] = s1 + s2;
-                a2[e] = s1 - s2;
-                dn[e] = (double)a[e] - (double)d[3 - e];
-                dm[3 - e] = (double)b[3 - e] - (double)c[e];
-            }
-            *reinterpret_cast<f64x4*>(P + blk_index(row, q, rows)) = dn;
-            *reinterpret_cast<f64x4*>(P + blk_index(row, Nh - 4 - q, rows)) = dm;
-        } else {
-            f32x4 c[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) c[e] = *reinterpret_cast<const f32x4*>(x + 4 * (q + e));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { a1[e] = (double)c[e][0]; a2[e] = (double)c[e][2]; }
-            double* o = P + blk_index(row, 2 * q, rows);           // 2 q is a multiple of 8: one whole k-block piece
-            *reinterpret_cast<f64x4*>(o) = (f64x4){(double)c[0][1], (double)c[0][3], (double)c[1][1], (double)c[1][3]};
-            *reinterpret_cast<f64x4*>(o + 4) = (f64x4){(double)c[2][1], (double)c[2][3], (double)c[3][1], (double)c[3][3]};
-        }
-    }
-    *reinterpret_cast<f64x4*>(Q1 + blk_index(row, q, rows)) = a1;
-    *reinterpret_cast<f64x4*>(Q2 + blk_index(row, q, rows)) = a2;
-    if (q == 0)
-        for (unsigned z = Nh; z < Kp; z += 4) *reinterpret_cast<f64x4*>(P + blk_index(row, z, rows)) = (f64x4){0, 0, 0, 0};
-}
-
-// Column pass: lines = (frame, column); block tile 32 q x 32 columns, transposed through LDS and
-// written as 2 KB runs (32 lines x one 64-byte k-block piece).
-template <bool INVERSE>
-__global__ __launch_bounds__(256) void pair_prep4_cols_kernel(const float* __restrict__ IN, double* __restrict__ Q1,
-                                                             double* __restrict__ Q2, double* __restrict__ P,
-                                                             unsigned W, unsigned H, unsigned Kq, unsigned Kp,
-                                                             unsigned n_frames, unsigned tiles_q, unsigned tiles_c) {
-    __shared__ double sA[32][33], sB[32][33], sC[32][33], sD[32][33];
-    const unsigned Hh = H / 2, Hq = H / 4;
-    const unsigned z = blockIdx.x / (tiles_q * tiles_c);
-    const unsigned tt = blockIdx.x % (tiles_q * tiles_c);
-    const unsigned q0 = (tt % tiles_q) * 32, c0 = (tt / tiles_q) * 32;
-    const float* __restrict__ Pz = IN + (size_t)z * H * W;
-    const unsigned tid = threadIdx.x;
-    {
-        const unsigned qr = tid >> 3, cq = (tid & 7) * 4, q = q0 + qr;
-        unsigned c = c0 + cq;
-        c = c + 4 <= W ? c : W - 4;                               // W % 4 == 0; duplicates are never written out
-        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, cc = a, d = a;
-        if (q < Hq) {
-            const unsigned ra = INVERSE ? 4 * q : q, rb = INVERSE ? 4 * q + 2 : Hh - 1 - q;
-            const unsigned rc = INVERSE ? 4 * q + 1 : Hh + q, rd = INVERSE ? 4 * q + 3 : H - 1 - q;
-            a = *reinterpret_cast<const f32x4*>(Pz + (size_t)ra * W + c);
-            b = *reinterpret_cast<const f32x4*>(Pz + (size_t)rb * W + c);
-            cc = *reinterpret_cast<const f32x4*>(Pz + (size_t)rc * W + c);
-            d = *reinterpret_cast<const f32x4*>(Pz + (size_t)rd * W + c);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (!INVERSE) {
-                const double s1 = (double)a[e] + (double)d[e], s2 = (double)b[e] + (double)cc[e];
-                sA[cq + e][qr] = s1 + s2;
-                sB[cq + e][qr] = s1 - s2;
-                sC[cq + e][qr] = (double)a[e] - (double)d[e];        // D[q]
-                sD[cq + e][qr] = (double)b[e] - (double)cc[e];       // D[H/2-1-q]
-            } else {
-                sA[cq + e][qr] = (double)a[e];                        // EE[q]
-                sB[cq + e][qr] = (double)b[e];                        // EO[q]
-                sC[cq + e][qr] = (double)cc[e];                       // O[2q]
-                sD[cq + e][qr] = (double)d[e];                        // O[2q+1]
-            }
-        }
-    }
-    __syncthreads();
-    {
-        const unsigned cl = tid & 31, kq = (tid >> 5) * 4;         // 4 consecutive q of one column per thread
-        const unsigned c = c0 + cl, q = q0 + kq;
-        if (c < W && q < Kq) {
-            const size_t line = (size_t)z * W + c, lines = (size_t)n_frames * W;
-            *reinterpret_cast<f64x4*>(Q1 + blk_index(line, q, lines)) = (f64x4){sA[cl][kq], sA[cl][kq + 1], sA[cl][kq + 2], sA[cl][kq + 3]};
-            *reinterpret_cast<f64x4*>(Q2 + blk_index(line, q, lines)) = (f64x4){sB[cl][kq], sB[cl][kq + 1], sB[cl][kq + 2], sB[cl][kq + 3]};
-            if (q < Hq) {
-                if (!INVERSE) {
-                    *reinterpret_cast<f64x4*>(P + blk_index(line, q, lines)) = (f64x4){sC[cl][kq], sC[cl][kq + 1], sC[cl][kq + 2], sC[cl][kq + 3]};
-                    *reinterpret_cast<f64x4*>(P + blk_index(line, Hh - 4 - q, lines)) = (f64x4){sD[cl][kq + 3], sD[cl][kq + 2], sD[cl][kq + 1], sD[cl][kq]};
-                } else {
-                    double* o = P + blk_index(line, 2 * q, lines);
-                    *reinterpret_cast<f64x4*>(o) = (f64x4){sC[cl][kq], sD[cl][kq], sC[cl][kq + 1], sD[cl][kq + 1]};
-                    *reinterpret_cast<f64x4*>(o + 4) = (f64x4){sC[cl][kq + 2], sD[cl][kq + 2], sC[cl][kq + 3], sD[cl][kq + 3]};
-                }
-            }
-            if (q == 0)
-                for (unsigned zz = Hh; zz < Kp; zz += 4) *reinterpret_cast<f64x4*>(P + blk_index(line, zz, lines)) = (f64x4){0, 0, 0, 0};
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Launchers
-// ---------------------------------------------------------------------------------------------
-size_t dct_pair_operand_elems(size_t n_frames, size_t w, size_t h) {
-    const size_t a = n_frames * h * half_basis_kpad(w), b = n_frames * w * half_basis_kpad(h);
-    return a > b ? a : b;
-}
-
-bool dct_pair_can_run(size_t n_frames, size_t w, size_t h, const float* in, const float* out) {
-    // an operand plane must stay below 4 GB (32-bit scalar offsets walk its k-blocks)
-    return dct_rows_can_fold(w, in, out) && dct_cols_can_fold(w, h, in, out) && w % 8 == 0 && h % 8 == 0 &&
-           dct_pair_operand_elems(n_frames, w, h) * sizeof(double) <= 0xFFFFFFFFull;
-}
-// second level along an axis of length len: quarter length a multiple of 4, at least one k-step pair
-bool dct_pair_can_fold2(size_t len) { return len % 16 == 0 && len >= 64; }
-
-
-int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
-                             size_t h, double* o1, double* o2) {
-    if (n_frames == 0) return SSW_OK;
-    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
-    if (is_row) {
-        const unsigned Kp = (unsigned)half_basis_kpad(w), tiles_k = (Kp + 31) / 32;
-        const size_t rows = n_frames * h;
-        const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_k;
-        if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-        if (inverse) pair_prep_rows_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)rows, (unsigned)w, Kp, tiles_k);
-        else         pair_prep_rows_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)rows, (unsigned)w, Kp, tiles_k);
-    } else {
-        const unsigned Kp = (unsigned)half_basis_kpad(h);
-        const unsigned tiles_k = Kp / 32 + (Kp % 32 ? 1 : 0), tiles_c = (unsigned)((w + 63) / 64);
-        const unsigned long long nblk = (unsigned long long)tiles_k * tiles_c * n_frames;
-        if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-        if (inverse) pair_prep_cols_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)w, (unsigned)h, Kp, (unsigned)n_frames, tiles_k, tiles_c);
-        else         pair_prep_cols_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)w, (unsigned)h, Kp, (unsigned)n_frames, tiles_k, tiles_c);
-    }
-    SSW_HIP_CHECK(hipGetLastError());
-    return SSW_OK;
-}
-
-int launch_dct_pair_prep4_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
-                              size_t h, double* q1, double* q2, double* p) {
-    if (n_frames == 0) return SSW_OK;
-    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const size_t len = is_row ? w : h;
-    const unsigned Kp = (unsigned)half_basis_kpad(len), Kq = (unsigned)half_basis_kpad(len / 2);
-    const unsigned tiles_q = (Kq + 31) / 32;
-    if (is_row) {
-        const size_t rows = n_frames * h;
-        const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_q;
-        if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-        if (inverse) pair_prep4_rows_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)rows, (unsigned)w, Kq, Kp, tiles_q);
-        else         pair_prep4_rows_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)rows, (unsigned)w, Kq, Kp, tiles_q);
-    } else {
-        const unsigned tiles_c = (unsigned)((w + 31) / 32);
-        const unsigned long long nblk = (unsigned long long)tiles_q * tiles_c * n_frames;
-        if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-        if (inverse) pair_prep4_cols_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)w, (unsigned)h, Kq, Kp, (unsigned)n_frames, tiles_q, tiles_c);
-        else         pair_prep4_cols_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)w, (unsigned)h, Kq, Kp, (unsigned)n_frames, tiles_q, tiles_c);
-    }
-    SSW_HIP_CHECK(hipGetLastError());
-    return SSW_OK;
-}
 
 // One launch of the operand-ready GEMM.  `kind` selects the epilogue:
 //   0  one folding level (forward: interleave even/odd; inverse: mirror)            pairs = len/2, K = len/2
@@ -617,7 +296,7 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned L = (unsigned)lines;
     const unsigned NP = (unsigned)(kind == 0 ? len / 2 : len / 4);
-    const unsigned Kp = (unsigned)(kind == 1 ? half_basis_kpad(len / 2) : half_basis_kpad(len));
+    const unsigned Kp = (unsigned)(kind == 1 ? pair_kpad<double>(len / 2) : pair_kpad<double>(len));
     const unsigned BM = 128, BN = 64;
     const unsigned tiles_m = (L + BM - 1) / BM, tiles_n = (NP + BN - 1) / BN;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;

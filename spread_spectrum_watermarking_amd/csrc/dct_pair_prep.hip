@@ -1,0 +1,322 @@
+// HBM-bound pre-passes of the operand-ready GEMMs (dct_pair_f64.hip / dct_pair_f32.hip): they write
+// the image operand of a pass once, already folded (forward) or split (inverse), in the precision the
+// MFMA consumes (T = double: every sum exact; T = float: one rounding per sum) and in the k-blocked
+// layout (dct_pair_common.hpp).  Also the half bases in that layout.
+#include "dct_pair_common.hpp"
+
+namespace ssw {
+
+// ---------------------------------------------------------------------------------------------
+// Half bases in the k-blocked layout: [Kp / 8][n / 2][8], same values as make_half_basis_f64_kernel.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void make_half_basis_blocked_kernel(size_t n, bool inverse, int parity, size_t kpad, T* out) {
+    const size_t nh = n / 2, total = nh * kpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = i / kpad, s = i % kpad;
+        double v = 0.0;
+        if (s < nh) {
+            const size_t freq = inverse ? 2 * s + parity : 2 * o + parity;
+            const size_t pos = inverse ? o : s;
+            unsigned long long a = (unsigned long long)freq * (2ull * pos + 1ull);
+            a %= 4ull * n;
+            const double c = cospi((double)a / (double)(2ull * n));
+            v = !inverse ? 2.0 * c : (freq == 0 ? 0.25 : 0.5 * c);
+        }
+        out[blk_index<T>(o, (unsigned)s, nh)] = (T)v;
+    }
+}
+
+size_t dct_pair_kpad(bool f64, size_t n) { return f64 ? pair_kpad<double>(n) : pair_kpad<float>(n); }
+
+int launch_make_half_basis_blocked(hipStream_t st, bool f64, size_t n, bool inverse, int parity, void* out) {
+    const size_t kp = dct_pair_kpad(f64, n), total = (n / 2) * kp;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (f64) make_half_basis_blocked_kernel<double><<<blocks ? blocks : 1, 256, 0, st>>>(n, inverse, parity, kp, (double*)out);
+    else     make_half_basis_blocked_kernel<float><<<blocks ? blocks : 1, 256, 0, st>>>(n, inverse, parity, kp, (float*)out);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-passes (HBM-bound): f32 plane -> the f64 operand planes of the pass, k-blocked.
+// One folding level:   forward  O1 = S, O2 = D;   inverse  O1 = E (even coefficients), O2 = O (odd)
+// ---------------------------------------------------------------------------------------------
+// Row pass: line = image row, k along the row.  Block = 32 lines x 32 k; thread = 4 consecutive k of
+// one line: 128-byte read runs per line, 512-byte write runs per k-block.
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep_rows_kernel(const float* __restrict__ X, T* __restrict__ O1,
+                                                            T* __restrict__ O2, unsigned rows, unsigned W, unsigned Kp,
+                                                            unsigned tiles_k) {
+    const unsigned Nh = W / 2;
+    const unsigned s = (blockIdx.x % tiles_k) * 32 + (threadIdx.x & 7) * 4;
+    const unsigned row = (blockIdx.x / tiles_k) * 32 + (threadIdx.x >> 3);
+    if (row >= rows || s >= Kp) return;
+    vec4_t<T> a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (s < Nh) {                                                 // Nh % 4 == 0
+        const float* x = X + (size_t)row * W;
+        if (!INVERSE) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(x + s);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + (W - 4 - s));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = (T)u[e] + (T)v[3 - e];
+                b[e] = (T)u[e] - (T)v[3 - e];
+            }
+        } else {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(x + 2 * s);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + 2 * s + 4);
+            a = (vec4_t<T>){(T)u[0], (T)u[2], (T)v[0], (T)v[2]};
+            b = (vec4_t<T>){(T)u[1], (T)u[3], (T)v[1], (T)v[3]};
+        }
+    }
+    *reinterpret_cast<vec4_t<T>*>(O1 + blk_index<T>(row, s, rows)) = a;
+    *reinterpret_cast<vec4_t<T>*>(O2 + blk_index<T>(row, s, rows)) = b;
+}
+
+// Column pass: line = (frame, column), k along the image rows: fold / split + transpose through LDS.
+// Block tile: 32 k x 64 columns; written as 4 KB runs (64 lines x one 64-byte k-block piece).
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep_cols_kernel(const float* __restrict__ IN, T* __restrict__ O1,
+                                                            T* __restrict__ O2, unsigned W, unsigned H, unsigned Kp,
+                                                            unsigned n_frames, unsigned tiles_k, unsigned tiles_c) {
+    __shared__ T s1[64][33];
+    __shared__ T s2[64][33];
+    const unsigned Hh = H / 2;
+    const unsigned z = blockIdx.x / (tiles_k * tiles_c);
+    const unsigned tt = blockIdx.x % (tiles_k * tiles_c);
+    const unsigned k0 = (tt % tiles_k) * 32, c0 = (tt / tiles_k) * 64;
+    const float* __restrict__ P = IN + (size_t)z * H * W;
+    const unsigned tid = threadIdx.x;
+    {
+        const unsigned kr = tid >> 4, cq = (tid & 15) * 4;       // 16 k-rows per sweep, 4 columns per thread
+        unsigned c = c0 + cq;
+        c = c + 4 <= W ? c : W - 4;                               // W % 4 == 0; duplicates are never written out
+#pragma unroll
+        for (int sw = 0; sw < 2; ++sw) {
+            const unsigned kl = kr + 16 * sw, k = k0 + kl;
+            f32x4 u = {0.f, 0.f, 0.f, 0.f}, v = {0.f, 0.f, 0.f, 0.f};
+            if (k < Hh) {
+                const unsigned ra = INVERSE ? 2 * k : k, rb = INVERSE ? 2 * k + 1 : H - 1 - k;
+                u = *reinterpret_cast<const f32x4*>(P + (size_t)ra * W + c);
+                v = *reinterpret_cast<const f32x4*>(P + (size_t)rb * W + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[cq + e][kl] = INVERSE ? (T)u[e] : (T)u[e] + (T)v[e];
+                s2[cq + e][kl] = INVERSE ? (T)v[e] : (T)u[e] - (T)v[e];
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned cl = tid & 63, kq = (tid >> 6) * 8;        // one 64-byte k-block piece of one column per thread
+        const unsigned c = c0 + cl;
+        if (c < W && k0 + kq < Kp) {                              // Kp % 8 == 0
+            const size_t at = blk_index<T>((size_t)z * W + c, k0 + kq, (size_t)n_frames * W);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                *reinterpret_cast<vec2_t<T>*>(O1 + at + e) = (vec2_t<T>){s1[cl][kq + e], s1[cl][kq + e + 1]};
+                *reinterpret_cast<vec2_t<T>*>(O2 + at + e) = (vec2_t<T>){s2[cl][kq + e], s2[cl][kq + e + 1]};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two-level pre-passes: f32 plane -> (SS, SD, D) forward / (EE, EO, O) inverse in one sweep
+// (12 B/px of HBM traffic; a separate second-level pass over S would make it 20).
+//   forward, q < n/4:  S[q] = x[q] + x[n-1-q],  S' = x[n/2-1-q] + x[n/2+q];  SS = S + S',  SD = S - S'
+//                      D[q] = x[q] - x[n-1-q],  D[n/2-1-q] = x[n/2-1-q] - x[n/2+q]
+//   inverse, q < n/4:  EE[q] = c[4q],  EO[q] = c[4q+2],  O[2q] = c[4q+1],  O[2q+1] = c[4q+3]
+// Q1, Q2: kq = half_basis_kpad(n/2) wide; P: kp = half_basis_kpad(n) wide; k-blocked, zero padded.
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep4_rows_kernel(const float* __restrict__ X, T* __restrict__ Q1,
+                                                             T* __restrict__ Q2, T* __restrict__ P,
+                                                             unsigned rows, unsigned W, unsigned Kq, unsigned Kp,
+                                                             unsigned tiles_q) {
+    const unsigned Nh = W / 2, Nq = W / 4;
+    const unsigned q = (blockIdx.x % tiles_q) * 32 + (threadIdx.x & 7) * 4;
+    const unsigned row = (blockIdx.x / tiles_q) * 32 + (threadIdx.x >> 3);
+    if (row >= rows || q >= Kq) return;
+    vec4_t<T> a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    if (q < Nq) {                                                 // Nq % 4 == 0
+        const float* x = X + (size_t)row * W;
+        if (!INVERSE) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(x + q);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(x + (Nh - 4 - q));
+            const f32x4 c = *reinterpret_cast<const f32x4*>(x + (Nh + q));
+            const f32x4 d = *reinterpret_cast<const f32x4*>(x + (W - 4 - q));
+            vec4_t<T> dn, dm;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const T s1 = (T)a[e] + (T)d[3 - e], s2 = (T)b[3 - e] + (T)c[e];
+                a1[e] = s1 + s2;
+                a2[e] = s1 - s2;
+                dn[e] = (T)a[e] - (T)d[3 - e];
+                dm[3 - e] = (T)b[3 - e] - (T)c[e];
+            }
+            *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(row, q, rows)) = dn;
+            *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(row, Nh - 4 - q, rows)) = dm;
+        } else {
+            f32x4 c[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) c[e] = *reinterpret_cast<const f32x4*>(x + 4 * (q + e));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a1[e] = (T)c[e][0]; a2[e] = (T)c[e][2]; }
+            T* o = P + blk_index<T>(row, 2 * q, rows);           // 2 q is a multiple of 8: one whole k-block piece
+            *reinterpret_cast<vec4_t<T>*>(o) = (vec4_t<T>){(T)c[0][1], (T)c[0][3], (T)c[1][1], (T)c[1][3]};
+            *reinterpret_cast<vec4_t<T>*>(o + 4) = (vec4_t<T>){(T)c[2][1], (T)c[2][3], (T)c[3][1], (T)c[3][3]};
+        }
+    }
+    *reinterpret_cast<vec4_t<T>*>(Q1 + blk_index<T>(row, q, rows)) = a1;
+    *reinterpret_cast<vec4_t<T>*>(Q2 + blk_index<T>(row, q, rows)) = a2;
+    if (q == 0)
+        for (unsigned z = Nh; z < Kp; z += 4) *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(row, z, rows)) = (vec4_t<T>){0, 0, 0, 0};
+}
+
+// Column pass: lines = (frame, column); block tile 32 q x 32 columns, transposed through LDS and
+// written as 2 KB runs (32 lines x one 64-byte k-block piece).
+template <typename T, bool INVERSE>
+__global__ __launch_bounds__(256) void pair_prep4_cols_kernel(const float* __restrict__ IN, T* __restrict__ Q1,
+                                                             T* __restrict__ Q2, T* __restrict__ P,
+                                                             unsigned W, unsigned H, unsigned Kq, unsigned Kp,
+                                                             unsigned n_frames, unsigned tiles_q, unsigned tiles_c) {
+    __shared__ T sA[32][33], sB[32][33], sC[32][33], sD[32][33];
+    const unsigned Hh = H / 2, Hq = H / 4;
+    const unsigned z = blockIdx.x / (tiles_q * tiles_c);
+    const unsigned tt = blockIdx.x % (tiles_q * tiles_c);
+    const unsigned q0 = (tt % tiles_q) * 32, c0 = (tt / tiles_q) * 32;
+    const float* __restrict__ Pz = IN + (size_t)z * H * W;
+    const unsigned tid = threadIdx.x;
+    {
+        const unsigned qr = tid >> 3, cq = (tid & 7) * 4, q = q0 + qr;
+        unsigned c = c0 + cq;
+        c = c + 4 <= W ? c : W - 4;                               // W % 4 == 0; duplicates are never written out
+        f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = a, cc = a, d = a;
+        if (q < Hq) {
+            const unsigned ra = INVERSE ? 4 * q : q, rb = INVERSE ? 4 * q + 2 : Hh - 1 - q;
+            const unsigned rc = INVERSE ? 4 * q + 1 : Hh + q, rd = INVERSE ? 4 * q + 3 : H - 1 - q;
+            a = *reinterpret_cast<const f32x4*>(Pz + (size_t)ra * W + c);
+            b = *reinterpret_cast<const f32x4*>(Pz + (size_t)rb * W + c);
+            cc = *reinterpret_cast<const f32x4*>(Pz + (size_t)rc * W + c);
+            d = *reinterpret_cast<const f32x4*>(Pz + (size_t)rd * W + c);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (!INVERSE) {
+                const T s1 = (T)a[e] + (T)d[e], s2 = (T)b[e] + (T)cc[e];
+                sA[cq + e][qr] = s1 + s2;
+                sB[cq + e][qr] = s1 - s2;
+                sC[cq + e][qr] = (T)a[e] - (T)d[e];        // D[q]
+                sD[cq + e][qr] = (T)b[e] - (T)cc[e];       // D[H/2-1-q]
+            } else {
+                sA[cq + e][qr] = (T)a[e];                        // EE[q]
+                sB[cq + e][qr] = (T)b[e];                        // EO[q]
+                sC[cq + e][qr] = (T)cc[e];                       // O[2q]
+                sD[cq + e][qr] = (T)d[e];                        // O[2q+1]
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const unsigned cl = tid & 31, kq = (tid >> 5) * 4;         // 4 consecutive q of one column per thread
+        const unsigned c = c0 + cl, q = q0 + kq;
+        if (c < W && q < Kq) {
+            const size_t line = (size_t)z * W + c, lines = (size_t)n_frames * W;
+            *reinterpret_cast<vec4_t<T>*>(Q1 + blk_index<T>(line, q, lines)) = (vec4_t<T>){sA[cl][kq], sA[cl][kq + 1], sA[cl][kq + 2], sA[cl][kq + 3]};
+            *reinterpret_cast<vec4_t<T>*>(Q2 + blk_index<T>(line, q, lines)) = (vec4_t<T>){sB[cl][kq], sB[cl][kq + 1], sB[cl][kq + 2], sB[cl][kq + 3]};
+            if (q < Hq) {
+                if (!INVERSE) {
+                    *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, q, lines)) = (vec4_t<T>){sC[cl][kq], sC[cl][kq + 1], sC[cl][kq + 2], sC[cl][kq + 3]};
+                    *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, Hh - 4 - q, lines)) = (vec4_t<T>){sD[cl][kq + 3], sD[cl][kq + 2], sD[cl][kq + 1], sD[cl][kq]};
+                } else {
+                    T* o = P + blk_index<T>(line, 2 * q, lines);
+                    *reinterpret_cast<vec4_t<T>*>(o) = (vec4_t<T>){sC[cl][kq], sD[cl][kq], sC[cl][kq + 1], sD[cl][kq + 1]};
+                    *reinterpret_cast<vec4_t<T>*>(o + 4) = (vec4_t<T>){sC[cl][kq + 2], sD[cl][kq + 2], sC[cl][kq + 3], sD[cl][kq + 3]};
+                }
+            }
+            if (q == 0)
+                for (unsigned zz = Hh; zz < Kp; zz += 4) *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, zz, lines)) = (vec4_t<T>){0, 0, 0, 0};
+        }
+    }
+}
+// ---------------------------------------------------------------------------------------------
+// Launchers
+// ---------------------------------------------------------------------------------------------
+size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h) {
+    const size_t a = n_frames * h * dct_pair_kpad(f64, w), b = n_frames * w * dct_pair_kpad(f64, h);
+    return a > b ? a : b;
+}
+
+bool dct_pair_can_run(bool f64, size_t n_frames, size_t w, size_t h, const float* in, const float* out) {
+    // an operand plane must stay below 4 GB (32-bit scalar offsets walk its k-blocks)
+    return dct_rows_can_fold(w, in, out) && dct_cols_can_fold(w, h, in, out) && w % 8 == 0 && h % 8 == 0 &&
+           dct_pair_operand_elems(f64, n_frames, w, h) * (f64 ? 8 : 4) <= 0xFFFFFFFFull;
+}
+// second level along an axis of length len: quarter length a multiple of 4, at least one k-step pair
+bool dct_pair_can_fold2(size_t len) { return len % 16 == 0 && len >= 64; }
+
+template <typename T>
+static int prep_impl(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w, size_t h,
+                     T* o1, T* o2) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if (is_row) {
+        const unsigned Kp = (unsigned)pair_kpad<T>(w), tiles_k = (Kp + 31) / 32;
+        const size_t rows = n_frames * h;
+        const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_k;
+        if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+        if (inverse) pair_prep_rows_kernel<T, true><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)rows, (unsigned)w, Kp, tiles_k);
+        else         pair_prep_rows_kernel<T, false><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)rows, (unsigned)w, Kp, tiles_k);
+    } else {
+        const unsigned Kp = (unsigned)pair_kpad<T>(h);
+        const unsigned tiles_k = (Kp + 31) / 32, tiles_c = (unsigned)((w + 63) / 64);
+        const unsigned long long nblk = (unsigned long long)tiles_k * tiles_c * n_frames;
+        if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+        if (inverse) pair_prep_cols_kernel<T, true><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)w, (unsigned)h, Kp, (unsigned)n_frames, tiles_k, tiles_c);
+        else         pair_prep_cols_kernel<T, false><<<(unsigned)nblk, 256, 0, st>>>(in, o1, o2, (unsigned)w, (unsigned)h, Kp, (unsigned)n_frames, tiles_k, tiles_c);
+    }
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+template <typename T>
+static int prep4_impl(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w, size_t h,
+                      T* q1, T* q2, T* p) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const size_t len = is_row ? w : h;
+    const unsigned Kp = (unsigned)pair_kpad<T>(len), Kq = (unsigned)pair_kpad<T>(len / 2);
+    const unsigned tiles_q = (Kq + 31) / 32;
+    if (is_row) {
+        const size_t rows = n_frames * h;
+        const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_q;
+        if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+        if (inverse) pair_prep4_rows_kernel<T, true><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)rows, (unsigned)w, Kq, Kp, tiles_q);
+        else         pair_prep4_rows_kernel<T, false><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)rows, (unsigned)w, Kq, Kp, tiles_q);
+    } else {
+        const unsigned tiles_c = (unsigned)((w + 31) / 32);
+        const unsigned long long nblk = (unsigned long long)tiles_q * tiles_c * n_frames;
+        if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+        if (inverse) pair_prep4_cols_kernel<T, true><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)w, (unsigned)h, Kq, Kp, (unsigned)n_frames, tiles_q, tiles_c);
+        else         pair_prep4_cols_kernel<T, false><<<(unsigned)nblk, 256, 0, st>>>(in, q1, q2, p, (unsigned)w, (unsigned)h, Kq, Kp, (unsigned)n_frames, tiles_q, tiles_c);
+    }
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+int launch_dct_pair_prep(hipStream_t st, bool f64, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
+                         size_t h, void* o1, void* o2) {
+    return f64 ? prep_impl<double>(st, is_row, inverse, in, n_frames, w, h, (double*)o1, (double*)o2)
+               : prep_impl<float>(st, is_row, inverse, in, n_frames, w, h, (float*)o1, (float*)o2);
+}
+
+int launch_dct_pair_prep4(hipStream_t st, bool f64, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
+                          size_t h, void* q1, void* q2, void* p) {
+    return f64 ? prep4_impl<double>(st, is_row, inverse, in, n_frames, w, h, (double*)q1, (double*)q2, (double*)p)
+               : prep4_impl<float>(st, is_row, inverse, in, n_frames, w, h, (float*)q1, (float*)q2, (float*)p);
+}
+
+}  // namespace ssw

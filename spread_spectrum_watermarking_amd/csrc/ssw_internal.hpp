@@ -86,19 +86,26 @@ bool dct_rows_can_fold2(size_t w, const float* in, const float* out);
 int launch_dct_rows_fold2_fwd_f64(hipStream_t st, const float* in, float* out, size_t rows, size_t w,
                                   const double* b_odd, const double* b_even_even, const double* b_even_odd, Epilogue ep);
 
-// dct_pair_f64.hip: operand-ready folded f64 GEMMs (no VALU work in the MFMA loop) + their pre-passes
-bool dct_pair_can_run(size_t n_frames, size_t w, size_t h, const float* in, const float* out);
-int launch_make_half_basis_blocked_f64(hipStream_t st, size_t n, bool inverse, int parity, double* out);   // [Kp/8][n/2][8]
-size_t dct_pair_operand_elems(size_t n_frames, size_t w, size_t h);   // doubles per operand plane
-int launch_dct_pair_prep_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
-                             size_t h, double* o1, double* o2);
+// dct_pair_prep.hip / dct_pair_f64.hip / dct_pair_f32.hip: "operand-ready" folded GEMMs (no VALU work in
+// the MFMA loop): pre-passes write the folded operands once per pass as k-blocked planes in the GEMM's
+// precision (f64 flag), the half bases are cached in the same layout.
+size_t dct_pair_kpad(bool f64, size_t n);                               // row stride of operands / bases of a length-n axis
+size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h);   // elements per operand plane
+bool dct_pair_can_run(bool f64, size_t n_frames, size_t w, size_t h, const float* in, const float* out);
 bool dct_pair_can_fold2(size_t len);
-// f32 plane -> (SS, SD | EE, EO) [lines][kpad(len/2)] and (D | O) [lines][kpad(len)] in one sweep
-int launch_dct_pair_prep4_f64(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
-                              size_t h, double* q1, double* q2, double* p);
+int launch_make_half_basis_blocked(hipStream_t st, bool f64, size_t n, bool inverse, int parity, void* out);
+// one level: (S, D) forward / (E, O) inverse
+int launch_dct_pair_prep(hipStream_t st, bool f64, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
+                         size_t h, void* o1, void* o2);
+// two levels: (SS, SD | EE, EO) [kpad(len/2) wide] and (D | O) [kpad(len) wide] in one sweep
+int launch_dct_pair_prep4(hipStream_t st, bool f64, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
+                          size_t h, void* q1, void* q2, void* p);
 // kind 0: one folding level; 1 / 2: the even / odd half of two levels (see dct_pair_f64.hip)
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
+                             size_t h, Epilogue ep);
+int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, const float* x1, const float* x2,
+                             const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep);
 
 // select.hip
@@ -159,7 +166,7 @@ struct ssw_ctx {
     size_t chunk_frames = 16;
 
     // basis cache: (N, inverse, f64, kind) -> device pointer; kind 0 = dense N x N,
-    // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded kernels; 3 / 4 = the same, k-blocked (f64 operand-ready GEMMs)
+    // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded kernels; 3 / 4 = the same, k-blocked (operand-ready GEMMs)
     std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
     bool fold = true;             // use the even/odd-folded GEMMs where the shape allows
     int fold_level = SSW_DCT_FOLDING_DEFAULT;           // 2 (opt-in): also fold the even half once more where a kernel exists (f64 forward rows)
@@ -171,7 +178,7 @@ struct ssw_ctx {
         size_t bytes = 0;
     };
     Buf plane[4];                 // y / i / q / t planes of the current chunk
-    Buf operand[5];               // f64 operand planes of the operand-ready GEMMs (fold_level 3 / 4): S|E, D|O, SS|EE, SD|EO, T
+    Buf operand[5];               // operand planes of the operand-ready GEMMs (fold_level 3 / 4): S|E, D|O, SS|EE, SD|EO, T
     Buf idx;                      // [chunk][k] u32
     ssw::SelectWorkspace sel;
     Buf small;                    // misc (mark offsets, sims, ...)

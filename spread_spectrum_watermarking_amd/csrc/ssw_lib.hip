@@ -114,9 +114,9 @@ int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const vo
     auto it = ctx->basis.find(key);
     if (it != ctx->basis.end()) { *out = it->second; return SSW_OK; }
     void* p = nullptr;
-    const size_t elems = kind == 0 ? n * dense_basis_kpad(n) : (n / 2) * half_basis_kpad(n);
+    const size_t elems = kind == 0 ? n * dense_basis_kpad(n) : kind >= 3 ? (n / 2) * dct_pair_kpad(f64, n) : (n / 2) * half_basis_kpad(n);
     SSW_HIP_CHECK(hipMalloc(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float))));
-    int rc = kind >= 3 ? launch_make_half_basis_blocked_f64(ctx->stream, n, inverse, kind - 3, (double*)p)
+    int rc = kind >= 3 ? launch_make_half_basis_blocked(ctx->stream, f64, n, inverse, kind - 3, p)
              : kind != 0 ? (f64 ? launch_make_half_basis_f64(ctx->stream, n, inverse, kind - 1, (double*)p)
                               : launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p))
              : f64     ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
@@ -159,10 +159,10 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         const bool fold = ctx->fold && (is_row ? dct_rows_can_fold(w, src, dst) : dct_cols_can_fold(w, h, src, dst));
         const size_t len = is_row ? w : h;
         const void *b0 = nullptr, *b1 = nullptr;
-        const bool operand = fold && f64 && ctx->fold_level >= 3 && dct_pair_can_run(n, w, h, src, dst);
+        const bool operand = fold && ctx->fold_level >= 3 && dct_pair_can_run(f64, n, w, h, src, dst);
         if (operand) {
-            SSW_TRY(get_basis(ctx, len, inverse, true, 3, &b0));       // k-blocked half bases
-            SSW_TRY(get_basis(ctx, len, inverse, true, 4, &b1));
+            SSW_TRY(get_basis(ctx, len, inverse, f64, 3, &b0));        // k-blocked half bases
+            SSW_TRY(get_basis(ctx, len, inverse, f64, 4, &b1));
         } else if (fold) {
             SSW_TRY(get_basis(ctx, len, inverse, f64, 1, &b0));
             SSW_TRY(get_basis(ctx, len, inverse, f64, 2, &b1));
@@ -170,44 +170,49 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
             SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
         }
         if (operand) {
-            const size_t elems = dct_pair_operand_elems(n, w, h);
+            const size_t esz = f64 ? sizeof(double) : sizeof(float);
+            const size_t bytes = dct_pair_operand_elems(f64, n, w, h) * esz;
             const bool two = ctx->fold_level >= 4 && dct_pair_can_fold2(len);
             const int st_pass = is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL;
             const int st_main = is_row ? SSW_STAGE_DCT_ROW_MAIN : SSW_STAGE_DCT_COL_MAIN;
+            auto gemm = [&](int kind, const void* x1, const void* x2, const void* y1, const void* y2, void* tmpE) {
+                return f64 ? launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, kind, (const double*)x1, (const double*)x2,
+                                                      (const double*)y1, (const double*)y2, dst, (double*)tmpE, n, w, h, ep)
+                           : launch_dct_pair_gemm_f32(ctx->stream, is_row, inverse, kind, (const float*)x1, (const float*)x2,
+                                                      (const float*)y1, (const float*)y2, dst, (float*)tmpE, n, w, h, ep);
+            };
             if (!two) {
-                for (int b = 0; b < 2; ++b) SSW_TRY(grow(ctx->operand[b], elems * sizeof(double)));
-                double* x1 = (double*)ctx->operand[0].p;
-                double* x2 = (double*)ctx->operand[1].p;
+                for (int b = 0; b < 2; ++b) SSW_TRY(grow(ctx->operand[b], bytes));
+                void* x1 = ctx->operand[0].p;
+                void* x2 = ctx->operand[1].p;
                 {
                     StageTimer t(ctx, SSW_STAGE_DCT_PREP);
-                    SSW_TRY(launch_dct_pair_prep_f64(ctx->stream, is_row, inverse, src, n, w, h, x1, x2));
+                    SSW_TRY(launch_dct_pair_prep(ctx->stream, f64, is_row, inverse, src, n, w, h, x1, x2));
                 }
                 StageTimer t(ctx, st_pass);
                 StageTimer tm(ctx, st_main);
-                SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 0, x1, x2, (const double*)b0, (const double*)b1,
-                                                 dst, nullptr, n, w, h, ep));
+                SSW_TRY(gemm(0, x1, x2, b0, b1, nullptr));
             } else {
-                for (int b = 1; b < (inverse ? 5 : 4); ++b) SSW_TRY(grow(ctx->operand[b], elems * sizeof(double)));
-                double* x2 = (double*)ctx->operand[1].p;      // D | O
-                double* xx1 = (double*)ctx->operand[2].p;     // SS | EE
-                double* xx2 = (double*)ctx->operand[3].p;     // SD | EO
-                double* tmpE = (double*)ctx->operand[4].p;    // inverse: the even half E in f64
+                for (int b = 1; b < (inverse ? 5 : 4); ++b) SSW_TRY(grow(ctx->operand[b], bytes));
+                void* x2 = ctx->operand[1].p;       // D | O
+                void* xx1 = ctx->operand[2].p;      // SS | EE
+                void* xx2 = ctx->operand[3].p;      // SD | EO
+                void* tmpE = ctx->operand[4].p;     // inverse: the even half E, unrounded
                 const void *q0 = nullptr, *q1 = nullptr;
-                SSW_TRY(get_basis(ctx, len / 2, inverse, true, 3, &q0));
-                SSW_TRY(get_basis(ctx, len / 2, inverse, true, 4, &q1));
+                SSW_TRY(get_basis(ctx, len / 2, inverse, f64, 3, &q0));
+                SSW_TRY(get_basis(ctx, len / 2, inverse, f64, 4, &q1));
                 {
                     StageTimer t(ctx, SSW_STAGE_DCT_PREP);
-                    SSW_TRY(launch_dct_pair_prep4_f64(ctx->stream, is_row, inverse, src, n, w, h, xx1, xx2, x2));
+                    SSW_TRY(launch_dct_pair_prep4(ctx->stream, f64, is_row, inverse, src, n, w, h, xx1, xx2, x2));
                 }
                 StageTimer t(ctx, st_pass);
                 // even half: a half-length transform of S (forward) / of the even coefficients (inverse), folded again
-                SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 1, xx1, xx2, (const double*)q0, (const double*)q1,
-                                                 dst, tmpE, n, w, h, ep));
-                // odd half: full half-length sum, the odd basis split into two row blocks
-                const double* bo = (const double*)b1;
+                SSW_TRY(gemm(1, xx1, xx2, q0, q1, tmpE));
+                // odd half: full half-length sum, the odd basis split into two row blocks (second block:
+                // len/4 lines further inside every k-block of the same plane = 64 bytes per line)
+                const char* bo2 = (const char*)b1 + (len / 4) * 64;
                 StageTimer tm(ctx, st_main);
-                SSW_TRY(launch_dct_pair_gemm_f64(ctx->stream, is_row, inverse, 2, x2, x2, bo, bo + (len / 4) * 8,
-                                                 dst, tmpE, n, w, h, ep));
+                SSW_TRY(gemm(2, x2, x2, b1, bo2, tmpE));
             }
         } else if (is_row && fold && f64 && !inverse && ctx->fold_level == 2 && dct_rows_can_fold2(w, src, dst)) {
             const void *bee = nullptr, *beo = nullptr;

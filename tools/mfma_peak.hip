@@ -87,6 +87,29 @@ __global__ __launch_bounds__(256, 2) void f32_loop(float* out, const float* in, 
     out[blockIdx.x * 256 + lane] = s;
 }
 
+// f32 MFMA with one extra VALU instruction per MFMA: 0 none, 1 v_add_f32, 2 v_mov_b32, 3 two v_add_f32
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void f32_mix(float* out, const float* in, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0;
+    const int lane = threadIdx.x;
+    float a = in[lane & 63], b = in[(lane + 7) & 63];
+    float f0 = in[lane & 31], f1 = in[(lane + 5) & 31]; int i0 = lane, i1 = lane * 3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (KIND == 1) asm volatile("v_add_f32 %0, %1, %2" : "=v"(f0) : "v"(f1), "v"(f1));
+            if (KIND == 2) asm volatile("v_mov_b32 %0, %1" : "=v"(i0) : "v"(i1));
+            if (KIND == 3) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(f0) : "v"(f1), "v"(f1));
+                             asm volatile("v_add_f32 %0, %1, %2" : "=v"(f0) : "v"(f1), "v"(f1)); }
+            acc[j & 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j & 3], 0, 0, 0);
+        }
+    }
+    float s = f0 + i0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) s += acc[i][j];
+    out[blockIdx.x * 256 + lane] = s;
+}
+
 int main() {
     float* in; double* out;
     CK(hipMalloc(&in, 4096 * 4)); CK(hipMalloc(&out, 4096 * 256 * 8));
@@ -136,6 +159,24 @@ int main() {
         }
         const double flop = (double)grid * 4 * iters * 16 * 2048.0;
         printf("f64 mfma + 1x %-14s per mfma, 2 blocks/CU: %.3f ms  %.1f TFLOP/s\n", kinds[kind], best, flop / best / 1e9);
+    }
+    const char* fk[4] = {"nothing", "v_add_f32", "v_mov_b32", "2x v_add_f32"};
+    for (int kind = 0; kind < 4; ++kind) {
+        const int grid = 512; float best = 1e30f;
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipEventRecord(e0));
+            switch (kind) {
+                case 0: f32_mix<0><<<grid, 256>>>((float*)out, in, iters); break;
+                case 1: f32_mix<1><<<grid, 256>>>((float*)out, in, iters); break;
+                case 2: f32_mix<2><<<grid, 256>>>((float*)out, in, iters); break;
+                default: f32_mix<3><<<grid, 256>>>((float*)out, in, iters); break;
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best) best = ms;
+        }
+        const double flop = (double)grid * 4 * iters * 16 * 4096.0;
+        printf("f32 32x32x2 mfma + 1x %-12s per mfma, 2 blocks/CU: %.3f ms  %.1f TFLOP/s\n", fk[kind], best, flop / best / 1e9);
     }
     return 0;
 }
