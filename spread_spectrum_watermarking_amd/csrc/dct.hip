@@ -573,7 +573,7 @@ int launch_gemm_nt_f32(hipStream_t st, const float* A, size_t M, const float* B,
     const unsigned tiles_m = (m + BM - 1) / BM, tiles_n = (n + BN - 1) / BN;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const Epilogue ep{0, 0.f, 0.f, 0.f};
+    const Epilogue ep{1.f, 1.f};
     // aligned instance: unpredicated 16-B loads, needs K to be a whole number of k-tiles (row stride = K)
     const bool al = (k % BK == 0) && aligned16(A) && aligned16(B);
     if (al) dct_rows_f32_kernel<true><<<(unsigned)nblk, THREADS, 0, st>>>(A, B, out, m, n, k, k, tiles_m, tiles_n, ep);

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
 
     // C/D map of 32x32x2 f32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const unsigned n = po.n, W = po.W, H = po.H;
-    auto emit = [&](float* lp, float* tp, size_t es, unsigned pair, float a1, float a2) {
+    // element offsets idx * es stay below 2^32 (W * H < 2^32: indices are u32 throughout)
+    auto emit = [&](float* lp, float* tp, unsigned es, unsigned pair, float a1, float a2) {
         if (EPI == EPI_FWD || EPI == EPI_FWD_ADJ) {
             const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
             if (EPI == EPI_FWD_ADJ) {

@@ -221,7 +221,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     // D map of 16x16x4 f64: col = lane & 15, row = (lane >> 4) + 4 reg
     const unsigned n = po.n, W = po.W, H = po.H;
     // one output line: element idx of the transformed axis lives at lp[idx * es] (and tp[idx * es] in T)
-    auto emit = [&](float* lp, double* tp, size_t es, unsigned pair, double a1, double a2) {
+    // element offsets idx * es stay below 2^32 (W * H < 2^32: indices are u32 throughout)
+    auto emit = [&](float* lp, double* tp, unsigned es, unsigned pair, double a1, double a2) {
         if (EPI == EPI_FWD || EPI == EPI_FWD_ADJ) {
             const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
             if (EPI == EPI_FWD_ADJ) {

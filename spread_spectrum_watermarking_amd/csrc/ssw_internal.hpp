@@ -51,10 +51,8 @@ size_t dense_basis_kpad(size_t n);   // row stride of a dense basis: N rounded u
 int launch_make_basis_f32(hipStream_t st, size_t n, bool inverse, float* out);
 int launch_make_basis_f64(hipStream_t st, size_t n, bool inverse, double* out);
 
-struct Epilogue {
-    int mode;        // 0: store acc; 1: orthogonal scale by output index; 2: multiply by corr
-    float s0, sn;    // mode 1
-    float corr;      // mode 2
+struct Epilogue {    // stored value = f32(acc) * (output index == 0 ? first : base); both 1 = plain store
+    float first, base;
 };
 // Row pass: out[r][v] = sum_c in[r][c] * basis[v][c]   for rows = n_frames*h rows of width w.
 int launch_dct_rows(hipStream_t st, int precision, const float* in, float* out, size_t rows, size_t w,

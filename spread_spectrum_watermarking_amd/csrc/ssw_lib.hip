@@ -144,13 +144,13 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
     const bool inverse = (type == SSW_DCT3);
     const bool f64 = (precision == SSW_PRECISION_F64);
     const bool rows_first = (w >= h);                                  // src/dct2d.rs:93-98
-    Epilogue plain{0, 0.f, 0.f, 0.f};
+    Epilogue plain{1.f, 1.f};
     auto ortho = [&](size_t len) {                                      // src/dct2d.rs:154-155
-        Epilogue e{1, std::sqrt(1.0f / (4.0f * (float)len)), std::sqrt(1.0f / (2.0f * (float)len)), 0.f};
+        Epilogue e{std::sqrt(1.0f / (4.0f * (float)len)), std::sqrt(1.0f / (2.0f * (float)len))};
         return e;
     };
     Epilogue last = plain;
-    if (type == SSW_DCT3) { last.mode = 2; last.corr = (float)4 / (float)(w * h); }   // :213-217
+    if (type == SSW_DCT3) last.first = last.base = (float)4 / (float)(w * h);           // :213-217
     for (int pass = 0; pass < 2; ++pass) {
         const bool is_row = (pass == 0) ? rows_first : !rows_first;
         const float* src = (pass == 0) ? data : tmp;
