@@ -43,7 +43,6 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
     const unsigned m0 = tm * BM, p0 = tn * BN;
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
-    const unsigned wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
     const unsigned lr = lane & 31, lh = lane >> 5;
 
     // staging: line = tid / 4 (+ 64 q), 16-byte chunk = tid % 4
@@ -63,12 +62,6 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
     const __amdgpu_buffer_rsrc_t y1r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y1g + (size_t)p0 * 16), 0, 0xFFFFFFFFu, 0x00020000);
     const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y2g + (size_t)p0 * 16), 0, 0xFFFFFFFFu, 0x00020000);
     const unsigned xstep = L * 64u, ystep = yrows * 64u;
-
-    f32x16 acc1[2], acc2[2], tot1[2], tot2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc1[i][r] = 0.f; acc2[i][r] = 0.f; tot1[i][r] = 0.f; tot2[i][r] = 0.f; }
 
     u32x4 rx1[XQ], rx2[XQ], ry1, ry2;
     auto gload = [&](unsigned t) {
@@ -92,6 +85,18 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
         *reinterpret_cast<u32x4*>(&sY[buf][0][st]) = ry1;
         *reinterpret_cast<u32x4*>(&sY[buf][1][st]) = ry2;
     };
+    // The wave grid is 2 x 2 (each wave 64 lines x 32 pairs: NI = 2 line tiles) unless the tile holds at
+    // most 32 valid pairs, where it is 4 x 1 (each wave 32 lines x 32 pairs: NI = 1) and the tile takes
+    // half the MFMAs instead of computing padding.
+    auto run = [&](auto nic) {
+    constexpr int NI = decltype(nic)::value;
+    const unsigned wm = NI == 2 ? (wave >> 1) * 64 : wave * 32, wn = NI == 2 ? (wave & 1) * 32 : 0;
+    f32x16 acc1[NI], acc2[NI], tot1[NI], tot2[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc1[i][r] = 0.f; acc2[i][r] = 0.f; tot1[i][r] = 0.f; tot2[i][r] = 0.f; }
+
     const unsigned fsw = (lr >> 2) & 3;
     unsigned rdx[2], rdy[2];
 #pragma unroll
@@ -99,14 +104,14 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
         rdx[sh] = (wm + lr) * QBK + 4 * ((2 * sh + lh) ^ fsw);
         rdy[sh] = (wn + lr) * QBK + 4 * ((2 * sh + lh) ^ fsw);
     }
-    struct Frag { f32x4 x1[2], x2[2], y1, y2; };
+    struct Frag { f32x4 x1[NI], x2[NI], y1, y2; };
     auto fread = [&](auto bufc, auto shc, Frag& f) {
         constexpr int cur = decltype(bufc)::value;
         constexpr int sh = decltype(shc)::value;
         f.y1 = *reinterpret_cast<const f32x4*>(&sY[cur][0][rdy[sh]]);
         f.y2 = *reinterpret_cast<const f32x4*>(&sY[cur][1][rdy[sh]]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             f.x1[i] = *reinterpret_cast<const f32x4*>(&sX[cur][0][rdx[sh] + 32 * i * QBK]);
             if (!SAMEX) f.x2[i] = *reinterpret_cast<const f32x4*>(&sX[cur][NX - 1][rdx[sh] + 32 * i * QBK]);
         }
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 const float xa = f.x1[i][j], xb = SAMEX ? f.x1[i][j] : f.x2[i][j];
                 if (!COLS) {      // D[row = line][col = pair]
                     acc1[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa, f.y1[j], acc1[i], 0, 0, 0);
@@ -132,7 +137,8 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
     // Same half-step-shifted software pipeline as the f64 kernel: 16 MFMAs per half-step; the next
     // half-step's fragments are read one ds_read_b128 per MFMA behind the first MFMAs, the staged tile is
     // written one ds_write_b128 per MFMA in the second half of a step, its loads issued a step earlier.
-    constexpr int NRD = 2 + (SAMEX ? 2 : 4);                    // LDS reads per half-step
+    constexpr int NMF = 8 * NI;                                 // MFMAs per half-step
+    constexpr int NRD = 2 + NI * NX;                            // LDS reads per half-step
     constexpr int NLD = XQ * NX + 2;                            // staged 16-byte loads (= LDS writes) per thread
     auto interleave = [&](auto storec) {
         constexpr bool STORE = decltype(storec)::value != 0;
@@ -147,10 +153,10 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 16 - NRD - NLD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD - NLD > 0 ? NMF - NRD - NLD : 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 16 - NRD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
         step(B1{}, B0{}, t + 1);
         if (((t + 2) & (QCHUNK - 1)) == 0) {   // every MFMA of steps <= t + 1 has been issued
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NI; ++i) {
                 tot1[i] += acc1[i]; tot2[i] += acc2[i];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc1[i][r] = 0.f; acc2[i][r] = 0.f; }
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
     interleave(B0{});
     fmma(fb);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { acc1[i] = tot1[i] + acc1[i]; acc2[i] = tot2[i] + acc2[i]; }
+    for (int i = 0; i < NI; ++i) { acc1[i] = tot1[i] + acc1[i]; acc2[i] = tot2[i] + acc2[i]; }
 
     // C/D map of 32x32x2 f32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
     const unsigned n = po.n, W = po.W, H = po.H;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
         const unsigned pair = p0 + wn + lr;
         if (pair < NP) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const unsigned line = m0 + wm + 32 * i + lr;       // = frame * W + column
             if (line >= L) continue;
             const unsigned z = line / W, col = line - z * W;
@@ -257,6 +263,9 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
             }
         }
     }
+    };
+    if (NP - p0 <= 32) run(std::integral_constant<int, 1>{});
+    else               run(std::integral_constant<int, 2>{});
 }
 
 // kind: 0 one folding level; 1 / 2 the even / odd half of two levels (see launch_dct_pair_gemm_f64)

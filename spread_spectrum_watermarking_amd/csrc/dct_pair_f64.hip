@@ -54,7 +54,6 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     const unsigned m0 = tm * BM, p0 = tn * BN;
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
-    const unsigned wm = (wave >> 1) * 64, wn = (wave & 1) * 32;
     const unsigned li = lane & 15, lq = lane >> 4;
 
     // LDS tile rows hold 8 consecutive k (64 bytes); double k of row r sits at position
@@ -80,12 +79,6 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     const __amdgpu_buffer_rsrc_t y1r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y1g + (size_t)p0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
     const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y2g + (size_t)p0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
     const unsigned xstep = L * 64u, ystep = yrows * 64u;
-
-    f64x4 acc1[4][2], acc2[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) { acc1[i][j] = (f64x4){0, 0, 0, 0}; acc2[i][j] = (f64x4){0, 0, 0, 0}; }
 
     u32x4 rx1[XQ], rx2[XQ], ry1, ry2;
     auto gload = [&](unsigned t) {
@@ -113,6 +106,18 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         put(&sY[buf][0][0], ry1);
         put(&sY[buf][1][0], ry2);
     };
+    // The wave grid is 2 x 2 (each wave 64 lines x 32 pairs: NI = 4 line tiles) unless the tile holds at
+    // most 32 valid pairs -- the last tile column of e.g. 540 pairs -- where it is 4 x 1 (each wave
+    // 32 lines x 32 pairs: NI = 2) and the tile takes half the MFMAs instead of computing padding.
+    auto run = [&](auto nic) {
+    constexpr int NI = decltype(nic)::value;
+    const unsigned wm = NI == 4 ? (wave >> 1) * 64 : wave * 32, wn = NI == 4 ? (wave & 1) * 32 : 0;
+    f64x4 acc1[NI][2], acc2[NI][2];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc1[i][j] = (f64x4){0, 0, 0, 0}; acc2[i][j] = (f64x4){0, 0, 0, 0}; }
+
     // fragment of half-step s: lane group lq supplies k = 4 s + lq
     const unsigned fsw = (li >> 1) & 7;
     unsigned rdx[2], rdy[2];
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         rdx[sh] = (wm + li) * PBK + ((4 * sh + lq) ^ fsw);
         rdy[sh] = (wn + li) * PBK + ((4 * sh + lq) ^ fsw);
     }
-    struct Frag { double x1[4], x2[4], y1[2], y2[2]; };
+    struct Frag { double x1[NI], x2[NI], y1[2], y2[2]; };
     auto fread = [&](auto bufc, auto shc, Frag& f) {
         constexpr int cur = decltype(bufc)::value;
         constexpr int sh = decltype(shc)::value;
@@ -131,14 +136,14 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             f.y2[jn] = sY[cur][1][rdy[sh] + 16 * jn * PBK];
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             f.x1[i] = sX[cur][0][rdx[sh] + 16 * i * PBK];
             if (!SAMEX) f.x2[i] = sX[cur][NX - 1][rdx[sh] + 16 * i * PBK];
         }
     };
     auto fmma = [&](const Frag& f) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) {
                 const double xb = SAMEX ? f.x1[i] : f.x2[i];
@@ -169,8 +174,10 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     // wave at the LDS queue with its MFMAs behind it), then the staging writes two per MFMA
     auto interleave = [&](auto storec) {
         constexpr bool STORE = decltype(storec)::value != 0;
+        constexpr int NMF = 4 * NI;                             // MFMAs per half-step
+        constexpr int NRD = (4 + NI * NX) / 2;                  // ds_read2_b64 per half-step (fragments pair up)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < NRD; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
@@ -181,10 +188,10 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 10 - NLD, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD - NLD > 0 ? NMF - NRD - NLD : 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);
         } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             const unsigned pair = p0 + wn + 16 * jn + li;
             if (pair >= NP) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned row = m0 + wm + 16 * i + lq + 4 * r;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const unsigned line = m0 + wm + 16 * i + li;       // = frame * W + column
             if (line >= L) continue;
             const unsigned z = line / W, col = line - z * W;
@@ -279,6 +286,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 }
         }
     }
+    };
+    if (NP - p0 <= 32) run(std::integral_constant<int, 2>{});
+    else               run(std::integral_constant<int, 4>{});
 }
 
 
