@@ -186,6 +186,27 @@ def test_dct_operand_ready_path_matches(shape, dct_type, level):
     assert np.abs(three.astype(np.float64) - ref).max() <= 2e-7 * max(ac_max(ref), 1.0)
 
 
+@pytest.mark.parametrize("shape", [(24, 40), (72, 136), (136, 72), (80, 208), (144, 1040), (1080, 1920)])
+@pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
+@pytest.mark.parametrize("level", [1, 3, 4])
+def test_dct_f32_every_strategy_within_tolerance(shape, dct_type, level):
+    """f32 precision: in-kernel folding (1) and the operand-ready GEMMs with one (3) / two (4) folding
+    levels round differently (each folding level adds one rounding per operand sum) but all stay
+    inside the f32 bars of test_dct_f32_mfma_within_tolerance."""
+    rng = np.random.default_rng(shape[0] * 11 + shape[1])
+    x = rng.random((2,) + shape).astype(np.float32)
+    if dct_type == L.DCT3:
+        x = np.stack([O.dct2d(p, O.DCT2) for p in x])
+    G.ctx().set_dct_folding(level)
+    try:
+        got = G.dct2d(x, dct_type, F32)
+    finally:
+        G.ctx().set_dct_folding(True)
+    ref = np.stack([O.dct2d(p, dct_type, O.BACKEND_F64) for p in x])
+    scale = max(float(np.abs(ref).max()), 1e-30)
+    assert np.abs(got.astype(np.float64) - ref).max() <= (4e-6 if dct_type == L.DCT3 else 1e-6) * scale
+
+
 @pytest.mark.parametrize("precision", [F32, F64])
 def test_dct_batched_equals_single(precision):
     rng = np.random.default_rng(2)
