@@ -8,7 +8,7 @@
 //
 // Here the GEMM main loop contains no VALU instruction at all: global_load -> ds_write ->
 // ds_read -> MFMA, with scalar address arithmetic.  Its operands are produced once per pass by
-// HBM-bound pre-passes (this file) in exactly the form the MFMA consumes:
+// HBM-bound pre-passes (dct_pair_prep.hip) in exactly the form the MFMA consumes:
 //   forward:  S[s] = (double)x[s] + (double)x[N-1-s],  D[s] = (double)x[s] - (double)x[N-1-s]
 //   inverse:  E[s] = (double)c[2s],                    O[s] = (double)c[2s+1]
 // stored k-blocked: [Kp / 8][lines][8] doubles (zero padded to Kp), i.e. the 64-byte piece of every
@@ -23,7 +23,9 @@
 //
 // Block: 256 threads = 4 waves as 2 x 2; block tile 128 lines x 64 pairs x 2 products; k-step 8;
 // per wave 16 MFMA 16x16 tiles = 128 accumulator registers; LDS 48 KB double-buffered (XOR-swizzled
-// 64-byte rows, conflict-free ds_read_b128), one barrier per k-step, 2 blocks per CU.
+// 64-byte rows, conflict-free ds_read_b64 / ds_read2_b64), one barrier per k-step, 2 blocks per CU.
+// Lane l: li = l & 15 (line / pair inside a 16x16 tile), lq = l >> 4: in half-step s lane group lq
+// supplies k = 4 s + lq (the same assignment on both operands).
 #include "dct_pair_common.hpp"
 
 #include <type_traits>
