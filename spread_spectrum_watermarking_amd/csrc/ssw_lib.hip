@@ -144,6 +144,17 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
     const bool inverse = (type == SSW_DCT3);
     const bool f64 = (precision == SSW_PRECISION_F64);
     const bool rows_first = (w >= h);                                  // src/dct2d.rs:93-98
+    // The operand-ready GEMMs walk an operand plane with 32-bit scalar offsets: keep each call's planes
+    // below 4 GB by transforming the frames in groups (frames are independent).
+    if (ctx->fold && ctx->fold_level >= 3 && n > 1) {
+        const size_t per_frame = dct_pair_operand_elems(f64, 1, w, h) * (f64 ? sizeof(double) : sizeof(float));
+        const size_t max_frames = per_frame ? 0xFFFFFFFFull / per_frame : 0;
+        if (max_frames >= 1 && n > max_frames) {
+            for (size_t f0 = 0; f0 < n; f0 += max_frames)
+                SSW_TRY(dct2d_planes(ctx, type, precision, std::min(max_frames, n - f0), w, h, data + f0 * w * h, tmp + f0 * w * h));
+            return SSW_OK;
+        }
+    }
     Epilogue plain{1.f, 1.f};
     auto ortho = [&](size_t len) {                                      // src/dct2d.rs:154-155
         Epilogue e{std::sqrt(1.0f / (4.0f * (float)len)), std::sqrt(1.0f / (2.0f * (float)len))};
