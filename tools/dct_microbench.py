@@ -24,7 +24,11 @@ for _ in range(reps):
     buf = ctx.to_device(host)          # fresh finite data each time (the transform is in place and unnormalised)
     check(lib.ssw_dct2d(ctx.handle, typ, prec, n, W, H, buf.ptr), "dct")
 t = ctx.timing()
-fold = not os.environ.get("SSW_NO_FOLD")
-rf = 2.0 * n * H * W * W * reps / (2 if fold else 1); cf = 2.0 * n * W * H * H * reps / (2 if fold else 1)
+# executed fraction of the dense flop per axis (mirrors dct2d_planes): none 1, one folding level 1/2, two 3/8
+level = 0 if os.environ.get("SSW_NO_FOLD") else int(os.environ.get("SSW_FOLD_LEVEL", L.DCT_FOLDING_DEFAULT))
+def frac(length):
+    if level == 0 or length % 8: return 1.0
+    return 0.375 if (level >= 4 and length % 16 == 0 and length >= 64) else 0.5
+rf = 2.0 * n * H * W * W * reps * frac(W); cf = 2.0 * n * W * H * H * reps * frac(H)
 print("rows %.2f ms %.1f TF | cols %.2f ms %.1f TF (executed flop)" % (
     t["dct_row"]["ms"] / reps, rf / t["dct_row"]["ms"] / 1e9, t["dct_col"]["ms"] / reps, cf / t["dct_col"]["ms"] / 1e9))
