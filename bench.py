@@ -234,6 +234,9 @@ def main():
         if not operand and fold_rows and prec_name == "f64" and fold_level == 2 and W % 16 == 0 and W >= 64:
             row_frac = (3 * 0.375 + 1 * 0.5) / 4.0   # in-kernel second level: the three forward row passes of a step
         row_flops, col_flops = row_dense * row_frac, col_dense * col_frac
+        esz = 8.0 if prec_name == "f64" else 4.0
+        fused_rgb = bool(two_rows and W >= H)        # the three forward transforms of a step start from RGB
+        rgb_bytes = (3 * 12.0 + 8.0 + 3 * esz) if fused_rgb else 56.0
         row_ms, row_n = stage["dct_row"]["ms"], max(stage["dct_row"]["launches"], 1)
         col_ms, col_n = stage["dct_col"]["ms"], max(stage["dct_col"]["launches"], 1)
         row_tf = row_flops / (row_ms * 1e-3) / 1e12 if row_ms > 0 else 0.0
@@ -250,9 +253,12 @@ def main():
                          "pass_ms": round(col_ms / passes, 4),
                          "timed_passes": col_n, "executed_fraction_of_dense": col_frac,
                          "effective_dense_tflops": round(col_dense / (col_ms * 1e-3) / 1e12, 2) if col_ms > 0 else 0.0},
-            # algorithmic bytes: writer rgb->yiq 24 B/px + two reader rgb->y 16 B/px = 56 B/px
-            "rgb_to_yiq": {"gbs": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]), 1),
-                           "frac_hbm": round(gbs(56.0, 1, stage["rgb_to_yiq"]["ms"]) / PEAK_HBM_GBS, 4)},
+            # algorithmic bytes: writer rgb->yiq 24 B/px + two reader rgb->y 16 B/px = 56 B/px;
+            # fused with the first operand pre-pass (below) the stage reads 12 B/px three times and writes
+            # I, Q once and the operand planes (esz B/px) three times
+            "rgb_to_yiq": {"gbs": round(gbs(rgb_bytes, 1, stage["rgb_to_yiq"]["ms"]), 1),
+                           "frac_hbm": round(gbs(rgb_bytes, 1, stage["rgb_to_yiq"]["ms"]) / PEAK_HBM_GBS, 4),
+                           "fused_with_operand_prepass": fused_rgb},
             "yiq_to_rgb": {"gbs": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]), 1),
                            "frac_hbm": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]) / PEAK_HBM_GBS, 4)},
             # top-k: 4 B/px algorithmic, two selections per step (writer + base reader)
@@ -261,8 +267,9 @@ def main():
         }
         if operand:
             # operand pre-passes: f32 plane in (4 B/px), operand planes out (8 B/px in f64, 4 in f32), once per pass
-            per_px = 24.0 if prec_name == "f64" else 16.0
-            prep_gbs = gbs(per_px, transforms_per_step, stage["dct_prep"]["ms"])
+            per_pass = 4.0 + esz
+            prep_passes = transforms_per_step * 2 - (3 if fused_rgb else 0)
+            prep_gbs = gbs(per_pass, prep_passes, stage["dct_prep"]["ms"])
             kernels["dct_prep"] = {"gbs": round(prep_gbs, 1), "frac_hbm": round(prep_gbs / PEAK_HBM_GBS, 4),
                                    "ms_per_step": round(stage["dct_prep"]["ms"] / steps, 3)}
         lines_per_launch = min(args.chunk, B) * H

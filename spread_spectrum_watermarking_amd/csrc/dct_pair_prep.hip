@@ -243,6 +243,89 @@ __global__ __launch_bounds__(256) void pair_prep4_cols_kernel(const float* __res
     }
 }
 // ---------------------------------------------------------------------------------------------
+// First pass of a forward transform straight from the RGB frame: rgb -> Y (yiq.rs:177-186, the same
+// arithmetic as color.hip / attack.hip) fused with the two-level row pre-pass above, so the Y plane is
+// never written and re-read as f32 (8 B/px less HBM traffic per transform); I and Q planes are written
+// for the writer, not for readers.
+// ---------------------------------------------------------------------------------------------
+__device__ inline float prep_dot3(float m0, float m1, float m2, float a, float b, float c) { return m0 * a + m1 * b + m2 * c; }
+
+// 4 consecutive pixels starting at pixel x of a row (x % 4 == 0): Y (and I, Q)
+template <bool U8, bool WITH_IQ>
+__device__ inline void load_yiq4(const void* row_base, unsigned x, f32x4& y, f32x4& iv, f32x4& qv) {
+    float r[4], g[4], b[4];
+    if (!U8) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(static_cast<const float*>(row_base) + 3 * (size_t)x);
+        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
+        r[0] = v0[0]; g[0] = v0[1]; b[0] = v0[2];
+        r[1] = v0[3]; g[1] = v1[0]; b[1] = v1[1];
+        r[2] = v1[2]; g[2] = v1[3]; b[2] = v2[0];
+        r[3] = v2[1]; g[3] = v2[2]; b[3] = v2[3];
+    } else {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(row_base) + 3 * (size_t)x);
+        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+        const uint8_t by[12] = {(uint8_t)w0, (uint8_t)(w0 >> 8), (uint8_t)(w0 >> 16), (uint8_t)(w0 >> 24),
+                                (uint8_t)w1, (uint8_t)(w1 >> 8), (uint8_t)(w1 >> 16), (uint8_t)(w1 >> 24),
+                                (uint8_t)w2, (uint8_t)(w2 >> 8), (uint8_t)(w2 >> 16), (uint8_t)(w2 >> 24)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                               // into_rgb32f: v / 255
+            r[e] = (float)by[3 * e] / 255.0f; g[e] = (float)by[3 * e + 1] / 255.0f; b[e] = (float)by[3 * e + 2] / 255.0f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        y[e] = prep_dot3(0.30f, 0.59f, 0.11f, r[e], g[e], b[e]);
+        if (WITH_IQ) {
+            iv[e] = prep_dot3(0.60f, -0.28f, -0.32f, r[e], g[e], b[e]);
+            qv[e] = prep_dot3(0.21f, -0.52f, 0.31f, r[e], g[e], b[e]);
+        }
+    }
+}
+
+template <typename T, bool U8, bool WITH_IQ>
+__global__ __launch_bounds__(256) void pair_prep4_rows_rgb_kernel(const void* __restrict__ RGB, T* __restrict__ Q1,
+                                                                 T* __restrict__ Q2, T* __restrict__ P,
+                                                                 float* __restrict__ IP, float* __restrict__ QP,
+                                                                 unsigned rows, unsigned W, unsigned Kq, unsigned Kp,
+                                                                 unsigned tiles_q) {
+    const unsigned Nh = W / 2, Nq = W / 4;
+    const unsigned q = (blockIdx.x % tiles_q) * 32 + (threadIdx.x & 7) * 4;
+    const unsigned row = (blockIdx.x / tiles_q) * 32 + (threadIdx.x >> 3);
+    if (row >= rows || q >= Kq) return;
+    vec4_t<T> a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+    if (q < Nq) {                                                 // Nq % 4 == 0
+        const void* base = U8 ? static_cast<const void*>(static_cast<const uint8_t*>(RGB) + (size_t)row * W * 3)
+                              : static_cast<const void*>(static_cast<const float*>(RGB) + (size_t)row * W * 3);
+        const unsigned pos[4] = {q, Nh - 4 - q, Nh + q, W - 4 - q};
+        f32x4 y[4], iv, qv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            load_yiq4<U8, WITH_IQ>(base, pos[u], y[u], iv, qv);
+            if (WITH_IQ) {
+                *reinterpret_cast<f32x4*>(IP + (size_t)row * W + pos[u]) = iv;
+                *reinterpret_cast<f32x4*>(QP + (size_t)row * W + pos[u]) = qv;
+            }
+        }
+        const f32x4 a = y[0], b = y[1], c = y[2], d = y[3];
+        vec4_t<T> dn, dm;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const T s1 = (T)a[e] + (T)d[3 - e], s2 = (T)b[3 - e] + (T)c[e];
+            a1[e] = s1 + s2;
+            a2[e] = s1 - s2;
+            dn[e] = (T)a[e] - (T)d[3 - e];
+            dm[3 - e] = (T)b[3 - e] - (T)c[e];
+        }
+        *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(row, q, rows)) = dn;
+        *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(row, Nh - 4 - q, rows)) = dm;
+    }
+    *reinterpret_cast<vec4_t<T>*>(Q1 + blk_index<T>(row, q, rows)) = a1;
+    *reinterpret_cast<vec4_t<T>*>(Q2 + blk_index<T>(row, q, rows)) = a2;
+    if (q == 0)
+        for (unsigned z = Nh; z < Kp; z += 4) *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(row, z, rows)) = (vec4_t<T>){0, 0, 0, 0};
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
 size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h) {
@@ -317,6 +400,36 @@ int launch_dct_pair_prep4(hipStream_t st, bool f64, bool is_row, bool inverse, c
                           size_t h, void* q1, void* q2, void* p) {
     return f64 ? prep4_impl<double>(st, is_row, inverse, in, n_frames, w, h, (double*)q1, (double*)q2, (double*)p)
                : prep4_impl<float>(st, is_row, inverse, in, n_frames, w, h, (float*)q1, (float*)q2, (float*)p);
+}
+
+template <typename T>
+static int prep4_rgb_impl(hipStream_t st, bool u8, const void* rgb, size_t n_frames, size_t w, size_t h,
+                          T* q1, T* q2, T* p, float* ip, float* qp) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned Kp = (unsigned)pair_kpad<T>(w), Kq = (unsigned)pair_kpad<T>(w / 2), tiles_q = (Kq + 31) / 32;
+    const size_t rows = n_frames * h;
+    const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_q;
+    if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const bool iq = ip && qp;
+#define SSW_PREP_RGB(U8V, IQV) pair_prep4_rows_rgb_kernel<T, U8V, IQV><<<(unsigned)nblk, 256, 0, st>>>( \
+        rgb, q1, q2, p, ip, qp, (unsigned)rows, (unsigned)w, Kq, Kp, tiles_q)
+    if (u8) { if (iq) SSW_PREP_RGB(true, true); else SSW_PREP_RGB(true, false); }
+    else    { if (iq) SSW_PREP_RGB(false, true); else SSW_PREP_RGB(false, false); }
+#undef SSW_PREP_RGB
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// rows-first forward transform with two folding levels on the row axis: the first pre-pass straight
+// from the interleaved RGB frames (u8 or f32); ip / qp (both or neither) receive the I and Q planes.
+bool dct_pair_can_prep_from_rgb(size_t w, size_t h, const void* rgb, bool u8) {
+    return w >= h && dct_pair_can_fold2(w) && (reinterpret_cast<uintptr_t>(rgb) & (u8 ? 3 : 15)) == 0;
+}
+int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, bool u8, const void* rgb, size_t n_frames, size_t w, size_t h,
+                                   void* q1, void* q2, void* p, float* ip, float* qp) {
+    return f64 ? prep4_rgb_impl<double>(st, u8, rgb, n_frames, w, h, (double*)q1, (double*)q2, (double*)p, ip, qp)
+               : prep4_rgb_impl<float>(st, u8, rgb, n_frames, w, h, (float*)q1, (float*)q2, (float*)p, ip, qp);
 }
 
 }  // namespace ssw

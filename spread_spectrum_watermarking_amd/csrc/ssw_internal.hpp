@@ -98,6 +98,11 @@ int launch_dct_pair_prep(hipStream_t st, bool f64, bool is_row, bool inverse, co
 // two levels: (SS, SD | EE, EO) [kpad(len/2) wide] and (D | O) [kpad(len) wide] in one sweep
 int launch_dct_pair_prep4(hipStream_t st, bool f64, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,
                           size_t h, void* q1, void* q2, void* p);
+// first pass of a rows-first forward transform straight from interleaved RGB (u8 or f32), two levels;
+// ip / qp: I and Q planes out (both or neither)
+bool dct_pair_can_prep_from_rgb(size_t w, size_t h, const void* rgb, bool u8);
+int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, bool u8, const void* rgb, size_t n_frames, size_t w, size_t h,
+                                   void* q1, void* q2, void* p, float* ip, float* qp);
 // kind 0: one folding level; 1 / 2: the even / odd half of two levels (see dct_pair_f64.hip)
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,

@@ -140,7 +140,10 @@ int check_config(const ssw_config* cfg) {
 }
 
 // dct2d::dct2_2d on n contiguous planes, `data` in place, `tmp` same size scratch.
-int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size_t h, float* data, float* tmp) {
+// `rgb` (optional; forward transforms only, see forward_from_rgb below): the frames `data` would have been
+// converted from -- the first pass then reads them directly and `data` is only written by the last pass.
+int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size_t h, float* data, float* tmp,
+                 const void* rgb = nullptr, bool rgb_u8 = false, float* iq_i = nullptr, float* iq_q = nullptr) {
     const bool inverse = (type == SSW_DCT3);
     const bool f64 = (precision == SSW_PRECISION_F64);
     const bool rows_first = (w >= h);                                  // src/dct2d.rs:93-98
@@ -151,7 +154,9 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         const size_t max_frames = per_frame ? 0xFFFFFFFFull / per_frame : 0;
         if (max_frames >= 1 && n > max_frames) {
             for (size_t f0 = 0; f0 < n; f0 += max_frames)
-                SSW_TRY(dct2d_planes(ctx, type, precision, std::min(max_frames, n - f0), w, h, data + f0 * w * h, tmp + f0 * w * h));
+                SSW_TRY(dct2d_planes(ctx, type, precision, std::min(max_frames, n - f0), w, h, data + f0 * w * h, tmp + f0 * w * h,
+                                     rgb ? static_cast<const char*>(rgb) + f0 * w * h * 3 * (rgb_u8 ? 1 : sizeof(float)) : nullptr,
+                                     rgb_u8, iq_i ? iq_i + f0 * w * h : nullptr, iq_q ? iq_q + f0 * w * h : nullptr));
             return SSW_OK;
         }
     }
@@ -180,6 +185,8 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         } else {
             SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
         }
+        if (rgb && pass == 0 && !(operand && is_row && ctx->fold_level >= 4 && dct_pair_can_fold2(len)))
+            return SSW_ERR_BAD_ARG;                                    // forward_from_rgb() checks the same conditions
         if (operand) {
             const size_t esz = f64 ? sizeof(double) : sizeof(float);
             const size_t bytes = dct_pair_operand_elems(f64, n, w, h) * esz;
@@ -212,7 +219,10 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
                 const void *q0 = nullptr, *q1 = nullptr;
                 SSW_TRY(get_basis(ctx, len / 2, inverse, f64, 3, &q0));
                 SSW_TRY(get_basis(ctx, len / 2, inverse, f64, 4, &q1));
-                {
+                if (rgb && pass == 0) {                      // eligibility was checked by forward_from_rgb()
+                    StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ);
+                    SSW_TRY(launch_dct_pair_prep4_rows_rgb(ctx->stream, f64, rgb_u8, rgb, n, w, h, xx1, xx2, x2, iq_i, iq_q));
+                } else {
                     StageTimer t(ctx, SSW_STAGE_DCT_PREP);
                     SSW_TRY(launch_dct_pair_prep4(ctx->stream, f64, is_row, inverse, src, n, w, h, xx1, xx2, x2));
                 }
@@ -513,6 +523,19 @@ int rgb_in_to_yiq(ssw_ctx* ctx, const void* rgb, bool u8, size_t first_px, size_
     return launch_rgb_to_yiq(ctx->stream, static_cast<const float*>(rgb) + first_px * 3, npix, y, i, q);
 }
 
+// Writer::new / Reader::base / Reader::derived: rgb -> Y (+ I, Q) -> forward 2-D DCT of Y into `y`.
+// Where the default GEMM strategy applies (rows first, two folding levels on the row axis) the colour
+// conversion is fused into the first operand pre-pass and the f32 Y plane is never materialised.
+int forward_from_rgb(ssw_ctx* ctx, int precision, const void* rgb, bool u8, size_t first_px, size_t n, size_t w, size_t h,
+                     float* y, float* i, float* q, float* tmp) {
+    const bool f64 = precision == SSW_PRECISION_F64;
+    const char* src = static_cast<const char*>(rgb) + first_px * 3 * (u8 ? 1 : sizeof(float));
+    if (ctx->fold && ctx->fold_level >= 4 && dct_pair_can_run(f64, 1, w, h, y, tmp) && dct_pair_can_prep_from_rgb(w, h, src, u8))
+        return dct2d_planes(ctx, SSW_DCT2, precision, n, w, h, y, tmp, src, u8, i, q);
+    SSW_TRY(rgb_in_to_yiq(ctx, rgb, u8, first_px, n * w * h, y, i, q));
+    return dct2d_planes(ctx, SSW_DCT2, precision, n, w, h, y, tmp);
+}
+
 int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, bool u8_in, size_t n_frames,
                      size_t w, size_t h, const float* dev_marks, size_t k, void* dev_rgb_out, bool u8_out,
                      float* dev_coef_out, uint32_t* dev_indices_out) {
@@ -532,8 +555,7 @@ int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, b
     float* tmp = (float*)ctx->plane[3].p;
     for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const size_t n = std::min(chunk, n_frames - f0);
-        SSW_TRY(rgb_in_to_yiq(ctx, dev_rgb, u8_in, f0 * plane, n * plane, y, pi, pq));   // Writer::new :308
-        SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, y, tmp));          // :313
+        SSW_TRY(forward_from_rgb(ctx, cfg->precision, dev_rgb, u8_in, f0 * plane, n, w, h, y, pi, pq, tmp));   // Writer::new :308-313
         if (dev_coef_out)
             SSW_HIP_CHECK(hipMemcpyAsync(dev_coef_out + f0 * plane, y, n * plane * sizeof(float),
                                          hipMemcpyDeviceToDevice, ctx->stream));
@@ -574,11 +596,9 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
     for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const size_t n = std::min(chunk, n_frames - f0);
         // Reader::base (:474-480): only the Y plane is ever used by a reader
-        SSW_TRY(rgb_in_to_yiq(ctx, dev_base_rgb, u8, f0 * plane, n * plane, yb, nullptr, nullptr));
-        SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, yb, tmp));
+        SSW_TRY(forward_from_rgb(ctx, cfg->precision, dev_base_rgb, u8, f0 * plane, n, w, h, yb, nullptr, nullptr, tmp));
         if (k > 0) SSW_TRY(topk(ctx, yb, n, w, h, cfg->ordering, k, idx));      // :493
-        SSW_TRY(rgb_in_to_yiq(ctx, dev_derived_rgb, u8, f0 * plane, n * plane, yd, nullptr, nullptr));   // Reader::derived
-        SSW_TRY(dct2d_planes(ctx, SSW_DCT2, cfg->precision, n, w, h, yd, tmp));
+        SSW_TRY(forward_from_rgb(ctx, cfg->precision, dev_derived_rgb, u8, f0 * plane, n, w, h, yd, nullptr, nullptr, tmp));   // Reader::derived
         if (k > 0) {
             StageTimer t(ctx, SSW_STAGE_EXTRACT);                               // :529-539
             SSW_TRY(launch_extract(ctx->stream, yb, yd, n, plane, idx, k, cfg->method, cfg->alpha,

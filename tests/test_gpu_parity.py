@@ -557,6 +557,35 @@ def test_batch_path_equals_handles_and_oracle(precision):
             assert abs(sims[f] - o_sim) < 1e-4 * abs(o_sim) + 1e-4
 
 
+@pytest.mark.parametrize("precision", [F32, F64])
+@pytest.mark.parametrize("shape", [(80, 208), (144, 1040)])
+def test_batch_path_fused_colour_prepass_equals_handles(precision, shape):
+    """Shapes that take the default GEMM strategy (W >= H, W % 16 == 0, H % 8 == 0): the batch entry
+    points read the RGB frames in the first operand pre-pass (no f32 Y plane); the handle API converts
+    first.  Same arithmetic, so coefficients, indices, marked frames and extraction are bit-identical --
+    also from 8-bit frames."""
+    h, w = shape
+    n, k = 3, 200
+    rgb = G.synth(5, 1, n, w, h)
+    marks = np.random.default_rng(3).standard_normal((n, k)).astype(np.float32)
+    cfg = G.default_config(precision)
+    res = G.batch_embed(rgb, marks, cfg, want_coef=True, want_idx=True)
+    ext, sims = G.batch_extract(rgb, res["rgb"], k, marks, cfg)
+    for f in range(n):
+        wr = wm.Writer(rgb[f], wm.WriteConfig(precision=precision))
+        assert np.array_equal(res["coef"][f], wr.coefficient_image())
+        assert np.array_equal(res["rgb"][f], wr.mark([marks[f]]))
+        rd = wm.Reader.base(rgb[f], wm.ReadConfig(precision=precision))
+        assert np.array_equal(res["idx"][f], rd.indices(k).astype(np.uint32))
+        assert np.array_equal(ext[f], rd.extract(wm.Reader.derived(res["rgb"][f], precision=precision), k))
+    frames8 = O.f32_to_u8(rgb)
+    wm8 = G.batch_embed_rgb8(frames8, marks, cfg)
+    assert np.array_equal(wm8, O.f32_to_u8(G.batch_embed(O.u8_to_f32(frames8), marks, cfg)["rgb"]))
+    e8, s8 = G.batch_extract_rgb8(frames8, wm8, k, marks, cfg)
+    e32, s32 = G.batch_extract(O.u8_to_f32(frames8), O.u8_to_f32(wm8), k, marks, cfg)
+    assert np.array_equal(e8, e32) and np.array_equal(s8, s32)
+
+
 # ---- BASELINE.json sizes and degenerate inputs ---------------------------------------------------
 def test_full_hd_pipeline_parity_with_oracle():
     """configs[2] frame size (1920x1080), canonical precision: the whole embed -> extract -> similarity
