@@ -13,13 +13,16 @@
 // Per frame (HBM-bound, ~1.02 reads of the plane, decided entirely on the device):
 //   1. sample pass   -- one pseudo-randomly placed element out of every 64 goes into a 2048-bin
 //                       histogram of the top 11 key bits
-//   2. sample find   -- the digit d whose upper tail holds ~4k/64 samples: a conservative threshold
-//                       (expected 4k survivors, never fewer than k short of a >40-sigma event)
+//   2. sample find   -- the digit d whose upper tail holds ~2.5k/64 samples: a conservative threshold
+//                       (expected 2.5k survivors; fewer than k = 1000 is a -3.7 sigma event, and then step 4
+//                       falls back to the exact whole-plane select)
 //   3. compaction    -- the one full pass: every coefficient whose top digit >= d is appended to a
-//                       candidate list (16-B loads, rare atomics)
-//   4. finish        -- one block per frame: exact MSD radix select (11-bit digits, LDS histogram)
-//                       of the k-th largest composite among the candidates, gather of exactly k,
-//                       bitonic sort in LDS, emit ~low32.
+//                       candidate list (two 16-B loads in flight per thread, rare atomics; for the
+//                       default energy ordering the test is one multiply and one float compare)
+//   4. finish        -- one block per frame: MSD radix select (11-bit digits, LDS histogram, wave-shuffle
+//                       scan) on the candidates until everything from the chosen bin upwards fits the
+//                       1024-entry sort buffer (one or two rounds), gather, bitonic sort with one key per
+//                       thread (shuffles inside a wave, LDS only for strides >= 64), emit ~low32.
 //   Degenerate data (fewer than k candidates, or more than the candidate buffer holds: massive
 //   ties, constant planes) is handled in the same finish kernel by running the exact select over
 //   the whole plane instead of the candidate list -- slow but exact, and never taken by images.
@@ -69,11 +72,70 @@ __device__ inline uint32_t mix32(uint32_t x) {
     return x;
 }
 
-// per-frame control block: [0] threshold digit, [1] candidate count.  ctrl and the sample
+// per-frame control block: [0] threshold digit, [1] candidate count ([2], [3] spare).  ctrl and the sample
 // histogram are zero when a selection starts: the workspace is zero-filled at allocation and the
 // finish kernel re-zeroes what it consumed.
 
 // 1. sample pass: one pseudo-randomly placed 16-B quad out of every 256 elements (rate 1/64)
+// First of 256 partial sums (LDS) at which the running total reaches `need`, found by one wave without
+// barriers: lane l owns partials 4l..4l+3, a shuffle scan gives its exclusive prefix.  Returns the owner
+// in [0, 256) and its exclusive prefix through `excl_out`; 256 if the total stays below `need`.
+__device__ inline unsigned wave_find_owner(const uint32_t* part, uint64_t need, uint64_t* excl_out) {
+    const unsigned lane = threadIdx.x & 63;
+    const uint32_t a0 = part[4 * lane], a1 = part[4 * lane + 1], a2 = part[4 * lane + 2], a3 = part[4 * lane + 3];
+    const uint32_t s = a0 + a1 + a2 + a3;
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= (unsigned)d) incl += up;
+    }
+    uint64_t run = incl - s;
+    unsigned owner = 256;
+    uint64_t ex = 0;
+    const uint32_t a[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (owner == 256 && run < need && run + a[j] >= need) { owner = 4 * lane + j; ex = run; }
+        run += a[j];
+    }
+    const unsigned long long found = __ballot(owner != 256);      // at most one lane
+    if (!found) return 256;
+    const int src = __ffsll((long long)found) - 1;
+    owner = __shfl(owner, src, 64);
+    const uint32_t ex_lo = __shfl((uint32_t)ex, src, 64), ex_hi = __shfl((uint32_t)(ex >> 32), src, 64);
+    *excl_out = ((uint64_t)ex_hi << 32) | ex_lo;
+    return owner;
+}
+
+// threshold digit: smallest upper tail of the sample histogram holding >= m samples (256 threads)
+__device__ inline void find_threshold_digit(const uint32_t* h, uint32_t m, uint32_t* part /*LDS, 256*/, uint32_t* thr_out) {
+    const int t = threadIdx.x;
+    uint32_t local[8], sum = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { local[e] = h[NBINS - 1 - (8 * t + e)]; sum += local[e]; }
+    part[t] = sum;
+    __shared__ unsigned owner_s;
+    __shared__ uint32_t excl_s;
+    __syncthreads();
+    if (t < 64) {
+        uint64_t ex = 0;
+        const unsigned o = wave_find_owner(part, m, &ex);
+        if (t == 0) { owner_s = o; excl_s = (uint32_t)ex; }
+    }
+    __syncthreads();
+    if (t == 0 && owner_s == 256) *thr_out = 0;                   // fewer than m samples: keep everything
+    if ((unsigned)t == owner_s) {
+        uint32_t run = excl_s;
+        int e = 0;
+        for (; e < 7; ++e) {
+            if (run + local[e] >= m) break;
+            run += local[e];
+        }
+        *thr_out = (uint32_t)(NBINS - 1 - (8 * t + e));
+    }
+}
+
 __global__ __launch_bounds__(256) void select_sample_kernel(const float* __restrict__ coef, size_t plane_len,
                                                             KeyParams kp, uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[NBINS];
@@ -106,62 +168,53 @@ __global__ __launch_bounds__(256) void select_sample_kernel(const float* __restr
     }
 }
 
-// 2. threshold digit: smallest upper tail of the sample histogram holding >= m samples
+// 2. threshold digit of every frame (one block per frame)
 __global__ __launch_bounds__(256) void select_sample_find_kernel(uint32_t* __restrict__ ctrl,
                                                                  const uint32_t* __restrict__ hist, uint32_t m) {
     __shared__ uint32_t part[256];
-    __shared__ uint32_t chosen[2];
-    const size_t f = blockIdx.x;
-    const uint32_t* h = hist + f * NBINS;
-    const int t = threadIdx.x;
-    uint32_t local[8], sum = 0;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { local[e] = h[NBINS - 1 - (8 * t + e)]; sum += local[e]; }
-    part[t] = sum;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        int owner = -1;
-        for (int i = 0; i < 256; ++i) {
-            if (run + part[i] >= m) { owner = i; break; }
-            run += part[i];
-        }
-        chosen[0] = (uint32_t)owner;
-        chosen[1] = run;
-        if (owner < 0) ctrl[f * 2 + 0] = 0;                           // fewer than m samples: keep everything
-    }
-    __syncthreads();
-    if (t == (int)chosen[0]) {
-        uint32_t run = chosen[1];
-        int e = 0;
-        for (; e < 7; ++e) {
-            if (run + local[e] >= m) break;
-            run += local[e];
-        }
-        ctrl[f * 2 + 0] = (uint32_t)(NBINS - 1 - (8 * t + e));
-    }
+    find_threshold_digit(hist + (size_t)blockIdx.x * NBINS, m, part, &ctrl[(size_t)blockIdx.x * 4 + 0]);
 }
 
-// 3. the one full pass over the plane: append every coefficient whose top digit >= threshold
+// 3. the one full pass over the plane: append every coefficient whose top digit >= threshold.
+// ENERGY ordering (the default; keys c*c >= 0, so digit order = float order): the test is one multiply and
+// one float compare against the threshold digit's lower edge, two 16-byte loads in flight per thread.
+template <bool ENERGY>
 __global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ coef, size_t plane_len,
                                                              KeyParams kp, uint32_t* __restrict__ ctrl,
                                                              uint64_t* __restrict__ cand, size_t cap) {
     const size_t f = blockIdx.y;
-    const uint32_t thr = ctrl[f * 2 + 0];
-    uint32_t* count = &ctrl[f * 2 + 1];
+    const uint32_t thr = ctrl[f * 4 + 0];
+    uint32_t* count = &ctrl[f * 4 + 1];
     const float* __restrict__ c = coef + f * plane_len;
     uint64_t* __restrict__ out = cand + f * cap;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    // lower edge of digit `thr` as a float (digits below 2^(DIGIT_BITS-1) hold negative keys: keep everything)
+    const float edge = thr > (1u << (DIGIT_BITS - 1)) ? __uint_as_float((thr << (32 - DIGIT_BITS)) & 0x7FFFFFFFu) : 0.0f;
+    auto append = [&](size_t j, uint32_t kb) {
+        const uint32_t pos = atomicAdd(count, 1u);
+        if (pos < cap) out[pos] = ((uint64_t)kb << 32) | (uint32_t)(~(uint32_t)j);
+    };
     auto consider = [&](size_t j, float v) {
-        const uint32_t kb = key_bits(kp, (uint32_t)j, v);
-        if ((kb >> (32 - DIGIT_BITS)) >= thr && j != 0) {
-            const uint32_t pos = atomicAdd(count, 1u);
-            if (pos < cap) out[pos] = ((uint64_t)kb << 32) | (uint32_t)(~(uint32_t)j);
+        if (ENERGY) {
+            const float key = v * v;                                     // :214-221
+            if (!(key < edge) && j != 0) append(j, sortable(key));      // NaN keys pass, like in the digit test
+        } else {
+            const uint32_t kb = key_bits(kp, (uint32_t)j, v);
+            if ((kb >> (32 - DIGIT_BITS)) >= thr && j != 0) append(j, kb);
         }
     };
     if ((plane_len % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0)) {
         const size_t nquad = plane_len / 4;
-        for (size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x; q < nquad; q += stride) {
+        size_t q = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+        for (; q + stride < nquad; q += 2 * stride) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(c + 4 * q);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(c + 4 * (q + stride));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) consider(4 * q + e, v0[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) consider(4 * (q + stride) + e, v1[e]);
+        }
+        if (q < nquad) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(c + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) consider(4 * q + e, v[e]);
@@ -215,15 +268,13 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
             lpart[tid] = sum;
         }
         __syncthreads();
-        if (tid == 0) {
-            uint64_t run = 0;
-            int owner = 255;
-            for (int i = 0; i < 256; ++i) {
-                if (run + lpart[i] >= need) { owner = i; break; }
-                run += lpart[i];
-            }
-            lstate[5] = (uint64_t)owner;
-            lstate[6] = run;
+        // owner of the need-th key among the 256 partials: one wave, shuffle scan, no barriers (a serial
+        // scan by one thread cost ~7 us per round)
+        if (tid < 64) {
+            uint64_t ex = 0;
+            unsigned o = wave_find_owner(lpart, need, &ex);
+            if (o == 256) { o = 255; ex = 0; for (int i = 0; i < 255; ++i) ex += lpart[i]; }   // cannot happen: n >= need
+            if (tid == 0) { lstate[5] = o; lstate[6] = ex; }
         }
         __syncthreads();
         if (tid == (unsigned)lstate[5]) {
@@ -238,11 +289,14 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
             lstate[0] = (prefix << width) | (uint64_t)(d & mask);
             lstate[1] = (uint64_t)(bits_done + width);
             lstate[2] = new_need;
-            lstate[3] = (local[e] == new_need || bits_done + width >= 64) ? 1 : 0;
+            // done when the chosen bin is needed whole, when the key is exhausted, or -- the usual exit, after
+            // one or two rounds instead of six -- when everything from this bin upwards fits the sort buffer
+            // (the sort then orders the bin's surplus behind position k)
+            lstate[3] = (local[e] == new_need || bits_done + width >= 64 || (k - new_need) + local[e] <= n_pow2) ? 1 : 0;
         }
         __syncthreads();
     }
-    // gather exactly k survivors
+    // gather the survivors: everything from the chosen bin upwards (>= k of them, <= n_pow2)
     {
         const uint64_t prefix = lstate[0];
         const int bits_done = (int)lstate[1];
@@ -255,11 +309,40 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
             }
         }
         __syncthreads();
+        const unsigned gathered = (unsigned)lstate[4];            // k <= gathered <= n_pow2
         for (unsigned i = tid; i < n_pow2; i += blockDim.x)
-            if (i >= k) lbuf[i] = 0ull;
+            if (i >= gathered) lbuf[i] = 0ull;                    // 0 sorts behind every real key
         __syncthreads();
     }
     // bitonic sort, descending
+    if (n_pow2 <= blockDim.x) {
+        // one key per thread in a register: the 45 of 55 sweeps whose partner is within the wave use
+        // shuffles (no LDS, no barrier); the ten with stride >= 64 exchange through LDS
+        const unsigned N = blockDim.x;
+        uint64_t v = tid < n_pow2 ? lbuf[tid] : 0ull;
+        __syncthreads();
+        for (unsigned size = 2; size <= N; size <<= 1) {
+            const bool up = (tid & size) == 0;
+            for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
+                uint64_t other;
+                if (stride >= 64) {
+                    lbuf[tid] = v;
+                    __syncthreads();
+                    other = lbuf[tid ^ stride];
+                    __syncthreads();
+                } else {
+                    const uint32_t lo = __shfl_xor((uint32_t)v, (int)stride, 64);
+                    const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), (int)stride, 64);
+                    other = ((uint64_t)hi << 32) | lo;
+                }
+                const bool lower = (tid & stride) == 0;
+                const uint64_t mx = v > other ? v : other, mn = v > other ? other : v;
+                v = (lower == up) ? mx : mn;
+            }
+        }
+        if (tid < k) indices[tid] = ~(uint32_t)(v & 0xFFFFFFFFull);
+        return;
+    }
     for (unsigned size = 2; size <= n_pow2; size <<= 1) {
         for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
             for (unsigned i = tid; i < n_pow2 / 2; i += blockDim.x) {
@@ -280,15 +363,15 @@ __global__ __launch_bounds__(FINISH_THREADS) void select_finish_kernel(
     uint32_t* __restrict__ hist, const uint64_t* __restrict__ cand, size_t cap, size_t k, unsigned n_pow2,
     uint32_t* __restrict__ indices) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint64_t* lbuf = reinterpret_cast<uint64_t*>(smem_raw);                      // n_pow2 entries
-    uint64_t* lstate = lbuf + n_pow2;                                            // 8 entries
+    uint64_t* lbuf = reinterpret_cast<uint64_t*>(smem_raw);                      // max(n_pow2, blockDim.x) entries
+    uint64_t* lstate = lbuf + (n_pow2 > blockDim.x ? n_pow2 : blockDim.x);       // 8 entries
     uint32_t* lhist = reinterpret_cast<uint32_t*>(lstate + 8);                   // NBINS entries
     uint32_t* lpart = lhist + NBINS;                                             // 256 entries
     const size_t f = blockIdx.x;
-    const uint32_t n = ctrl[f * 2 + 1];
+    const uint32_t n = ctrl[f * 4 + 1];
     __syncthreads();
     for (unsigned i = threadIdx.x; i < NBINS; i += blockDim.x) hist[f * NBINS + i] = 0;   // ready for the next
-    if (threadIdx.x == 0) { ctrl[f * 2 + 0] = 0; ctrl[f * 2 + 1] = 0; }                      // selection
+    if (threadIdx.x == 0) { ctrl[f * 4 + 0] = 0; ctrl[f * 4 + 1] = 0; }                      // selection
     if (n >= k && n <= cap) {
         CandSource src{cand + f * cap};
         block_select_sort(src, n, k, n_pow2, lhist, lpart, lbuf, lstate, indices + f * k);
@@ -328,24 +411,29 @@ int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, si
     size_t sb = (groups + 256 * 2 - 1) / (256 * 2);
     if (sb < 1) sb = 1;
     if (sb > 256) sb = 256;
-    select_sample_kernel<<<dim3((unsigned)sb, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.hist);
-    // expected survivors ~ 4k (sampling noise at this depth is < 15 %); at least 32 samples deep
-    uint32_t m = (uint32_t)((4 * k + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE);
+
+    // expected survivors ~ 2.5k (sampling noise at this depth is ~16 %: falling short of k = 1000 is a
+    // -3.7 sigma event, and then the exact whole-plane select still answers); at least 32 samples deep
+    uint32_t m = (uint32_t)((5 * k / 2 + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE);
     if (m < 32) m = 32;
+    select_sample_kernel<<<dim3((unsigned)sb, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.hist);
     select_sample_find_kernel<<<(unsigned)n_frames, 256, 0, st>>>(ws.ctrl, ws.hist, m);
     size_t bpf = (plane_len + 256 * 32 - 1) / (256 * 32);             // >= 32 elements per thread
     if (bpf < 1) bpf = 1;
     if (bpf > 2048) bpf = 2048;
-    select_compact_kernel<<<dim3((unsigned)bpf, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.ctrl,
-                                                                                  ws.cand, ws.cap);
+    if (ordering == SSW_ORDER_ENERGY)
+        select_compact_kernel<true><<<dim3((unsigned)bpf, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.ctrl, ws.cand, ws.cap);
+    else
+        select_compact_kernel<false><<<dim3((unsigned)bpf, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.ctrl, ws.cand, ws.cap);
     unsigned n_pow2 = 2;
     while (n_pow2 < k) n_pow2 <<= 1;
-    const size_t smem = (size_t)n_pow2 * sizeof(uint64_t) + 8 * sizeof(uint64_t) + (NBINS + 256) * sizeof(uint32_t);
+    const size_t smem = (size_t)(n_pow2 > FINISH_THREADS ? n_pow2 : FINISH_THREADS) * sizeof(uint64_t) + 8 * sizeof(uint64_t) +
+                        (NBINS + 256) * sizeof(uint32_t);
+    constexpr size_t LDS_LIMIT = 160 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
         SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_finish_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)(MAX_K * sizeof(uint64_t) + 64 + (NBINS + 256) * sizeof(uint32_t))));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
         attr_set = true;
     }
     select_finish_kernel<<<(unsigned)n_frames, FINISH_THREADS, smem, st>>>(coef, plane_len, kp, ws.ctrl, ws.hist,

@@ -114,7 +114,7 @@ int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind
 // select.hip
 struct SelectWorkspace {
     uint32_t* hist = nullptr;       // [n_frames][2048] sample histogram
-    uint32_t* ctrl = nullptr;       // [n_frames][2]: threshold digit, candidate count
+    uint32_t* ctrl = nullptr;       // [n_frames][4]: threshold digit, candidate count, 2 spare
     uint64_t* cand = nullptr;       // [n_frames][cap] candidate composite keys
     size_t frames = 0, cap = 0;
 };

@@ -63,10 +63,10 @@ int grow_select(ssw_ctx* ctx, size_t frames, size_t k) {
     if (s.cand) (void)hipFree(s.cand);
     s = SelectWorkspace();
     SSW_HIP_CHECK(hipMalloc((void**)&s.hist, nf * 2048 * sizeof(uint32_t)));
-    SSW_HIP_CHECK(hipMalloc((void**)&s.ctrl, nf * 2 * sizeof(uint32_t)));
+    SSW_HIP_CHECK(hipMalloc((void**)&s.ctrl, nf * 4 * sizeof(uint32_t)));
     SSW_HIP_CHECK(hipMalloc((void**)&s.cand, nf * cap * sizeof(uint64_t)));
     SSW_HIP_CHECK(hipMemsetAsync(s.hist, 0, nf * 2048 * sizeof(uint32_t), ctx->stream));   // see select.hip:
-    SSW_HIP_CHECK(hipMemsetAsync(s.ctrl, 0, nf * 2 * sizeof(uint32_t), ctx->stream));      // zero between uses
+    SSW_HIP_CHECK(hipMemsetAsync(s.ctrl, 0, nf * 4 * sizeof(uint32_t), ctx->stream));      // zero between uses
     s.frames = nf;
     s.cap = cap;
     return SSW_OK;
