@@ -13,8 +13,8 @@
 // Per frame (HBM-bound, ~1.02 reads of the plane, decided entirely on the device):
 //   1. sample pass   -- one pseudo-randomly placed element out of every 64 goes into a 2048-bin
 //                       histogram of the top 11 key bits
-//   2. sample find   -- the digit d whose upper tail holds ~2.5k/64 samples: a conservative threshold
-//                       (expected 2.5k survivors; fewer than k = 1000 is a -3.7 sigma event, and then step 4
+//   2. sample find   -- the digit d whose upper tail holds ~3k/64 samples: a conservative threshold
+//                       (expected 3k survivors; fewer than k = 1000 is a -4.6 sigma event, and then step 4
 //                       falls back to the exact whole-plane select)
 //   3. compaction    -- the one full pass: every coefficient whose top digit >= d is appended to a
 //                       candidate list (two 16-B loads in flight per thread, rare atomics; for the
@@ -412,9 +412,9 @@ int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, si
     if (sb < 1) sb = 1;
     if (sb > 256) sb = 256;
 
-    // expected survivors ~ 2.5k (sampling noise at this depth is ~16 %: falling short of k = 1000 is a
-    // -3.7 sigma event, and then the exact whole-plane select still answers); at least 32 samples deep
-    uint32_t m = (uint32_t)((5 * k / 2 + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE);
+    // expected survivors ~ 3k (sampling noise at this depth is ~15 %: falling short of k = 1000 is a
+    // -4.6 sigma event, and then the exact whole-plane select still answers); at least 32 samples deep
+    uint32_t m = (uint32_t)((3 * k + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE);
     if (m < 32) m = 32;
     select_sample_kernel<<<dim3((unsigned)sb, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.hist);
     select_sample_find_kernel<<<(unsigned)n_frames, 256, 0, st>>>(ws.ctrl, ws.hist, m);
