@@ -180,11 +180,15 @@ int launch_dct_rows_fold2_fwd_f64(hipStream_t st, const float* in, float* out, s
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t smem8 = 2 * sizeof(Fold2Smem8);
-    static bool attr8 = false;
-    if (!attr8) {
-        SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dct_rows_fold2_fwd_f64_k8_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
-        attr8 = true;
+    {   // per-device function attribute (79.9 KB of dynamic LDS)
+        static bool attr8[64] = {false};
+        int dev = 0;
+        SSW_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr8[dev]) {
+            SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dct_rows_fold2_fwd_f64_k8_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
+            if (dev >= 0 && dev < 64) attr8[dev] = true;
+        }
     }
     dct_rows_fold2_fwd_f64_k8_kernel<<<(unsigned)nblk, 256, smem8, st>>>(in, bo, bee, beo, out, M, W, kp1, kp2, tiles_m, tiles_n, ep);
     SSW_HIP_CHECK(hipGetLastError());

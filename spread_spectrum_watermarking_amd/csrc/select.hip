@@ -430,11 +430,15 @@ int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, si
     const size_t smem = (size_t)(n_pow2 > FINISH_THREADS ? n_pow2 : FINISH_THREADS) * sizeof(uint64_t) + 8 * sizeof(uint64_t) +
                         (NBINS + 256) * sizeof(uint32_t);
     constexpr size_t LDS_LIMIT = 160 * 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_finish_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        attr_set = true;
+    {   // the dynamic-LDS ceiling is a per-device function attribute: set it once on every device used
+        static bool attr_set[64] = {false};
+        int dev = 0;
+        SSW_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_finish_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     select_finish_kernel<<<(unsigned)n_frames, FINISH_THREADS, smem, st>>>(coef, plane_len, kp, ws.ctrl, ws.hist,
                                                                             ws.cand, ws.cap, k, n_pow2, indices);
