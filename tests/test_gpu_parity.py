@@ -606,6 +606,31 @@ def test_full_hd_pipeline_parity_with_oracle():
     assert abs(float(sims[0]) - ref_sim) < 1e-4
 
 
+def test_4k_size_independent_properties():
+    """BASELINE configs[1]/[3] frame size (3840x2160), default strategy: properties that need no CPU
+    reference -- inverse(forward(x)) == x to f32 round-off, the operand-ready two-level GEMMs agree with
+    the in-kernel one-level ones, embed -> extract recovers the mark, linearity of the transform."""
+    w, h, k = 3840, 2160, 1000
+    rgb = G.synth(9, 5, 2, w, h)
+    y = np.ascontiguousarray(rgb[..., 0] * np.float32(0.3) + rgb[..., 1] * np.float32(0.59))
+    c = G.dct2d(y, L.DCT2, F64)
+    back = G.dct2d(c, L.DCT3, F64)
+    assert np.abs(back - y).max() <= 4e-7
+    G.ctx().set_dct_folding(1)
+    try:
+        c1 = G.dct2d(y, L.DCT2, F64)
+    finally:
+        G.ctx().set_dct_folding(True)
+    assert np.mean(c == c1) >= 0.9999 and np.abs(c - c1).max() <= 2e-7 * np.abs(c1).max()
+    lin = G.dct2d(np.float32(0.5) * y[0] + np.float32(0.25) * y[1], L.DCT2, F64)
+    assert np.abs(lin - (0.5 * c[0].astype(np.float64) + 0.25 * c[1])).max() <= 4e-7 * np.abs(c).max()
+    marks = np.random.default_rng(11).standard_normal((2, k)).astype(np.float32)
+    res = G.batch_embed(rgb, marks)
+    ext, sims = G.batch_extract(rgb, res["rgb"], k, marks)
+    assert np.all(sims > 0.97 * np.linalg.norm(marks, axis=1))
+    assert np.abs(ext - marks).max() < 0.05                      # Option2, alpha 0.1: clamp / round-off of the round trip
+
+
 def test_empty_and_degenerate_calls():
     lib, ctx = G.lib(), G.ctx()
     cfg = G.default_config()
