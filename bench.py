@@ -229,7 +229,10 @@ def main():
         operand = fold_level >= 3 and fold_rows and fold_cols
         two_rows = operand and fold_level >= 4 and W % 16 == 0 and W >= 64
         two_cols = operand and fold_level >= 4 and H % 16 == 0 and H >= 64
+        three_rows = two_rows and W % 32 == 0 and W >= 128 and (fold_level >= 6 or (fold_level == 5 and W >= 3072))
         row_frac = 0.375 if two_rows else (0.5 if fold_rows else 1.0)
+        if three_rows:                               # the three forward transforms of a step: 11/32; the inverse: 3/8
+            row_frac = (3 * 11.0 / 32.0 + 0.375) / 4.0
         col_frac = 0.375 if two_cols else (0.5 if fold_cols else 1.0)
         if not operand and fold_rows and prec_name == "f64" and fold_level == 2 and W % 16 == 0 and W >= 64:
             row_frac = (3 * 0.375 + 1 * 0.5) / 4.0   # in-kernel second level: the three forward row passes of a step

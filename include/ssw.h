@@ -117,11 +117,15 @@ int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
      3  "operand-ready" GEMMs -- HBM-bound pre-passes write the folded operands once per pass as
         k-blocked planes in the GEMM's precision and the MFMA loop issues no VALU instruction
         (csrc/dct_pair_f64.hip, dct_pair_f32.hip, dct_pair_prep.hip); one level
-     4  default.  Level 3 with the even half folded once more wherever the axis length is a
-        multiple of 16 (3/8 of the dense MACs on that axis)
+     4  level 3 with the even half folded once more wherever the axis length is a multiple of 16
+        (3/8 of the dense MACs on that axis)
+     5  default.  Level 4 plus a third folding level on forward row passes of at least 3072 columns
+        (a multiple of 32): 11/32 of the dense MACs there
+     6  level 5 without the size threshold (shorter rows lose more to the extra small launches than
+        they save; for tests)
    In f64 all levels produce the same f64-accurate result rounded once to f32; in f32 each folding
    level adds one rounding per operand sum (tests/test_gpu_parity.py holds both to their bars). */
-#define SSW_DCT_FOLDING_DEFAULT 4
+#define SSW_DCT_FOLDING_DEFAULT 5
 int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int level);
 
 /* Per-stage device timers (hipEvent pairs on the context's stream).  DCT_ROW / DCT_COL cover the

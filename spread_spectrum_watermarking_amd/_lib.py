@@ -26,7 +26,7 @@ DCT2, DCT2_ORTHOGONAL, DCT3 = 0, 1, 2
 PRECISION_F32, PRECISION_F64 = 0, 1
 STAGES = ["rgb_to_yiq", "dct_row", "dct_col", "select", "embed", "extract", "similarity", "yiq_to_rgb",
           "resize", "convert", "dct_prep", "dct_row_main", "dct_col_main"]
-DCT_FOLDING_DEFAULT = 4
+DCT_FOLDING_DEFAULT = 5
 
 
 class Config(C.Structure):

@@ -56,8 +56,9 @@ class Context:
 
     def set_dct_folding(self, level=True):
         """Basis-GEMM strategy (include/ssw.h): False / 0 dense; 1 / 2 folding inside the GEMM kernel
-        (one level / a second one for the f64 forward row pass); 3 / 4 f64 operand-ready GEMMs with
-        one / two folding levels.  True selects the default (4)."""
+        (one level / a second one for the f64 forward row pass); 3 / 4 operand-ready GEMMs with one / two
+        folding levels; 5 a third level on long forward row passes; 6 the same without the size
+        threshold.  True selects the default (5)."""
         lvl = (L.DCT_FOLDING_DEFAULT if level else 0) if isinstance(level, bool) else int(level)
         check(self._lib.ssw_ctx_set_dct_folding(self.handle, lvl), "ssw_ctx_set_dct_folding")
 

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
 }
 
 // kind: 0 one folding level; 1 / 2 the even / odd half of two levels (see launch_dct_pair_gemm_f64)
-int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, const float* x1, const float* x2,
+int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const float* x1, const float* x2,
                              const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep) {
     if (n_frames == 0) return SSW_OK;
@@ -278,14 +278,17 @@ int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind
     const size_t len = is_row ? w : h;
     if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned L = (unsigned)lines;
-    const unsigned NP = (unsigned)(kind == 0 ? len / 2 : len / 4);
-    const unsigned Kp = (unsigned)(kind == 1 ? pair_kpad<float>(len / 2) : pair_kpad<float>(len));
+    if (sub < 0 || sub > 8 || (sub > 0 && (inverse || kind == 0))) return SSW_ERR_BAD_ARG;
+    const size_t leff = len >> sub;                           // length of the (sub-)transform this launch serves
+    const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
+    const unsigned NP = (unsigned)(kind == 0 ? leff / 2 : leff / 4);
+    const unsigned Kp = (unsigned)(kind == 1 ? pair_kpad<float>(leff / 2) : pair_kpad<float>(leff));
     const unsigned tiles_m = (L + 127) / 128, tiles_n = (NP + 63) / 64;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     PairOutF po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)len, 0, 1, 2};
-    if (kind == 1) { po.c1 = 0; po.c2 = 2; po.cs = 4; }
-    if (kind == 2) { po.c1 = 1; po.c2 = 1 + 2 * NP; po.cs = 2; }
+    if (kind == 1) { po.c1 = 0; po.c2 = 2 * fs; po.cs = 4 * fs; }
+    if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     if ((unsigned long long)Kp * L * 4 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
 #define SSW_LAUNCH_PAIRF(COLS, EPI, SAMEX) pair_gemm_f32_kernel<COLS, EPI, SAMEX><<<(unsigned)nblk, QT, 0, st>>>( \

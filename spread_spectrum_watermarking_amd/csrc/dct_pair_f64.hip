@@ -299,7 +299,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 //   1  level 2, even half: X = (SS, SD) | (EE, EO), Y = half bases of len/2          pairs = len/4, K = len/4
 //   2  level 2, odd half:  X = D | O (shared), Y = the two halves of the odd basis   pairs = len/4, K = len/2
 // x*, y*: k-blocked planes (y2 of kind 2 = y1 + 8 * len/4: the second row block of the same plane).
-int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, const double* x1, const double* x2,
+// sub (forward only): the launch belongs to the transform of length len >> sub that a deeper folding level
+// applies to the even part (its frequencies are multiples of 2^sub of the full transform's).
+int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep) {
     if (n_frames == 0) return SSW_OK;
@@ -308,15 +310,18 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     const size_t len = is_row ? w : h;
     if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned L = (unsigned)lines;
-    const unsigned NP = (unsigned)(kind == 0 ? len / 2 : len / 4);
-    const unsigned Kp = (unsigned)(kind == 1 ? pair_kpad<double>(len / 2) : pair_kpad<double>(len));
+    if (sub < 0 || sub > 8 || (sub > 0 && (inverse || kind == 0))) return SSW_ERR_BAD_ARG;
+    const size_t leff = len >> sub;                           // length of the (sub-)transform this launch serves
+    const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
+    const unsigned NP = (unsigned)(kind == 0 ? leff / 2 : leff / 4);
+    const unsigned Kp = (unsigned)(kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
     const unsigned BM = 128, BN = 64;
     const unsigned tiles_m = (L + BM - 1) / BM, tiles_n = (NP + BN - 1) / BN;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)len, 0, 1, 2};
-    if (kind == 1) { po.c1 = 0; po.c2 = 2; po.cs = 4; }
-    if (kind == 2) { po.c1 = 1; po.c2 = 1 + 2 * NP; po.cs = 2; }
+    if (kind == 1) { po.c1 = 0; po.c2 = 2 * fs; po.cs = 4 * fs; }
+    if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     if ((unsigned long long)Kp * L * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
 #define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) pair_gemm_f64_kernel<COLS, EPI, SAMEX><<<(unsigned)nblk, PT, 0, st>>>( \

@@ -326,6 +326,84 @@ __global__ __launch_bounds__(256) void pair_prep4_rows_rgb_kernel(const void* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// Three folding levels on a forward row pass (n % 32 == 0): the even part of the even part folds once
+// more.  With S = fold(x) (length n/2), SS = fold(S) (n/4), SSS = fold(SS) (n/8):
+//   R1 = SSS, R2 = SS - mirror (-> frequencies 0, 4 mod 8; width kpad(n/4))
+//   M  = S - mirror            (-> frequencies 2 mod 4;    width kpad(n/2))
+//   P  = x - mirror            (-> odd frequencies;        width kpad(n))
+// One thread = one quad e < n/8 of one line: it reads the 8 quads of x that meet in it.  The source is
+// an f32 plane or the interleaved RGB frame (Y formed on the fly, I / Q written for the writer).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int SRC /*0 plane, 1 rgb f32, 2 rgb u8*/, bool WITH_IQ>
+__global__ __launch_bounds__(256) void pair_prep8_rows_kernel(const void* __restrict__ SRCP, T* __restrict__ R1,
+                                                             T* __restrict__ R2, T* __restrict__ M, T* __restrict__ P,
+                                                             float* __restrict__ IP, float* __restrict__ QP,
+                                                             unsigned rows, unsigned W, unsigned K8, unsigned Kq, unsigned Kp,
+                                                             unsigned tiles_e) {
+    const unsigned Nh = W / 2, Nq = W / 4, Ne = W / 8;
+    const unsigned e0 = (blockIdx.x % tiles_e) * 32 + (threadIdx.x & 7) * 4;
+    const unsigned row = (blockIdx.x / tiles_e) * 32 + (threadIdx.x >> 3);
+    if (row >= rows || e0 >= K8) return;
+    vec4_t<T> r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
+    if (e0 < Ne) {                                                // Ne % 4 == 0
+        // quads of x, ascending positions; quad u mirrors quad 7 - u
+        const unsigned pos[8] = {e0, Nq - 4 - e0, Nq + e0, Nh - 4 - e0, Nh + e0, 3 * Nq - 4 - e0, 3 * Nq + e0, W - 4 - e0};
+        f32x4 x[8];
+        if (SRC == 0) {
+            const float* xr = static_cast<const float*>(SRCP) + (size_t)row * W;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(xr + pos[u]);
+        } else {
+            const void* base = SRC == 2 ? static_cast<const void*>(static_cast<const uint8_t*>(SRCP) + (size_t)row * W * 3)
+                                        : static_cast<const void*>(static_cast<const float*>(SRCP) + (size_t)row * W * 3);
+            f32x4 iv, qv;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                load_yiq4<SRC == 2, WITH_IQ>(base, pos[u], x[u], iv, qv);
+                if (WITH_IQ) {
+                    *reinterpret_cast<f32x4*>(IP + (size_t)row * W + pos[u]) = iv;
+                    *reinterpret_cast<f32x4*>(QP + (size_t)row * W + pos[u]) = qv;
+                }
+            }
+        }
+        // level 1: S and D1 at the positions of quads 0..3 (their mirrors are quads 7..4, reversed)
+        vec4_t<T> S[4], D1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                S[u][i] = (T)x[u][i] + (T)x[7 - u][3 - i];
+                D1[u][i] = (T)x[u][i] - (T)x[7 - u][3 - i];
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(row, pos[u], rows)) = D1[u];
+        // level 2 on S (length n/2): quad 0 mirrors quad 3, quad 1 mirrors quad 2
+        vec4_t<T> SS[2], D2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                SS[u][i] = S[u][i] + S[3 - u][3 - i];
+                D2[u][i] = S[u][i] - S[3 - u][3 - i];
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<vec4_t<T>*>(M + blk_index<T>(row, pos[u], rows)) = D2[u];
+        // level 3 on SS (length n/4): quad 0 mirrors quad 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r1[i] = SS[0][i] + SS[1][3 - i];
+            r2[i] = SS[0][i] - SS[1][3 - i];
+        }
+    }
+    *reinterpret_cast<vec4_t<T>*>(R1 + blk_index<T>(row, e0, rows)) = r1;
+    *reinterpret_cast<vec4_t<T>*>(R2 + blk_index<T>(row, e0, rows)) = r2;
+    if (e0 == 0) {
+        for (unsigned z = Nh; z < Kp; z += 4) *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(row, z, rows)) = (vec4_t<T>){0, 0, 0, 0};
+        for (unsigned z = Nq; z < Kq; z += 4) *reinterpret_cast<vec4_t<T>*>(M + blk_index<T>(row, z, rows)) = (vec4_t<T>){0, 0, 0, 0};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
 size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h) {
@@ -430,6 +508,36 @@ int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, bool u8, const void
                                    void* q1, void* q2, void* p, float* ip, float* qp) {
     return f64 ? prep4_rgb_impl<double>(st, u8, rgb, n_frames, w, h, (double*)q1, (double*)q2, (double*)p, ip, qp)
                : prep4_rgb_impl<float>(st, u8, rgb, n_frames, w, h, (float*)q1, (float*)q2, (float*)p, ip, qp);
+}
+
+template <typename T>
+static int prep8_impl(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h,
+                      T* r1, T* r2, T* m, T* p, float* ip, float* qp) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned Kp = (unsigned)pair_kpad<T>(w), Kq = (unsigned)pair_kpad<T>(w / 2), K8 = (unsigned)pair_kpad<T>(w / 4);
+    const unsigned tiles_e = (K8 + 31) / 32;
+    const size_t rows = n_frames * h;
+    const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_e;
+    if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const bool iq = ip && qp;
+#define SSW_PREP8(SRCV, IQV) pair_prep8_rows_kernel<T, SRCV, IQV><<<(unsigned)nblk, 256, 0, st>>>( \
+        src, r1, r2, m, p, ip, qp, (unsigned)rows, (unsigned)w, K8, Kq, Kp, tiles_e)
+    if (src_kind == 0) SSW_PREP8(0, false);
+    else if (src_kind == 1) { if (iq) SSW_PREP8(1, true); else SSW_PREP8(1, false); }
+    else                    { if (iq) SSW_PREP8(2, true); else SSW_PREP8(2, false); }
+#undef SSW_PREP8
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// third folding level along an axis of length len (forward row passes only)
+bool dct_pair_can_fold3(size_t len) { return len % 32 == 0 && len >= 128; }
+// src_kind: 0 = f32 plane, 1 = interleaved RGB f32, 2 = interleaved RGB u8 (ip / qp: I, Q planes out or null)
+int launch_dct_pair_prep8_rows(hipStream_t st, bool f64, int src_kind, const void* src, size_t n_frames, size_t w, size_t h,
+                               void* r1, void* r2, void* m, void* p, float* ip, float* qp) {
+    return f64 ? prep8_impl<double>(st, src_kind, src, n_frames, w, h, (double*)r1, (double*)r2, (double*)m, (double*)p, ip, qp)
+               : prep8_impl<float>(st, src_kind, src, n_frames, w, h, (float*)r1, (float*)r2, (float*)m, (float*)p, ip, qp);
 }
 
 }  // namespace ssw

@@ -103,11 +103,16 @@ int launch_dct_pair_prep4(hipStream_t st, bool f64, bool is_row, bool inverse, c
 bool dct_pair_can_prep_from_rgb(size_t w, size_t h, const void* rgb, bool u8);
 int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, bool u8, const void* rgb, size_t n_frames, size_t w, size_t h,
                                    void* q1, void* q2, void* p, float* ip, float* qp);
-// kind 0: one folding level; 1 / 2: the even / odd half of two levels (see dct_pair_f64.hip)
-int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, const double* x1, const double* x2,
+// three levels on a forward row pass: (SSS, SS-) [kpad(w/4) wide], S- [kpad(w/2)], x- [kpad(w)] from an f32
+// plane (src_kind 0) or interleaved RGB f32 / u8 (1 / 2; ip / qp: I, Q planes out or null)
+bool dct_pair_can_fold3(size_t len);
+int launch_dct_pair_prep8_rows(hipStream_t st, bool f64, int src_kind, const void* src, size_t n_frames, size_t w, size_t h,
+                               void* r1, void* r2, void* m, void* p, float* ip, float* qp);
+// kind 0: one folding level; 1 / 2: the even / odd half of two levels; sub: see dct_pair_f64.hip
+int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep);
-int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, const float* x1, const float* x2,
+int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const float* x1, const float* x2,
                              const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep);
 
@@ -173,7 +178,7 @@ struct ssw_ctx {
     std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
     bool fold = true;             // use the even/odd-folded GEMMs where the shape allows
     int fold_level = SSW_DCT_FOLDING_DEFAULT;           // 2 (opt-in): also fold the even half once more where a kernel exists (f64 forward rows)
-                                  // 3: f64 passes read pre-folded f64 operand planes (dct_pair_f64.hip); 4: the same, two levels
+                                  // 3: operand-ready GEMMs (dct_pair_*.hip); 4: two levels; 5: + a third on long forward row passes; 6: on all
 
     // growable scratch
     struct Buf {

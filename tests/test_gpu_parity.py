@@ -163,12 +163,13 @@ def test_dct_second_folding_level_is_bit_identical(shape, dct_type):
 
 
 @pytest.mark.parametrize("shape", [(16, 16), (24, 40), (40, 128), (72, 136), (136, 72), (200, 328), (264, 8),
-                                   (64, 64), (80, 208), (208, 80), (144, 1040), (1080, 1920)])
+                                   (64, 64), (80, 208), (208, 80), (144, 1040), (72, 128), (40, 160), (1080, 1920)])
 @pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
-@pytest.mark.parametrize("level", [3, 4])
+@pytest.mark.parametrize("level", [3, 4, 6])
 def test_dct_operand_ready_path_matches(shape, dct_type, level):
     """Pre-folded f64 operand planes + VALU-free GEMM loop (folding level 3; level 4 folds the even
-    half once more wherever the axis length is a multiple of 16): same exact operands and f64
+    half once more wherever the axis length is a multiple of 16; level 6 a third time on forward row
+    passes whose length is a multiple of 32 -- the default, 5, does that from 3072 columns): same exact operands and f64
     products as the in-kernel folding, only the summation order differs, so the rounded result
     must agree with it and with the oracle."""
     rng = np.random.default_rng(shape[0] * 5 + shape[1])
@@ -188,7 +189,7 @@ def test_dct_operand_ready_path_matches(shape, dct_type, level):
 
 @pytest.mark.parametrize("shape", [(24, 40), (72, 136), (136, 72), (80, 208), (144, 1040), (1080, 1920)])
 @pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
-@pytest.mark.parametrize("level", [1, 3, 4])
+@pytest.mark.parametrize("level", [1, 3, 4, 6])
 def test_dct_f32_every_strategy_within_tolerance(shape, dct_type, level):
     """f32 precision: in-kernel folding (1) and the operand-ready GEMMs with one (3) / two (4) folding
     levels round differently (each folding level adds one rounding per operand sum) but all stay
@@ -558,8 +559,9 @@ def test_batch_path_equals_handles_and_oracle(precision):
 
 
 @pytest.mark.parametrize("precision", [F32, F64])
-@pytest.mark.parametrize("shape", [(80, 208), (144, 1040)])
-def test_batch_path_fused_colour_prepass_equals_handles(precision, shape):
+@pytest.mark.parametrize("shape", [(80, 208), (144, 1040), (72, 128)])
+@pytest.mark.parametrize("level", [5, 6])
+def test_batch_path_fused_colour_prepass_equals_handles(precision, shape, level):
     """Shapes that take the default GEMM strategy (W >= H, W % 16 == 0, H % 8 == 0): the batch entry
     points read the RGB frames in the first operand pre-pass (no f32 Y plane); the handle API converts
     first.  Same arithmetic, so coefficients, indices, marked frames and extraction are bit-identical --
@@ -569,6 +571,19 @@ def test_batch_path_fused_colour_prepass_equals_handles(precision, shape):
     rgb = G.synth(5, 1, n, w, h)
     marks = np.random.default_rng(3).standard_normal((n, k)).astype(np.float32)
     cfg = G.default_config(precision)
+    # level 6 = the default strategy without its 3072-column threshold for the third folding level, so that
+    # the three-level colour pre-pass is exercised at test sizes (W % 32 == 0 shapes); handles and batch
+    # calls use different contexts: set both
+    G.ctx().set_dct_folding(level)
+    wm.default_context().set_dct_folding(level)
+    try:
+        _fused_vs_handles(rgb, marks, cfg, precision, n, k)
+    finally:
+        G.ctx().set_dct_folding(True)
+        wm.default_context().set_dct_folding(True)
+
+
+def _fused_vs_handles(rgb, marks, cfg, precision, n, k):
     res = G.batch_embed(rgb, marks, cfg, want_coef=True, want_idx=True)
     ext, sims = G.batch_extract(rgb, res["rgb"], k, marks, cfg)
     for f in range(n):
