@@ -292,9 +292,11 @@ def main():
                         "kernel": ("pair_gemm_%s_kernel<rows, odd half>" if two_rows else "pair_gemm_%s_kernel<rows>") % prec_name,
                         "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(main_tf / peak, 4), "traffic": None,
+                        "instance": "ssw::pair_gemm_%s_kernel<false, %d, true, 0>" % (prec_name, 0),
                         "note": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency "
-                                 "half of the even/odd-folded basis GEMM) / its average duration; whole-pass rates incl. "
-                                 "the even-half launch in kernels.dct_rows")}
+                                 "half of the even/odd-folded basis GEMM) / its average duration (forward and inverse "
+                                 "launches; `instance` is the forward one's name in the rocprofv3 kernel stats); "
+                                 "whole-pass rates incl. the even-half launches in kernels.dct_rows")}
         else:
             roofline = {"bound": "mfma",
                         "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name

@@ -28,7 +28,8 @@ constexpr int QBK = 16;
 constexpr int QCHUNK = 16;              // k-steps per accumulation chunk (256 k)
 typedef PairOutT<float> PairOutF;
 
-template <bool COLS, int EPI, bool SAMEX>
+// SUB only names the instance (launches that serve a deeper folding level show up separately in profiles)
+template <bool COLS, int EPI, bool SAMEX, int SUB = 0>
 __global__ __launch_bounds__(QT, 2) void pair_gemm_f32_kernel(
     const float* __restrict__ X1g, const float* __restrict__ X2g, const float* __restrict__ Y1g,
     const float* __restrict__ Y2g, PairOutF po, unsigned L /*lines*/, unsigned NP /*pairs*/,
@@ -291,8 +292,10 @@ int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind
     if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     if ((unsigned long long)Kp * L * 4 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
-#define SSW_LAUNCH_PAIRF(COLS, EPI, SAMEX) pair_gemm_f32_kernel<COLS, EPI, SAMEX><<<(unsigned)nblk, QT, 0, st>>>( \
-        x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep)
+#define SSW_LAUNCH_PAIRF(COLS, EPI, SAMEX) do { \
+        if (sub == 0) pair_gemm_f32_kernel<COLS, EPI, SAMEX, 0><<<(unsigned)nblk, QT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep); \
+        else          pair_gemm_f32_kernel<COLS, EPI, SAMEX, 1><<<(unsigned)nblk, QT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep); \
+    } while (0)
     if (!inverse) {
         if (kind == 0) { if (is_row) SSW_LAUNCH_PAIRF(false, EPI_FWD_ADJ, false); else SSW_LAUNCH_PAIRF(true, EPI_FWD, false); }
         else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIRF(false, EPI_FWD, false); else SSW_LAUNCH_PAIRF(true, EPI_FWD, false); }

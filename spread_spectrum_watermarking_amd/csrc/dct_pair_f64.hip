@@ -41,7 +41,8 @@ typedef PairOutT<double> PairOut;
 // (one product's image operand feeds both basis operands; it is staged and read once).
 // (A 256-line x 32-pair block tile for pair counts that 64 divides badly -- 540 at 4K -- was measured:
 // equal on the shared-X launches, 10 % slower on the two-operand ones; not kept.)
-template <bool COLS, int EPI, bool SAMEX>
+// SUB only names the instance (launches that serve a deeper folding level show up separately in profiles)
+template <bool COLS, int EPI, bool SAMEX, int SUB = 0>
 __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     const double* __restrict__ X1g, const double* __restrict__ X2g, const double* __restrict__ Y1g,
     const double* __restrict__ Y2g, PairOut po, unsigned L /*lines*/, unsigned NP /*pairs*/,
@@ -324,8 +325,10 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     if ((unsigned long long)Kp * L * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
-#define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) pair_gemm_f64_kernel<COLS, EPI, SAMEX><<<(unsigned)nblk, PT, 0, st>>>( \
-        x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep)
+#define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) do { \
+        if (sub == 0) pair_gemm_f64_kernel<COLS, EPI, SAMEX, 0><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep); \
+        else          pair_gemm_f64_kernel<COLS, EPI, SAMEX, 1><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep); \
+    } while (0)
     if (!inverse) {
         if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD_ADJ, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
         else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
