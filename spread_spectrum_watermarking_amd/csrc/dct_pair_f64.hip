@@ -167,10 +167,19 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     // barrier taken) in the middle of step t, its global loads having been issued a step earlier.
     const unsigned nk = Kp / PBK;          // even and >= 2: Kp is a multiple of 16
     Frag fa, fb;
+    // k-steps 0 and 1 are requested together (one memory latency at the start of a tile, not two): step 1
+    // waits in registers that the fragments will use later
+    gload(1);
+    u32x4 nx1[XQ], nx2[XQ];
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) { nx1[q] = rx1[q]; if (!SAMEX) nx2[q] = rx2[q]; }
+    const u32x4 ny1 = ry1, ny2 = ry2;
     gload(0);
     lstore(B0{});
     __syncthreads();
-    gload(1);
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) { rx1[q] = nx1[q]; if (!SAMEX) rx2[q] = nx2[q]; }
+    ry1 = ny1; ry2 = ny2;
     fread(B0{}, B0{}, fa);
     // full step t on buffer CUR: needs t + 2 < nk
     // one LDS read behind each of the first MFMAs of a half-step (a burst of reads would stall the
