@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--k", type=int, default=1000)
-    ap.add_argument("--chunk", type=int, default=16, help="frames per internal pass (workspace = 4 planes x chunk)")
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="frames per internal pass (0 = the library's automatic choice, ~2^28 pixels; bounds the workspace)")
     ap.add_argument("--precision", choices=["f32", "f64"], default="f64",
                     help="headline precision: f64 = canonical (bit-parity with the CPU path), f32 = fast")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other precision")
@@ -147,6 +148,7 @@ def main():
     fold_level = 0 if args.no_fold else int(os.environ.get("SSW_FOLD_LEVEL", str(L.DCT_FOLDING_DEFAULT)))
     ctx.set_dct_folding(fold_level)
     W, H, K, B = args.width, args.height, args.k, args.batch
+    chunk_eff = min(args.chunk if args.chunk > 0 else max(1, (1 << 28) // (W * H)), B)   # mirrors effective_chunk() in the library
 
     # ---- inputs resident in HBM ------------------------------------------------------------------
     first_frame = rank * B                       # global frame index of this rank's shard (weak scaling)
@@ -275,7 +277,7 @@ def main():
             prep_gbs = gbs(per_pass, prep_passes, stage["dct_prep"]["ms"])
             kernels["dct_prep"] = {"gbs": round(prep_gbs, 1), "frac_hbm": round(prep_gbs / PEAK_HBM_GBS, 4),
                                    "ms_per_step": round(stage["dct_prep"]["ms"] / steps, 3)}
-        lines_per_launch = min(args.chunk, B) * H
+        lines_per_launch = chunk_eff * H
         if operand:
             # dominant launch: the row GEMM over the odd frequencies (all W/2 of them, K = W/2)
             main_ms, main_n = stage["dct_row_main"]["ms"], max(stage["dct_row_main"]["launches"], 1)
@@ -284,7 +286,7 @@ def main():
             kernels["dct_rows"]["main_launch"] = {"avg_ms": round(main_ms / main_n, 4), "launches": main_n,
                                                   "flop_per_launch": main_flop, "tflops": round(main_tf, 2)}
             cm_ms, cm_n = stage["dct_col_main"]["ms"], max(stage["dct_col_main"]["launches"], 1)
-            cm_flop = 2.0 * min(args.chunk, B) * W * (H / 2.0) * (H / 2.0)
+            cm_flop = 2.0 * chunk_eff * W * (H / 2.0) * (H / 2.0)
             kernels["dct_cols"]["main_launch"] = {"avg_ms": round(cm_ms / cm_n, 4), "launches": cm_n,
                                                   "flop_per_launch": cm_flop,
                                                   "tflops": round(cm_flop * cm_n / (cm_ms * 1e-3) / 1e12, 2) if cm_ms > 0 else 0.0}
@@ -312,7 +314,7 @@ def main():
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
             wl = pmc["workload"]
-            if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, min(args.chunk, B)) and roofline["kernel"] in pmc["kernels"]:
+            if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, chunk_eff) and roofline["kernel"] in pmc["kernels"]:
                 roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
                 roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
                 if operand:   # D operand plane in (W/2 elements per line), odd half basis, f32 odd outputs
@@ -320,7 +322,7 @@ def main():
                     roofline["algorithmic_bytes_per_launch"] = int(lines_per_launch * (W // 2) * esz + (W // 2) ** 2 * esz +
                                                                    lines_per_launch * (W // 2) * 4)
                 else:
-                    roofline["algorithmic_bytes_per_launch"] = int(min(args.chunk, B) * H * W * 8 +
+                    roofline["algorithmic_bytes_per_launch"] = int(chunk_eff * H * W * 8 +
                                                                    2 * (W // 2) ** 2 * (8 if prec_name == "f64" else 4))
         except (OSError, KeyError, ValueError):
             pass
@@ -367,7 +369,7 @@ def main():
             "config": {"workload": f"batch={B}/GPU {W}x{H} f32 frames, {K}-coeff mark, embed+extract+similarity "
                                    f"(per-GPU shard of configs[3]: batch=2048 3840x2160 across 8 GPUs)",
                        "frames_per_gpu": B, "width": W, "height": H, "k": K, "alpha": 0.1,
-                       "method": "Option2", "ordering": "Energy", "chunk_frames": args.chunk,
+                       "method": "Option2", "ordering": "Energy", "chunk_frames": chunk_eff,
                        "dct_folding_level": fold_level,
                        "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,

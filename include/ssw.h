@@ -104,8 +104,9 @@ int ssw_ctx_destroy(ssw_ctx* ctx);
 int ssw_ctx_synchronize(ssw_ctx* ctx);
 /* hipStream_t of the context, as an opaque pointer (for event timing by callers). */
 void* ssw_ctx_stream(ssw_ctx* ctx);
-/* Frames processed per internal pass of the batch entry points (bounds the
-   workspace: 4 planes * chunk).  Default 16. */
+/* Frames processed per internal pass of the batch entry points (bounds the workspace: 36 bytes per
+   pixel of a pass in the default GEMM strategy).  0 = automatic, the default: about 2^28 pixels per
+   pass (32 4K frames, 129 full-HD frames, 8 8K frames; 9.6 GB of workspace). */
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
 
 /* Even/odd folding of the basis GEMMs (fewer multiply-adds for the same transform; exact in f64,

@@ -171,7 +171,7 @@ int launch_widen_indices(hipStream_t st, const uint32_t* in, size_t n, uint64_t*
 struct ssw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    size_t chunk_frames = 16;
+    size_t chunk_frames = 0;      // frames per internal pass; 0 = automatic (~2^28 pixels)
 
     // basis cache: (N, inverse, f64, kind) -> device pointer; kind 0 = dense N x N,
     // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded kernels; 3 / 4 = the same, k-blocked (operand-ready GEMMs)

@@ -216,7 +216,7 @@ def test_dct_batched_equals_single(precision):
     try:
         batched = G.dct2d(x, L.DCT2, precision)
     finally:
-        G.ctx().set_chunk_frames(16)
+        G.ctx().set_chunk_frames(0)                      # back to automatic
     for f in range(5):
         assert np.array_equal(batched[f], G.dct2d(x[f], L.DCT2, precision))
 
@@ -540,7 +540,7 @@ def test_batch_path_equals_handles_and_oracle(precision):
         res = G.batch_embed(rgb, marks, cfg, want_coef=True, want_idx=True)
         ext, sims = G.batch_extract(rgb, res["rgb"], k, marks, cfg)
     finally:
-        G.ctx().set_chunk_frames(16)
+        G.ctx().set_chunk_frames(0)                      # back to automatic
     for f in range(n):
         wr = wm.Writer(rgb[f], wm.WriteConfig(precision=precision))
         assert np.array_equal(res["coef"][f], wr.coefficient_image())
