@@ -121,3 +121,23 @@ def test_gpu_attack_resize_flow(known_answers, marks, cat_images):
     o_back = O.resize_rgb8(O.resize_rgb8(o_wm8, w // 8, h // 8), w, h)
     _, o_sim = O.extract_frame(O.u8_to_f32(cat8), O.u8_to_f32(o_back), mark)
     assert abs(float(sims[0]) - o_sim) < 0.05                           # 8-bit flips of the marked frame
+
+
+@pytest.mark.gpu
+def test_gpu_attack_crop_flow(known_answers, marks, cat_images):
+    """tests/attack_crop.rs: embed and extract on the device, the 225x225 ROI composite on the host
+    (`imageops::replace` is a plain copy), against the oracle's run of the same flow."""
+    import gpu_util as G
+    cat8 = cat_images["cat"]
+    mark = marks["seed_2"]
+    x, y, rw, rh = known_answers["attack_crop"]["roi"]
+    wm8 = G.batch_embed_rgb8(cat8[None], mark[None])[0]
+    att = cat8.copy()
+    att[y:y + rh, x:x + rw] = wm8[y:y + rh, x:x + rw]
+    ext, sims = G.batch_extract_rgb8(cat8[None], att[None], 1000, mark[None])
+    assert sims[0] > 6.0                                                # reference: > 8.0 with its own JPEG decoder
+    o_wm8 = O.f32_to_u8(O.embed_frame(O.u8_to_f32(cat8), mark))
+    o_att = cat8.copy()
+    o_att[y:y + rh, x:x + rw] = o_wm8[y:y + rh, x:x + rw]
+    _, o_sim = O.extract_frame(O.u8_to_f32(cat8), O.u8_to_f32(o_att), mark)
+    assert abs(float(sims[0]) - o_sim) < 0.05                           # 8-bit flips of the marked frame
