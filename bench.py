@@ -230,7 +230,7 @@ def main():
         # which strategy each pass runs (mirrors dct2d_planes in csrc/ssw_lib.hip)
         operand = fold_level >= 3 and fold_rows and fold_cols
         two_rows = operand and fold_level >= 4 and W % 16 == 0 and W >= 64
-        two_cols = operand and fold_level >= 4 and H % 16 == 0 and H >= 64
+        two_cols = operand and fold_level >= 4 and H % 8 == 0 and H >= 64       # the transposing pre-pass needs H/4 even only
         three_rows = two_rows and W % 32 == 0 and W >= 128 and (fold_level >= 6 or (fold_level == 5 and W >= 3072))
         row_frac = 0.375 if two_rows else (0.5 if fold_rows else 1.0)
         if three_rows:                               # the three forward transforms of a step: 11/32; the inverse: 3/8

@@ -118,8 +118,8 @@ int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
      3  "operand-ready" GEMMs -- HBM-bound pre-passes write the folded operands once per pass as
         k-blocked planes in the GEMM's precision and the MFMA loop issues no VALU instruction
         (csrc/dct_pair_f64.hip, dct_pair_f32.hip, dct_pair_prep.hip); one level
-     4  level 3 with the even half folded once more wherever the axis length is a multiple of 16
-        (3/8 of the dense MACs on that axis)
+     4  level 3 with the even half folded once more on row passes with W % 16 == 0 and column
+        passes with H % 8 == 0 (3/8 of the dense MACs on that axis)
      5  default.  Level 4 plus a third folding level on forward row passes of at least 3072 columns
         (a multiple of 32): 11/32 of the dense MACs there
      6  level 5 without the size threshold (shorter rows lose more to the extra small launches than

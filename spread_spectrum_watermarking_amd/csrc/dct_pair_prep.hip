@@ -227,7 +227,17 @@ __global__ __launch_bounds__(256) void pair_prep4_cols_kernel(const float* __res
             const size_t line = (size_t)z * W + c, lines = (size_t)n_frames * W;
             *reinterpret_cast<vec4_t<T>*>(Q1 + blk_index<T>(line, q, lines)) = (vec4_t<T>){sA[cl][kq], sA[cl][kq + 1], sA[cl][kq + 2], sA[cl][kq + 3]};
             *reinterpret_cast<vec4_t<T>*>(Q2 + blk_index<T>(line, q, lines)) = (vec4_t<T>){sB[cl][kq], sB[cl][kq + 1], sB[cl][kq + 2], sB[cl][kq + 3]};
-            if (q < Hq) {
+            if (q < Hq && q + 4 > Hq) {                             // H/4 not a multiple of 4: the last quad is partial
+                for (unsigned e = 0; q + e < Hq; ++e) {
+                    if (!INVERSE) {
+                        P[blk_index<T>(line, q + e, lines)] = sC[cl][kq + e];
+                        P[blk_index<T>(line, Hh - 1 - (q + e), lines)] = sD[cl][kq + e];
+                    } else {
+                        P[blk_index<T>(line, 2 * (q + e), lines)] = sC[cl][kq + e];
+                        P[blk_index<T>(line, 2 * (q + e) + 1, lines)] = sD[cl][kq + e];
+                    }
+                }
+            } else if (q < Hq) {
                 if (!INVERSE) {
                     *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, q, lines)) = (vec4_t<T>){sC[cl][kq], sC[cl][kq + 1], sC[cl][kq + 2], sC[cl][kq + 3]};
                     *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, Hh - 4 - q, lines)) = (vec4_t<T>){sD[cl][kq + 3], sD[cl][kq + 2], sD[cl][kq + 1], sD[cl][kq]};
@@ -416,8 +426,10 @@ bool dct_pair_can_run(bool f64, size_t n_frames, size_t w, size_t h, const float
     return dct_rows_can_fold(w, in, out) && dct_cols_can_fold(w, h, in, out) && w % 8 == 0 && h % 8 == 0 &&
            dct_pair_operand_elems(f64, n_frames, w, h) * (f64 ? 8 : 4) <= 0xFFFFFFFFull;
 }
-// second level along an axis of length len: quarter length a multiple of 4, at least one k-step pair
+// second level along an axis of length len: quarter length a multiple of 4 (row passes read quads of a
+// line; the transposing column pre-pass only needs an even quarter), at least one k-step pair
 bool dct_pair_can_fold2(size_t len) { return len % 16 == 0 && len >= 64; }
+bool dct_pair_can_fold2_cols(size_t len) { return len % 8 == 0 && len >= 64; }
 
 template <typename T>
 static int prep_impl(hipStream_t st, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w, size_t h,

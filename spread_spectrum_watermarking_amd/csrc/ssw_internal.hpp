@@ -91,6 +91,7 @@ size_t dct_pair_kpad(bool f64, size_t n);                               // row s
 size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h);   // elements per operand plane
 bool dct_pair_can_run(bool f64, size_t n_frames, size_t w, size_t h, const float* in, const float* out);
 bool dct_pair_can_fold2(size_t len);
+bool dct_pair_can_fold2_cols(size_t len);   // column passes: H % 8 == 0 suffices (1080 rows)
 int launch_make_half_basis_blocked(hipStream_t st, bool f64, size_t n, bool inverse, int parity, void* out);
 // one level: (S, D) forward / (E, O) inverse
 int launch_dct_pair_prep(hipStream_t st, bool f64, bool is_row, bool inverse, const float* in, size_t n_frames, size_t w,

@@ -199,7 +199,7 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
         if (operand) {
             const size_t esz = f64 ? sizeof(double) : sizeof(float);
             const size_t bytes = dct_pair_operand_elems(f64, n, w, h) * esz;
-            const bool two = ctx->fold_level >= 4 && dct_pair_can_fold2(len);
+            const bool two = ctx->fold_level >= 4 && (is_row ? dct_pair_can_fold2(len) : dct_pair_can_fold2_cols(len));
             const int st_pass = is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL;
             const int st_main = is_row ? SSW_STAGE_DCT_ROW_MAIN : SSW_STAGE_DCT_COL_MAIN;
             auto gemm = [&](int kind, const void* x1, const void* x2, const void* y1, const void* y2, void* tmpE, int sub = 0) {
