@@ -236,8 +236,6 @@ def main():
         if three_rows:                               # the three forward transforms of a step: 11/32; the inverse: 3/8
             row_frac = (3 * 11.0 / 32.0 + 0.375) / 4.0
         col_frac = 0.375 if two_cols else (0.5 if fold_cols else 1.0)
-        if not operand and fold_rows and prec_name == "f64" and fold_level == 2 and W % 16 == 0 and W >= 64:
-            row_frac = (3 * 0.375 + 1 * 0.5) / 4.0   # in-kernel second level: the three forward row passes of a step
         row_flops, col_flops = row_dense * row_frac, col_dense * col_frac
         esz = 8.0 if prec_name == "f64" else 4.0
         fused_rgb = bool(two_rows and W >= H)        # the three forward transforms of a step start from RGB
@@ -301,8 +299,7 @@ def main():
                                  "whole-pass rates incl. the even-half launches in kernels.dct_rows")}
         else:
             roofline = {"bound": "mfma",
-                        "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name
-                                  + (" + dct_rows_fold2_fwd_f64_kernel (forward passes)" if row_frac not in (0.5, 1.0) else ""),
+                        "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name,
                         "achieved": round(row_tf, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(row_tf / peak, 4), "traffic": None,
                         "note": ("executed flop per launch (even/odd-folded basis: half the dense 2*rows*W*W) / average "

@@ -102,8 +102,26 @@ void ssw_config_default(ssw_config* cfg);
 int ssw_ctx_create(int device_id, ssw_ctx** out);
 int ssw_ctx_destroy(ssw_ctx* ctx);
 int ssw_ctx_synchronize(ssw_ctx* ctx);
-/* hipStream_t of the context, as an opaque pointer (for event timing by callers). */
+/* Stream contract.  Every entry point that takes "dev" pointers (ssw_rgb_to_yiq ... ssw_batch_*,
+   ssw_resize_rgb8, ssw_synth_frames) only ENQUEUES work on the context's stream and returns; by default
+   that is a private hipStreamNonBlocking stream, which is ordered neither against the null stream nor
+   against e.g. torch's current stream.  The caller must therefore
+     (1) make sure its inputs are complete before the call -- synchronise its producer, or hand the
+         library an event to wait for (ssw_ctx_wait_event), or put the library on its own stream
+         (ssw_ctx_set_stream);
+     (2) treat outputs as valid only after ssw_ctx_synchronize(), or after an event recorded with
+         ssw_ctx_record_event() has completed, or in later work on the stream given to ssw_ctx_set_stream.
+   Entry points that take HOST buffers (the Writer / Reader / Tester handles, ssw_copy_*) synchronise
+   before they return.  Calls change the calling thread's current HIP device only for their duration. */
+/* hipStream_t the context currently enqueues on, as an opaque pointer. */
 void* ssw_ctx_stream(ssw_ctx* ctx);
+/* Enqueue on the caller's hipStream_t from now on (NULL: back to the private stream).  Synchronises the
+   stream used so far.  The stream must belong to the context's GPU and outlive its use here. */
+int ssw_ctx_set_stream(ssw_ctx* ctx, void* hip_stream);
+/* hipStreamWaitEvent / hipEventRecord on the context's stream with the caller's hipEvent_t: chain the
+   library behind a producer, or a consumer behind the library, without a host synchronisation. */
+int ssw_ctx_wait_event(ssw_ctx* ctx, void* hip_event);
+int ssw_ctx_record_event(ssw_ctx* ctx, void* hip_event);
 /* Frames processed per internal pass of the batch entry points (bounds the workspace: 36 bytes per
    pixel of a pass in the default GEMM strategy).  0 = automatic, the default: about 2^28 pixels per
    pass (32 4K frames, 129 full-HD frames, 8 8K frames; 9.6 GB of workspace). */
@@ -114,7 +132,7 @@ int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
    Strategy levels:
      0  dense GEMMs
      1  one folding level inside the GEMM kernel (1/2 of the dense MACs)
-     2  level 1 + a second in-kernel level for the f64 forward row pass (3/8 of the dense MACs)
+     2  same as 1 (the in-kernel second level of round 1 was superseded by level 4 and removed)
      3  "operand-ready" GEMMs -- HBM-bound pre-passes write the folded operands once per pass as
         k-blocked planes in the GEMM's precision and the MFMA loop issues no VALU instruction
         (csrc/dct_pair_f64.hip, dct_pair_f32.hip, dct_pair_prep.hip); one level
@@ -208,9 +226,10 @@ int ssw_similarity_matrix(ssw_ctx* ctx, const float* dev_extracted, size_t n_ext
 /* ---- whole path, batched & device-resident (the bench path) ---------------- */
 /* Writer::new + Writer::mark for n_frames frames (algorithm.rs:295-316, :355-379):
    rgb -> yiq -> DCT2 -> top-k -> embed -> DCT3 -> rgb.  One mark of length k per
-   frame: dev_marks [n_frames][k].  Optional outputs (may be NULL):
+   frame: dev_marks [n_frames][k].  A mark longer than w*h-1 is cut at w*h-1 entries like the
+   reference's zip() does (:396); the stride of dev_marks stays k.  Optional outputs (may be NULL):
    dev_coef_out [n_frames][h][w] = Writer::coefficient_image() before embedding,
-   dev_indices_out [n_frames][k]. */
+   dev_indices_out [n_frames][min(k, w*h-1)]. */
 int ssw_batch_embed(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_rgb, size_t n_frames,
                     size_t w, size_t h, const float* dev_marks, size_t k, float* dev_rgb_out,
                     float* dev_coef_out, uint32_t* dev_indices_out);
@@ -250,7 +269,9 @@ int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
                       const ssw_config* cfg, ssw_writer** out);
 /* Writer::coefficient_image(), src/algorithm.rs:319-321 -> host [h][w]. */
 int ssw_writer_coefficients(ssw_writer* wr, float* out_plane);
-/* Writer::embed(&mut self, marks), src/algorithm.rs:348-352.  marks[m] has lens[m] floats (host). */
+/* Writer::embed(&mut self, marks), src/algorithm.rs:348-352.  marks[m] has lens[m] floats (host).
+   The ordering is the one Writer::new fixed from the ORIGINAL coefficients (:314): a second embed()
+   (the reference says "call once", but allows it) still ranks the original plane, not the modified one. */
 int ssw_writer_embed(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks);
 /* Writer::result(self), src/algorithm.rs:361-379 -> host [h][w][3]; consumes the writer. */
 int ssw_writer_result(ssw_writer* wr, float* out_rgb_hwc);

@@ -15,7 +15,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libssw_oracle.so")
+# SSW_ORACLE_LIB: load another build of the same source (the ASan/UBSan one of `make sanitize`)
+_LIB_PATH = os.environ.get("SSW_ORACLE_LIB") or os.path.join(_HERE, "libssw_oracle.so")
 
 DCT2, DCT2_ORTHOGONAL, DCT3 = 0, 1, 2
 BACKEND_F64, BACKEND_F32, BACKEND_NAIVE_F64 = 0, 1, 2

@@ -51,12 +51,23 @@ class Context:
     def synchronize(self):
         check(self._lib.ssw_ctx_synchronize(self.handle), "ssw_ctx_synchronize")
 
+    def set_stream(self, hip_stream=None):
+        """Enqueue on the caller's hipStream_t (an int / c_void_p, e.g. torch.cuda.current_stream().cuda_stream);
+        None returns to the context's private stream.  See the stream contract in include/ssw.h."""
+        check(self._lib.ssw_ctx_set_stream(self.handle, C.c_void_p(hip_stream) if hip_stream else None), "ssw_ctx_set_stream")
+
+    def wait_event(self, hip_event):
+        check(self._lib.ssw_ctx_wait_event(self.handle, C.c_void_p(hip_event)), "ssw_ctx_wait_event")
+
+    def record_event(self, hip_event):
+        check(self._lib.ssw_ctx_record_event(self.handle, C.c_void_p(hip_event)), "ssw_ctx_record_event")
+
     def set_chunk_frames(self, n: int):
         check(self._lib.ssw_ctx_set_chunk_frames(self.handle, n), "ssw_ctx_set_chunk_frames")
 
     def set_dct_folding(self, level=True):
-        """Basis-GEMM strategy (include/ssw.h): False / 0 dense; 1 / 2 folding inside the GEMM kernel
-        (one level / a second one for the f64 forward row pass); 3 / 4 operand-ready GEMMs with one / two
+        """Basis-GEMM strategy (include/ssw.h): False / 0 dense; 1 (= 2) one folding level inside the GEMM
+        kernel; 3 / 4 operand-ready GEMMs with one / two
         folding levels; 5 a third level on long forward row passes; 6 the same without the size
         threshold.  True selects the default (5)."""
         lvl = (L.DCT_FOLDING_DEFAULT if level else 0) if isinstance(level, bool) else int(level)

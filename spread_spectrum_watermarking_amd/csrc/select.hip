@@ -466,7 +466,7 @@ __global__ __launch_bounds__(256) void embed_kernel(float* __restrict__ coef, si
                                                     const float* __restrict__ marks,
                                                     const uint32_t* __restrict__ mark_offsets,
                                                     const uint32_t* __restrict__ mark_lens, size_t n_marks,
-                                                    size_t max_len, int method, float alpha) {
+                                                    size_t max_len, size_t mark_stride, int method, float alpha) {
     const size_t f = blockIdx.y;
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= max_len) return;
@@ -474,13 +474,13 @@ __global__ __launch_bounds__(256) void embed_kernel(float* __restrict__ coef, si
     float* c = coef + f * plane_len + j;
     const float original = *c;
     if (n_marks == 1) {                                                     // :394-398
-        const size_t off = mark_offsets ? mark_offsets[f] : f * max_len;
+        const size_t off = mark_offsets ? mark_offsets[f] : f * mark_stride;
         const size_t len = mark_lens ? mark_lens[f] : max_len;
         if (i < len) *c = insert_fn(method, alpha, original, marks[off + i]);
     } else {                                                                // :399-408
         float cur = original;
         for (size_t m = 0; m < n_marks; ++m) {
-            const size_t off = mark_offsets ? mark_offsets[f * n_marks + m] : (f * n_marks + m) * max_len;
+            const size_t off = mark_offsets ? mark_offsets[f * n_marks + m] : (f * n_marks + m) * mark_stride;
             const size_t len = mark_lens ? mark_lens[f * n_marks + m] : max_len;
             if (i < len) {
                 const float updated = insert_fn(method, alpha, original, marks[off + i]);
@@ -495,11 +495,11 @@ __global__ __launch_bounds__(256) void embed_kernel(float* __restrict__ coef, si
 int launch_embed(hipStream_t st, float* coef, size_t n_frames, size_t plane_len,
                  const uint32_t* indices, size_t idx_stride, const float* marks,
                  const uint32_t* mark_offsets, const uint32_t* mark_lens, size_t n_marks,
-                 size_t max_len, int method, float alpha) {
+                 size_t max_len, size_t mark_stride, int method, float alpha) {
     if (n_frames == 0 || n_marks == 0 || max_len == 0) return SSW_OK;
     const dim3 grid((unsigned)((max_len + 255) / 256), (unsigned)n_frames);
     embed_kernel<<<grid, 256, 0, st>>>(coef, plane_len, indices, idx_stride, marks, mark_offsets,
-                                       mark_lens, n_marks, max_len, method, alpha);
+                                       mark_lens, n_marks, max_len, mark_stride, method, alpha);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -79,11 +79,6 @@ int launch_dct_rows_folded_f64(hipStream_t st, bool inverse, const float* in, fl
 int launch_dct_cols_folded_f64(hipStream_t st, bool inverse, const float* in, float* out, size_t n_frames,
                                size_t w, size_t h, const double* b_even, const double* b_odd, Epilogue ep);
 
-// dct_fold2_f64.hip: two-level folding (3/8 of the dense MACs), f64
-bool dct_rows_can_fold2(size_t w, const float* in, const float* out);
-int launch_dct_rows_fold2_fwd_f64(hipStream_t st, const float* in, float* out, size_t rows, size_t w,
-                                  const double* b_odd, const double* b_even_even, const double* b_even_odd, Epilogue ep);
-
 // dct_pair_prep.hip / dct_pair_f64.hip / dct_pair_f32.hip: "operand-ready" folded GEMMs (no VALU work in
 // the MFMA loop): pre-passes write the folded operands once per pass as k-blocked planes in the GEMM's
 // precision (f64 flag), the half bases are cached in the same layout.
@@ -155,7 +150,7 @@ int launch_full_sort(hipStream_t st, const float* coef, size_t w, size_t h, int 
 int launch_embed(hipStream_t st, float* coef, size_t n_frames, size_t plane_len,
                  const uint32_t* indices, size_t idx_stride, const float* marks,
                  const uint32_t* mark_offsets, const uint32_t* mark_lens, size_t n_marks,
-                 size_t max_len, int method, float alpha);
+                 size_t max_len, size_t mark_stride /* between marks when mark_offsets is null */, int method, float alpha);
 int launch_extract(hipStream_t st, const float* base, const float* derived, size_t n_frames,
                    size_t plane_len, const uint32_t* indices, size_t k, int method, float alpha,
                    float* out);
@@ -171,14 +166,15 @@ int launch_widen_indices(hipStream_t st, const uint32_t* in, size_t n, uint64_t*
 // ---- context ----------------------------------------------------------------
 struct ssw_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // where every call enqueues: own_stream, or the caller's (ssw_ctx_set_stream)
+    hipStream_t own_stream = nullptr;   // private non-blocking stream created with the context
     size_t chunk_frames = 0;      // frames per internal pass; 0 = automatic (~2^28 pixels)
 
     // basis cache: (N, inverse, f64, kind) -> device pointer; kind 0 = dense N x N,
     // 1 / 2 = even / odd half basis (N/2 x N/2) of the folded kernels; 3 / 4 = the same, k-blocked (operand-ready GEMMs)
     std::map<std::tuple<size_t, bool, bool, int>, void*> basis;
     bool fold = true;             // use the even/odd-folded GEMMs where the shape allows
-    int fold_level = SSW_DCT_FOLDING_DEFAULT;           // 2 (opt-in): also fold the even half once more where a kernel exists (f64 forward rows)
+    int fold_level = SSW_DCT_FOLDING_DEFAULT;           // 1 / 2: one folding level inside the GEMM kernel (dct_folded*.hip)
                                   // 3: operand-ready GEMMs (dct_pair_*.hip); 4: two levels; 5: + a third on long forward row passes; 6: on all
 
     // growable scratch

@@ -21,6 +21,12 @@ struct ssw_writer {
     size_t w, h;
     ssw_config cfg;
     float *y = nullptr, *i = nullptr, *q = nullptr;   // device planes; y holds the coefficients
+    // Writer::new fixes the ordering from the ORIGINAL coefficients (:314); it is materialised lazily, for
+    // the longest mark seen so far.  embed() keeps a snapshot of the original plane so that a later,
+    // longer embed() still ranks what Writer::new ranked (mark() consumes the writer and needs none).
+    float* y0 = nullptr;
+    uint32_t* idx = nullptr;
+    size_t idx_k = 0;
     bool consumed = false;
 };
 struct ssw_reader {
@@ -36,20 +42,39 @@ struct ssw_reader {
 // ---- small helpers --------------------------------------------------------------------------
 namespace {
 
+// Makes the context's GPU current for the duration of one ABI call and restores the caller's device
+// afterwards (a host thread may drive several contexts, or torch on another GPU).
 struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev) {
+    int prev = -1, dev;
+    explicit DeviceGuard(int d) : dev(d) {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) (void)hipSetDevice(dev);
     }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
+
+// Device allocation: a failing hipMalloc is reported as SSW_ERR_OUT_OF_MEMORY whatever code the runtime
+// chose for it, and the runtime's sticky error is cleared so that the next call starts clean.
+int dev_malloc(void** p, size_t bytes) {
+    *p = nullptr;
+    const hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e == hipSuccess) return SSW_OK;
+    (void)hipGetLastError();
+    *p = nullptr;
+    set_last_error(std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    return SSW_ERR_OUT_OF_MEMORY;
+}
+#define SSW_ALLOC(pp, bytes) SSW_TRY(dev_malloc((void**)(pp), (bytes)))
 
 int grow(ssw_ctx::Buf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return SSW_OK;
     if (b.p) { SSW_HIP_CHECK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
-    if (bytes == 0) bytes = 16;
-    SSW_HIP_CHECK(hipMalloc(&b.p, bytes));
-    b.bytes = bytes;
+    SSW_ALLOC(&b.p, bytes);
+    b.bytes = bytes ? bytes : 16;
     return SSW_OK;
 }
 
@@ -62,9 +87,9 @@ int grow_select(ssw_ctx* ctx, size_t frames, size_t k) {
     if (s.ctrl) (void)hipFree(s.ctrl);
     if (s.cand) (void)hipFree(s.cand);
     s = SelectWorkspace();
-    SSW_HIP_CHECK(hipMalloc((void**)&s.hist, nf * 2048 * sizeof(uint32_t)));
-    SSW_HIP_CHECK(hipMalloc((void**)&s.ctrl, nf * 4 * sizeof(uint32_t)));
-    SSW_HIP_CHECK(hipMalloc((void**)&s.cand, nf * cap * sizeof(uint64_t)));
+    SSW_ALLOC(&s.hist, nf * 2048 * sizeof(uint32_t));
+    SSW_ALLOC(&s.ctrl, nf * 4 * sizeof(uint32_t));
+    SSW_ALLOC(&s.cand, nf * cap * sizeof(uint64_t));
     SSW_HIP_CHECK(hipMemsetAsync(s.hist, 0, nf * 2048 * sizeof(uint32_t), ctx->stream));   // see select.hip:
     SSW_HIP_CHECK(hipMemsetAsync(s.ctrl, 0, nf * 4 * sizeof(uint32_t), ctx->stream));      // zero between uses
     s.frames = nf;
@@ -115,7 +140,7 @@ int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const vo
     if (it != ctx->basis.end()) { *out = it->second; return SSW_OK; }
     void* p = nullptr;
     const size_t elems = kind == 0 ? n * dense_basis_kpad(n) : kind >= 3 ? (n / 2) * dct_pair_kpad(f64, n) : (n / 2) * half_basis_kpad(n);
-    SSW_HIP_CHECK(hipMalloc(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float))));
+    SSW_ALLOC(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float)));
     int rc = kind >= 3 ? launch_make_half_basis_blocked(ctx->stream, f64, n, inverse, kind - 3, p)
              : kind != 0 ? (f64 ? launch_make_half_basis_f64(ctx->stream, n, inverse, kind - 1, (double*)p)
                               : launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p))
@@ -269,13 +294,6 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
                 StageTimer tm(ctx, st_main);
                 SSW_TRY(gemm(2, x2, x2, b1, bo2, tmpE));
             }
-        } else if (is_row && fold && f64 && !inverse && ctx->fold_level == 2 && dct_rows_can_fold2(w, src, dst)) {
-            const void *bee = nullptr, *beo = nullptr;
-            SSW_TRY(get_basis(ctx, w / 2, false, true, 1, &bee));       // even / odd half bases of W/2
-            SSW_TRY(get_basis(ctx, w / 2, false, true, 2, &beo));
-            StageTimer t(ctx, SSW_STAGE_DCT_ROW);
-            SSW_TRY(launch_dct_rows_fold2_fwd_f64(ctx->stream, src, dst, n * h, w, (const double*)b1,
-                                                  (const double*)bee, (const double*)beo, ep));
         } else if (is_row) {
             StageTimer t(ctx, SSW_STAGE_DCT_ROW);
             if (fold && f64) SSW_TRY(launch_dct_rows_folded_f64(ctx->stream, inverse, src, dst, n * h, w, (const double*)b0, (const double*)b1, ep));
@@ -355,8 +373,9 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
     ssw_ctx* ctx = new (std::nothrow) ssw_ctx();
     if (!ctx) return SSW_ERR_OUT_OF_MEMORY;
     ctx->device = device_id;
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; set_last_error(hipGetErrorString(e)); return SSW_ERR_HIP; }
+    ctx->stream = ctx->own_stream;
     *out = ctx;
     return SSW_OK;
 }
@@ -367,6 +386,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->basis) (void)hipFree(kv.second);
     for (auto& b : ctx->plane) if (b.p) (void)hipFree(b.p);
+    for (auto& b : ctx->operand) if (b.p) (void)hipFree(b.p);
     if (ctx->idx.p) (void)hipFree(ctx->idx.p);
     if (ctx->small.p) (void)hipFree(ctx->small.p);
     if (ctx->sort_scratch.p) (void)hipFree(ctx->sort_scratch.p);
@@ -377,7 +397,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     if (ctx->sel.cand) (void)hipFree(ctx->sel.cand);
     for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
-    (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SSW_OK;
 }
@@ -390,6 +410,29 @@ int ssw_ctx_synchronize(ssw_ctx* ctx) {
 }
 
 void* ssw_ctx_stream(ssw_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int ssw_ctx_set_stream(ssw_ctx* ctx, void* hip_stream) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_TRY(flush_timers(ctx));                                      // pending event pairs belong to the old stream
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));                // workspace in flight on the old stream
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return SSW_OK;
+}
+
+int ssw_ctx_wait_event(ssw_ctx* ctx, void* hip_event) {
+    if (!ctx || !hip_event) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)hip_event, 0));
+    return SSW_OK;
+}
+
+int ssw_ctx_record_event(ssw_ctx* ctx, void* hip_event) {
+    if (!ctx || !hip_event) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    SSW_HIP_CHECK(hipEventRecord((hipEvent_t)hip_event, ctx->stream));
+    return SSW_OK;
+}
 
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames) {
     if (!ctx) return SSW_ERR_BAD_ARG;
@@ -435,7 +478,7 @@ int ssw_ctx_get_timing(ssw_ctx* ctx, double* ms, uint64_t* launches) {
 int ssw_dev_alloc(ssw_ctx* ctx, size_t bytes, void** dev_ptr) {
     if (!ctx || !dev_ptr) return SSW_ERR_BAD_ARG;
     DeviceGuard g(ctx->device);
-    SSW_HIP_CHECK(hipMalloc(dev_ptr, bytes ? bytes : 16));
+    SSW_ALLOC(dev_ptr, bytes);
     return SSW_OK;
 }
 int ssw_dev_free(ssw_ctx* ctx, void* dev_ptr) {
@@ -512,7 +555,7 @@ int ssw_embed_coefficients(ssw_ctx* ctx, float* dev_coef, size_t n_frames, size_
     DeviceGuard g(ctx->device);
     StageTimer t(ctx, SSW_STAGE_EMBED);
     return launch_embed(ctx->stream, dev_coef, n_frames, plane_len, dev_indices, k, dev_marks, nullptr,
-                        nullptr, n_marks, k, method, alpha);
+                        nullptr, n_marks, k, k, method, alpha);
 }
 
 int ssw_extract_coefficients(ssw_ctx* ctx, const float* dev_base, const float* dev_derived,
@@ -577,8 +620,7 @@ int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, b
     SSW_TRY(check_config(cfg));
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
     const size_t plane = w * h;
-    const size_t k_eff = std::min(k, plane - 1);                       // zip() truncation, :396
-    if (k_eff != k) return SSW_ERR_UNSUPPORTED;                        // k > w*h-1 in the batch path: use the Writer handle
+    const size_t k_eff = std::min(k, plane - 1);                       // zip() truncation, :396: a longer mark is cut silently
     DeviceGuard g(ctx->device);
     const size_t chunk = effective_chunk(ctx, w, h, n_frames);
     for (int p = 0; p < 4; ++p) SSW_TRY(grow(ctx->plane[p], chunk * plane * sizeof(float)));
@@ -598,7 +640,7 @@ int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, b
             SSW_TRY(topk(ctx, y, n, w, h, cfg->ordering, k_eff, idx));                  // :314 (first k only)
             StageTimer t(ctx, SSW_STAGE_EMBED);                                         // :356
             SSW_TRY(launch_embed(ctx->stream, y, n, plane, idx, k_eff, dev_marks + f0 * k, nullptr, nullptr,
-                                 1, k_eff, cfg->method, cfg->alpha));
+                                 1, k_eff, k, cfg->method, cfg->alpha));
         }
         SSW_TRY(dct2d_planes(ctx, SSW_DCT3, cfg->precision, n, w, h, y, tmp));           // :368-374
         {
@@ -654,9 +696,9 @@ int get_taps(ssw_ctx* ctx, size_t in_len, size_t out_len, DeviceTaps* out) {
     build_resize_taps(in_len, out_len, host);
     DeviceTaps d;
     d.max_taps = host.max_taps;
-    SSW_HIP_CHECK(hipMalloc((void**)&d.left, out_len * sizeof(uint32_t)));
-    SSW_HIP_CHECK(hipMalloc((void**)&d.count, out_len * sizeof(uint32_t)));
-    SSW_HIP_CHECK(hipMalloc((void**)&d.weights, host.weights.size() * sizeof(float)));
+    SSW_ALLOC(&d.left, out_len * sizeof(uint32_t));
+    SSW_ALLOC(&d.count, out_len * sizeof(uint32_t));
+    SSW_ALLOC(&d.weights, host.weights.size() * sizeof(float));
     SSW_HIP_CHECK(hipMemcpy(d.left, host.left.data(), out_len * sizeof(uint32_t), hipMemcpyHostToDevice));
     SSW_HIP_CHECK(hipMemcpy(d.count, host.count.data(), out_len * sizeof(uint32_t), hipMemcpyHostToDevice));
     SSW_HIP_CHECK(hipMemcpy(d.weights, host.weights.data(), host.weights.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -744,8 +786,8 @@ int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
     if (!wr) return SSW_ERR_OUT_OF_MEMORY;
     wr->ctx = ctx; wr->w = w; wr->h = h; wr->cfg = *cfg;
     auto fail = [&](int rc) { ssw_writer_destroy(wr); return rc; };
-    if (hipMalloc((void**)&wr->y, plane * 4) != hipSuccess || hipMalloc((void**)&wr->i, plane * 4) != hipSuccess ||
-        hipMalloc((void**)&wr->q, plane * 4) != hipSuccess)
+    if (dev_malloc((void**)&wr->y, plane * 4) != SSW_OK || dev_malloc((void**)&wr->i, plane * 4) != SSW_OK ||
+        dev_malloc((void**)&wr->q, plane * 4) != SSW_OK)
         return fail(SSW_ERR_OUT_OF_MEMORY);
     int rc = grow(ctx->plane[3], std::max(plane * 3, plane) * sizeof(float));
     if (rc != SSW_OK) return fail(rc);
@@ -770,7 +812,7 @@ int ssw_writer_coefficients(ssw_writer* wr, float* out_plane) {
     return ssw_copy_to_host(wr->ctx, out_plane, wr->y, wr->w * wr->h * sizeof(float));
 }
 
-int ssw_writer_embed(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks) {
+static int writer_embed_impl(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks, bool keep_original) {
     if (!wr || (n_marks && (!marks || !lens))) return SSW_ERR_BAD_ARG;
     if (wr->consumed) return SSW_ERR_CONSUMED;
     ssw_ctx* ctx = wr->ctx;
@@ -796,16 +838,28 @@ int ssw_writer_embed(ssw_writer* wr, const float* const* marks, const size_t* le
     SSW_HIP_CHECK(hipMemcpyAsync(base, packed.data(), total * 4, hipMemcpyHostToDevice, ctx->stream));
     SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks, offs.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
     SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks + bytes_tab, lns.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
-    SSW_TRY(grow(ctx->idx, max_len * sizeof(uint32_t)));
-    SSW_TRY(topk(ctx, wr->y, 1, wr->w, wr->h, wr->cfg.ordering, max_len, (uint32_t*)ctx->idx.p));   // :314
+    if (keep_original && !wr->y0) {
+        SSW_ALLOC(&wr->y0, plane * sizeof(float));
+        SSW_HIP_CHECK(hipMemcpyAsync(wr->y0, wr->y, plane * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (max_len > wr->idx_k) {                                        // :314, from the original coefficients
+        if (wr->idx) { SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream)); SSW_HIP_CHECK(hipFree(wr->idx)); wr->idx = nullptr; wr->idx_k = 0; }
+        SSW_ALLOC(&wr->idx, max_len * sizeof(uint32_t));
+        SSW_TRY(topk(ctx, wr->y0 ? wr->y0 : wr->y, 1, wr->w, wr->h, wr->cfg.ordering, max_len, wr->idx));
+        wr->idx_k = max_len;
+    }
     {
         StageTimer t(ctx, SSW_STAGE_EMBED);
-        SSW_TRY(launch_embed(ctx->stream, wr->y, 1, plane, (uint32_t*)ctx->idx.p, max_len, (const float*)base,
+        SSW_TRY(launch_embed(ctx->stream, wr->y, 1, plane, wr->idx, max_len, (const float*)base,
                              (const uint32_t*)(base + bytes_marks), (const uint32_t*)(base + bytes_marks + bytes_tab),
-                             n_marks, max_len, wr->cfg.method, wr->cfg.alpha));
+                             n_marks, max_len, max_len, wr->cfg.method, wr->cfg.alpha));
     }
     SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // host staging vectors die here
     return SSW_OK;
+}
+
+int ssw_writer_embed(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks) {
+    return writer_embed_impl(wr, marks, lens, n_marks, true);
 }
 
 int ssw_writer_result(ssw_writer* wr, float* out_rgb_hwc) {
@@ -829,7 +883,7 @@ int ssw_writer_result(ssw_writer* wr, float* out_rgb_hwc) {
 
 int ssw_writer_mark(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks,
                     float* out_rgb_hwc) {
-    SSW_TRY(ssw_writer_embed(wr, marks, lens, n_marks));              // :356
+    SSW_TRY(writer_embed_impl(wr, marks, lens, n_marks, false));      // :356 (consumed next: no snapshot needed)
     return ssw_writer_result(wr, out_rgb_hwc);                        // :357
 }
 
@@ -840,6 +894,8 @@ int ssw_writer_destroy(ssw_writer* wr) {
     if (wr->y) (void)hipFree(wr->y);
     if (wr->i) (void)hipFree(wr->i);
     if (wr->q) (void)hipFree(wr->q);
+    if (wr->y0) (void)hipFree(wr->y0);
+    if (wr->idx) (void)hipFree(wr->idx);
     delete wr;
     return SSW_OK;
 }
@@ -861,7 +917,7 @@ int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, in
     if (!rd) return SSW_ERR_OUT_OF_MEMORY;
     rd->ctx = ctx; rd->w = w; rd->h = h; rd->is_base = is_base != 0; rd->cfg = c;
     auto fail = [&](int rc) { ssw_reader_destroy(rd); return rc; };
-    if (hipMalloc((void**)&rd->y, plane * 4) != hipSuccess) return fail(SSW_ERR_OUT_OF_MEMORY);
+    if (dev_malloc((void**)&rd->y, plane * 4) != SSW_OK) return fail(SSW_ERR_OUT_OF_MEMORY);
     int rc = grow(ctx->plane[3], plane * 3 * sizeof(float));
     if (rc != SSW_OK) return fail(rc);
     float* stage = (float*)ctx->plane[3].p;
@@ -890,7 +946,7 @@ static int reader_ensure_indices(ssw_reader* rd, size_t k) {
     if (k <= rd->idx_k) return SSW_OK;
     ssw_ctx* ctx = rd->ctx;
     if (rd->idx) { SSW_HIP_CHECK(hipFree(rd->idx)); rd->idx = nullptr; rd->idx_k = 0; }
-    SSW_HIP_CHECK(hipMalloc((void**)&rd->idx, k * sizeof(uint32_t)));
+    SSW_ALLOC(&rd->idx, k * sizeof(uint32_t));
     SSW_TRY(topk(ctx, rd->y, 1, rd->w, rd->h, rd->cfg.ordering, k, rd->idx));           // :493
     rd->idx_k = k;
     return SSW_OK;

@@ -1,0 +1,63 @@
+"""ASan + UBSan on the CPU-side code: the oracle's C restatement and the C++ host
+wrappers of include/ssw.hpp.  The GPU pool has no sanitizer support, so device code is covered by the
+bit-parity tests instead."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _runtime(name):
+    p = subprocess.run(["gcc", f"-print-file-name={name}"], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+def test_oracle_golden_suite_under_asan_ubsan():
+    """Builds oracle/_san/libssw_oracle.so (-fsanitize=address,undefined) and re-runs the oracle's golden /
+    known-answer tests against it in a child interpreter with the ASan runtime preloaded."""
+    asan = _runtime("libasan.so")
+    if asan is None:
+        pytest.skip("no libasan in this image")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "sanitize"], check=True)
+    env = dict(os.environ)
+    env.update({"LD_PRELOAD": asan, "SSW_ORACLE_LIB": os.path.join(ROOT, "oracle", "_san", "libssw_oracle.so"),
+                # CPython itself is not leak-clean; everything else aborts the child at the first report
+                "ASAN_OPTIONS": "detect_leaks=0:abort_on_error=1:halt_on_error=1",
+                "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1"})
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_oracle_golden.py"), os.path.join(ROOT, "tests", "test_attack_harness.py"),
+                        "-m", "not gpu"], capture_output=True, text=True, env=env, cwd=ROOT)
+    report = r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, report
+    assert "runtime error:" not in report and "AddressSanitizer" not in report, report
+
+
+def test_cpp_host_wrappers_under_asan_ubsan(tmp_path):
+    """include/ssw.hpp + tests/cpp/crate_surface_test.cpp compiled with ASan/UBSan.  Without a GPU the
+    program must end in the wrapper's exception path (SSW_ERR_NO_DEVICE -> wm::Error), exit code 1, with no
+    sanitizer report; on a GPU box the full flow runs under the sanitizers (host code only)."""
+    if _runtime("libasan.so") is None:
+        pytest.skip("no libasan in this image")
+    import numpy as np
+    libdir = os.path.join(ROOT, "spread_spectrum_watermarking_amd", "lib")
+    exe = str(tmp_path / "crate_surface_test_san")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer",
+                    "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "crate_surface_test.cpp"),
+                    "-o", exe, "-L", libdir, "-lssw_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    w, h, k = 64, 48, 20
+    rng = np.random.default_rng(1)
+    rng.random((h, w, 3), dtype=np.float32).tofile(tmp_path / "rgb.f32")
+    rng.standard_normal(k).astype(np.float32).tofile(tmp_path / "mark.f32")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe, str(tmp_path / "rgb.f32"), str(w), str(h), str(tmp_path / "mark.f32"), str(k),
+                        str(tmp_path / "marked.f32"), str(tmp_path / "ext.f32")], capture_output=True, text=True, env=env)
+    report = r.stdout[-2000:] + r.stderr[-2000:]
+    assert "runtime error:" not in report and "AddressSanitizer" not in report, report
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0, report
+    else:
+        assert r.returncode == 1 and "no HIP device" in r.stderr, report
