@@ -8,11 +8,18 @@ Inputs (frames, marks) are resident in HBM before the timed region starts.  Work
 across ranks (one process per GPU, no data-path collective: frames are independent) -> weak scaling.
 
 Contract: python bench.py --gpus N --steps K --warmup W   prints ONE JSON line on rank 0.
+  * under torchrun (WORLD_SIZE / RANK / LOCAL_RANK in the environment) this process is one rank;
+  * run plainly with --gpus N > 1 it is the LAUNCHER: it starts N rank processes of itself (before it
+    has made any GPU call -- it never touches the GPU) and exits with their status.
+--config {1,2,3,4} selects the BASELINE.json configuration of that index (default: the per-GPU shard of
+configs[3], the one the metric is quoted on).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +34,62 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 
 PEAK_F64_MFMA_TFLOPS = 78.6      # MI355X spec sheet: FP64 matrix
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured copy)
 
+# BASELINE.json "configs", quoted verbatim, and what bench.py runs for each (per GPU)
+BASELINE_CONFIGS = {
+    1: {"quote": "single 3840\u00d72160 f32 frame, 1000-coeff embed + IDCT round-trip on 1 MI355X",
+        "batch": 1, "width": 3840, "height": 2160, "k": 1000, "flow": "embed"},
+    2: {"quote": "batch=256 1920\u00d71080 frames, embed+extract+similarity, 1 MI355X (HBM-roofline report)",
+        "batch": 256, "width": 1920, "height": 1080, "k": 1000, "flow": "embed+extract"},
+    3: {"quote": "batch=2048 3840\u00d72160 frames, 1000-coeff, batch-sharded across 8\u00d7MI355X (no collectives)",
+        "batch": 256, "width": 3840, "height": 2160, "k": 1000, "flow": "embed+extract"},
+    4: {"quote": "batch=512 7680\u00d74320 frames, 10000-coeff mark, + attack_resize 12.5% re-extract, 8\u00d7MI355X",
+        "batch": 64, "width": 7680, "height": 4320, "k": 10000, "flow": "attack"},
+}
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n: int) -> int:
+    """Parent of a plain `python bench.py --gpus N` run: one child process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment, the same command line.  The parent makes no GPU call
+    (torch.cuda.device_count() reads sysfs, it does not initialise HIP) and never re-execs."""
+    shared = bool(os.environ.get("SSW_BENCH_SHARE_DEVICE"))           # tests: every rank on device 0
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        print("bench.py needs a GPU: the product path has no CPU fallback", file=sys.stderr)
+        return 2
+    if n > n_dev and not shared:
+        print(f"bench.py: --gpus {n} but this node has {n_dev} GPU(s)", file=sys.stderr)
+        return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n))
+        # rank 0 owns stdout (the one JSON line); the others' chatter goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for o in pending:
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
 
 def shard_frames(total_frames: int, world: int, rank: int):
     """Contiguous block split of SURVEY 8(e): frame b -> rank floor(b * world / total)."""
@@ -35,19 +98,64 @@ def shard_frames(total_frames: int, world: int, rank: int):
     return lo, hi
 
 
+def timed_region(args, ctx, dist, step):
+    """W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + synchronize on both sides.
+    Returns (own seconds, MAX over ranks, per-stage event timings of the timed steps)."""
+    def barrier():
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.enable_timing(not args.no_stage_timers)      # hipEvent pairs around every stage, on the stream it runs on
+    ctx.reset_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0
+    barrier()
+    stage = ctx.timing()
+    prune = ctx.prune_stats()
+    ctx.enable_timing(False)
+    return own, (dist.max(own) if dist is not None else own), stage, prune
+
+
+def rate(work, ms):
+    return work / (ms * 1e-3) if ms > 0 else 0.0
+
+
+def hbm_report(stage, names):
+    """Achieved GB/s of algorithmic bytes (counted by the library per launch) per HBM-bound stage."""
+    out = {}
+    for n in names:
+        if stage[n]["launches"]:
+            g = rate(stage[n]["work"], stage[n]["ms"]) / 1e9
+            out[n] = {"gbs": round(g, 1), "frac_hbm": round(g / PEAK_HBM_GBS, 4),
+                      "avg_ms": round(stage[n]["ms"] / stage[n]["launches"], 4), "launches": stage[n]["launches"]}
+    return out
+
+
 def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb_out, marks, marks_host,
-                      extracted, sims, B, W, H, K):
+                      extracted, sims, B, W, H, K, workload_tag, rank_report, dump):
     """SURVEY 8(f) rank 1 / configs[4]: Writer::mark -> into_rgb8 -> resize to 1/8 (CatmullRom) and back
     -> Reader::extract + similarity, all on 8-bit device-resident frames (tests/attack_resize.rs)."""
     cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32)
     n_val = B * H * W * 3
     frames8 = torch.empty((B, H, W, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    check(lib.ssw_convert_f32_to_rgb8(ctx.handle, rgb.data_ptr(), n_val, frames8.data_ptr()), "to_rgb8")
+    ctx.synchronize()
+    del rgb, rgb_out                                   # the 8-bit flow does not need the f32 frames
+    torch.cuda.empty_cache()
     marked8 = torch.empty_like(frames8)
     small8 = torch.empty((B, H // 8, W // 8, 3), dtype=torch.uint8, device=dev)
     back8 = torch.empty_like(frames8)
     torch.cuda.synchronize()
-    check(lib.ssw_convert_f32_to_rgb8(ctx.handle, rgb.data_ptr(), n_val, frames8.data_ptr()), "to_rgb8")
-    ctx.synchronize()
 
     def step():
         check(lib.ssw_batch_embed_rgb8(ctx.handle, C.byref(cfg), frames8.data_ptr(), B, W, H, marks.data_ptr(), K,
@@ -57,48 +165,84 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
         check(lib.ssw_batch_extract_rgb8(ctx.handle, C.byref(cfg), frames8.data_ptr(), back8.data_ptr(), B, W, H, K,
                                          extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract_rgb8")
 
-    def barrier():
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    ctx.enable_timing(True)
-    ctx.reset_timing()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    stage = ctx.timing()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    own, elapsed, stage, prune = timed_region(args, ctx, dist, step)
     sims_host = sims.cpu().numpy()
+    ranks = rank_report(own)
+    dump(sims_host, extracted.cpu().numpy())
     if rank == 0:
         px = float(B) * W * H * args.steps
-        rz_ms = stage["resize"]["ms"]
-        # algorithmic bytes of the two resizes: 3 B/px read + 3/64 written (down), 3/64 read + 3 written (up)
-        rz_gbs = px * (6.0 + 6.0 / 64.0) / (rz_ms * 1e-3) / 1e9 if rz_ms > 0 else 0.0
+        main_ms, main_n = stage["dct_row_main"]["ms"], max(stage["dct_row_main"]["launches"], 1)
+        peak = PEAK_F64_MFMA_TFLOPS if args.precision == "f64" else PEAK_F32_MFMA_TFLOPS
+        main_tf = rate(stage["dct_row_main"]["work"], main_ms) / 1e12
         print(json.dumps({
             "metric": "Mpixels/sec embed + resize attack (12.5 %) + extract", "value": round(world * px / 1e6 / elapsed, 2),
             "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"batch={B}/GPU {W}x{H} 8-bit frames, {K}-coeff mark, embed -> into_rgb8 -> CatmullRom "
-                                   f"resize to 1/8 and back -> extract + similarity (configs[4] flow)",
-                       "frames_per_gpu": B, "width": W, "height": H, "k": K},
+                                   f"resize to 1/8 and back -> extract + similarity; {workload_tag}",
+                       "frames_per_gpu": B, "width": W, "height": H, "k": K,
+                       "parallelism": f"frame-sharded x{world}, no collectives"},
+            "roofline": {"bound": "mfma", "kernel": "pair_gemm_%s_kernel<rows, odd half>" % args.precision,
+                         "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(main_tf / peak, 4),
+                         "traffic": None, "avg_ms": round(main_ms / main_n, 4), "launches": main_n},
             "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in stage.items()},
-            "resize": {"gbs_algorithmic": round(rz_gbs, 1), "frac_hbm": round(rz_gbs / PEAK_HBM_GBS, 4)},
+            "hbm_kernels": hbm_report(stage, ["rgb_to_yiq", "dct_prep", "select", "yiq_to_rgb", "resize"]),
+            "pruned_derived_transform": prune,
+            "ranks": ranks,
             "sim_mean": round(float(sims_host.mean()), 4), "sim_min": round(float(sims_host.min()), 4),
             "sim_sigma_threshold_6_passed": bool((sims_host > 6.0).all()),
         }))
+
+
+class Dist:
+    """torch.distributed used for what the contract asks of it -- the barrier around the timed region, the
+    MAX over ranks of the elapsed time and the gather of per-rank results -- and nothing on the data path.
+    Backend "nccl" (= RCCL) with device tensors; SSW_BENCH_DIST_BACKEND=gloo (CPU tensors) lets tests run
+    several ranks on ONE GPU, which RCCL refuses."""
+
+    def __init__(self, rank, world, dev):
+        import torch.distributed as dist
+        self.dist, self.rank, self.world = dist, rank, world
+        backend = os.environ.get("SSW_BENCH_DIST_BACKEND", "nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+            self.tdev = dev
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            self.tdev = torch.device("cpu")
+        self.backend = backend
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max(self, x: float) -> float:
+        t = torch.tensor([x], dtype=torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, arr: np.ndarray):
+        """all_gather of equally shaped arrays -> list indexed by rank."""
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(self.tdev)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.cpu().numpy() for o in out]
+
+    def close(self):
+        self.dist.destroy_process_group()
+
+
+def marks_for_frames(seed: int, first_frame: int, n: int, k: int) -> torch.Tensor:
+    """One N(0,1) mark per GLOBAL frame index, so that a sharded run and a single-process run of the same
+    frames use the same marks (tests compare their similarities)."""
+    g = torch.Generator()
+    rows = []
+    for f in range(first_frame, first_frame + n):
+        g.manual_seed(seed * 1000003 + f)
+        rows.append(torch.randn(k, generator=g, dtype=torch.float32))
+    return torch.stack(rows) if rows else torch.zeros((0, k), dtype=torch.float32)
 
 
 def main():
@@ -106,10 +250,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="frames per GPU (configs[3]: 2048 frames / 8 GPUs)")
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--k", type=int, default=1000)
+    ap.add_argument("--config", type=int, choices=[1, 2, 3, 4], default=None,
+                    help="BASELINE.json configs[i] (per-GPU shard); default: configs[3], the metric's configuration")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU (configs[3]: 2048 frames / 8 GPUs = 256)")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=0,
                     help="frames per internal pass (0 = the library's automatic choice, ~2^28 pixels; bounds the workspace)")
     ap.add_argument("--precision", choices=["f32", "f64"], default="f64",
@@ -117,45 +263,64 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other precision")
     ap.add_argument("--attack-resize", action="store_true",
                     help="configs[4] flow on 8-bit frames: embed -> into_rgb8 -> CatmullRom 1/8 down + up -> extract")
+    ap.add_argument("--embed-only", action="store_true", help="configs[1] flow: Writer::new + mark only (DCT2 -> embed -> DCT3)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fold", action="store_true", help="dense basis GEMMs instead of the even/odd-folded ones")
+    ap.add_argument("--no-timers-off-leg", action="store_true", help="skip the short re-measurement with the stage timers off")
+    ap.add_argument("--no-serial-leg", action="store_true", help="skip the short re-measurement with one chunk at a time on one stream")
+    ap.add_argument("--no-stage-timers", action="store_true", help="no hipEvent pairs in the timed region (no roofline numbers)")
+    ap.add_argument("--dump", default=None, help="rank 0 writes the gathered per-frame sims / extracted marks here (.npz)")
     args = ap.parse_args()
 
+    preset = BASELINE_CONFIGS[args.config or 3]
+    for name in ("batch", "width", "height", "k"):
+        if getattr(args, name) is None:
+            setattr(args, name, preset[name])
+    if args.config is not None:
+        args.attack_resize = args.attack_resize or preset["flow"] == "attack"
+        args.embed_only = args.embed_only or preset["flow"] == "embed"
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))        # parent: no GPU call before or after this point
+
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
+    n_dev = torch.cuda.device_count()
+    dev_index = 0 if os.environ.get("SSW_BENCH_SHARE_DEVICE") else local_rank
+    if n_dev == 0 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dev_index >= n_dev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but this node has {n_dev} GPU(s)")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1 or os.environ.get("SSW_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist = Dist(rank, world, dev)
 
     import spread_spectrum_watermarking_amd as wm
     from spread_spectrum_watermarking_amd import _lib as L
     from spread_spectrum_watermarking_amd.api import check
 
     lib = L.load()
-    ctx = wm.Context(local_rank)
+    ctx = wm.Context(dev_index)
     ctx.set_chunk_frames(args.chunk)
     fold_level = 0 if args.no_fold else int(os.environ.get("SSW_FOLD_LEVEL", str(L.DCT_FOLDING_DEFAULT)))
     ctx.set_dct_folding(fold_level)
     W, H, K, B = args.width, args.height, args.k, args.batch
     chunk_eff = min(args.chunk if args.chunk > 0 else max(1, (1 << 28) // (W * H)), B)   # mirrors effective_chunk() in the library
+    workload_tag = (f"configs[{args.config or 3}] of BASELINE.json: \"{preset['quote']}\"" if (args.config is not None or
+                    (B, W, H, K) == (preset["batch"], preset["width"], preset["height"], preset["k"])) else "custom shape")
 
     # ---- inputs resident in HBM ------------------------------------------------------------------
     first_frame = rank * B                       # global frame index of this rank's shard (weak scaling)
     rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
     rgb_out = torch.empty_like(rgb)
-    gen = torch.Generator().manual_seed(args.seed * 1000003 + rank)
-    marks_host = torch.randn((B, K), generator=gen, dtype=torch.float32)
+    marks_host = marks_for_frames(args.seed, first_frame, B, K)
     marks = marks_host.to(dev)
     extracted = torch.zeros((B, K), dtype=torch.float32, device=dev)
     sims = torch.zeros((B,), dtype=torch.float32, device=dev)
@@ -163,195 +328,166 @@ def main():
     check(lib.ssw_synth_frames(ctx.handle, args.seed, first_frame, B, W, H, rgb.data_ptr()), "ssw_synth_frames")
     ctx.synchronize()
 
+    def rank_report(elapsed_own):
+        """ranks_seen / per-rank rates from an all-gather; exits non-zero when a rank is missing."""
+        mine = np.array([rank, dev_index, B, float(B) * W * H * args.steps / 1e6 / elapsed_own], dtype=np.float64)
+        rows = dist.gather(mine) if dist is not None else [mine]
+        seen = sorted(int(r[0]) for r in rows)
+        rep = {"ranks_seen": seen, "devices": [int(r[1]) for r in rows],
+               "mpix_per_s_per_rank": [round(float(r[3]), 2) for r in rows],
+               "dist_backend": dist.backend if dist is not None else None}
+        if seen != list(range(args.gpus)):
+            raise SystemExit(f"rank {rank}: expected ranks {list(range(args.gpus))}, saw {seen}")
+        return rep
+
+    def dump(sims_host, ext_host):
+        if not args.dump:
+            return
+        all_s = dist.gather(sims_host) if dist is not None else [sims_host]
+        all_e = dist.gather(ext_host) if dist is not None else [ext_host]
+        if rank == 0:
+            np.savez(args.dump, sims=np.concatenate(all_s), extracted=np.concatenate(all_e))
+
     if args.attack_resize:
         run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb_out, marks, marks_host,
-                          extracted, sims, B, W, H, K)
+                          extracted, sims, B, W, H, K, workload_tag, rank_report, dump)
         if dist is not None:
-            dist.destroy_process_group()
+            dist.close()
         ctx.close()
         return
 
-    def measure(prec_name):
-        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; returns
-        (seconds [max over ranks], per-stage hipEvent timings, sims of the last step)."""
+    embed_only = args.embed_only
+
+    def measure(prec_name, overlap=True):
+        """One timed region in the given precision; returns (own s, max-over-ranks s, stage timings, prune stats, sims, extracted)."""
         cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, L.PRECISION_F64 if prec_name == "f64" else L.PRECISION_F32)
+        ctx.set_overlap(overlap)
 
         def step():
             check(lib.ssw_batch_embed(ctx.handle, C.byref(cfg), rgb.data_ptr(), B, W, H, marks.data_ptr(), K,
                                       rgb_out.data_ptr(), None, None), "ssw_batch_embed")
+            if not embed_only:
+                check(lib.ssw_batch_extract(ctx.handle, C.byref(cfg), rgb.data_ptr(), rgb_out.data_ptr(), B, W, H, K,
+                                            extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
+
+        own, elapsed, stage, prune = timed_region(args, ctx, dist, step)
+        ctx.set_overlap(True)
+        if embed_only:                     # configs[1]: verify the round trip with one untimed extraction
             check(lib.ssw_batch_extract(ctx.handle, C.byref(cfg), rgb.data_ptr(), rgb_out.data_ptr(), B, W, H, K,
                                         extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
-
-        def barrier():
             ctx.synchronize()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-
-        for _ in range(args.warmup):
-            step()
-        ctx.enable_timing(True)                  # hipEvent pairs around every kernel on the ctx stream
-        ctx.reset_timing()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        ctx.synchronize()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        barrier()
-        stage = ctx.timing()
-        ctx.enable_timing(False)
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
         sims_host = sims.cpu().numpy()
+        ext_host = extracted.cpu().numpy()
+        # every frame of the batch: a wrong index or a wrong coefficient anywhere shows up as an O(1) error in
+        # the extracted mark (Option2, alpha 0.1, no quantisation: the round trip returns the mark to ~1e-2)
+        err = np.abs(ext_host - marks_host.numpy()).max(axis=1)
         norms = marks_host.norm(dim=1).numpy()
-        if not np.all(sims_host > 0.9 * norms):
-            raise SystemExit(f"rank {rank}: similarity check failed ({prec_name}): "
-                             f"min sim/|mark| = {(sims_host / norms).min():.3f}")
-        return elapsed, stage, sims_host
+        if not (np.all(err < 0.1) and np.all(sims_host > 0.97 * norms)):
+            bad = int(np.argmax(err))
+            raise SystemExit(f"rank {rank}: round-trip check failed ({prec_name}): frame {bad} max|extracted - mark| = "
+                             f"{err[bad]:.3g}, min sim/|mark| = {(sims_host / norms).min():.3f}")
+        return own, elapsed, stage, prune, sims_host, ext_host
 
     steps = args.steps
     px_total = float(B) * W * H * steps
-    transforms_per_step = 4                       # DCT2, DCT3 (embed), DCT2, DCT2 (extract)
-    fold_rows = (not args.no_fold) and W % 8 == 0 and W >= 16
-    fold_cols = (not args.no_fold) and H % 8 == 0 and H >= 16 and W % 4 == 0
+    transforms_per_step = 2 if embed_only else 4     # DCT2, DCT3 (embed) [, DCT2, DCT2 (extract)]
+    dense_flop_per_step = transforms_per_step * 2.0 * B * W * H * (W + H)      # SURVEY 8(d): F2D = 2 W H (W + H)
 
-    def kernel_report(prec_name, stage):
-        """Per-kernel achieved rates from the live event timers.  GEMMs: EXECUTED flop / time is the
-        utilisation (folding executes 1/2 or 3/8 of the dense 2*lines*N*N); the dense figure / time
-        is reported separately as "effective"."""
+    def kernel_report(prec_name, stage, steps):
+        """Per-kernel achieved rates from the live event timers and the work the library counted for the
+        same launches.  GEMMs: EXECUTED flop / time is the utilisation (folding executes 3/8 or 11/32 of
+        the dense 2*lines*N*N, the pruned derived transform a few percent of it); the reference's dense
+        flop / time is reported separately as "effective"."""
         peak = PEAK_F64_MFMA_TFLOPS if prec_name == "f64" else PEAK_F32_MFMA_TFLOPS
-        passes = transforms_per_step * steps
-        row_dense = 2.0 * B * H * W * W * passes
-        col_dense = 2.0 * B * W * H * H * passes
-        # which strategy each pass runs (mirrors dct2d_planes in csrc/ssw_lib.hip)
-        operand = fold_level >= 3 and fold_rows and fold_cols
-        two_rows = operand and fold_level >= 4 and W % 16 == 0 and W >= 64
-        two_cols = operand and fold_level >= 4 and H % 8 == 0 and H >= 64       # the transposing pre-pass needs H/4 even only
-        three_rows = two_rows and W % 32 == 0 and W >= 128 and (fold_level >= 6 or (fold_level == 5 and W >= 3072))
-        row_frac = 0.375 if two_rows else (0.5 if fold_rows else 1.0)
-        if three_rows:                               # the three forward transforms of a step: 11/32; the inverse: 3/8
-            row_frac = (3 * 11.0 / 32.0 + 0.375) / 4.0
-        col_frac = 0.375 if two_cols else (0.5 if fold_cols else 1.0)
-        row_flops, col_flops = row_dense * row_frac, col_dense * col_frac
-        esz = 8.0 if prec_name == "f64" else 4.0
-        fused_rgb = bool(two_rows and W >= H)        # the three forward transforms of a step start from RGB
-        rgb_bytes = (3 * 12.0 + 8.0 + 3 * esz) if fused_rgb else 56.0
-        row_ms, row_n = stage["dct_row"]["ms"], max(stage["dct_row"]["launches"], 1)
-        col_ms, col_n = stage["dct_col"]["ms"], max(stage["dct_col"]["launches"], 1)
-        row_tf = row_flops / (row_ms * 1e-3) / 1e12 if row_ms > 0 else 0.0
-        col_tf = col_flops / (col_ms * 1e-3) / 1e12 if col_ms > 0 else 0.0
-
-        def gbs(bytes_per_px, passes_, ms):
-            return (bytes_per_px * px_total * passes_) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        kernels = {
-            "dct_rows": {"tflops": round(row_tf, 2), "frac_mfma": round(row_tf / peak, 4),
-                         "pass_ms": round(row_ms / passes, 4),
-                         "timed_passes": row_n, "executed_fraction_of_dense": row_frac,
-                         "effective_dense_tflops": round(row_dense / (row_ms * 1e-3) / 1e12, 2) if row_ms > 0 else 0.0},
-            "dct_cols": {"tflops": round(col_tf, 2), "frac_mfma": round(col_tf / peak, 4),
-                         "pass_ms": round(col_ms / passes, 4),
-                         "timed_passes": col_n, "executed_fraction_of_dense": col_frac,
-                         "effective_dense_tflops": round(col_dense / (col_ms * 1e-3) / 1e12, 2) if col_ms > 0 else 0.0},
-            # algorithmic bytes (SURVEY 8(d)): writer rgb->yiq 24 B/px + two reader rgb->y 16 B/px = 56 B/px;
-            # fused with the first operand pre-pass (below) the stage reads 12 B/px three times and writes
-            # I, Q once and the operand planes (esz B/px) three times
-            "rgb_to_yiq": {"gbs": round(gbs(rgb_bytes, 1, stage["rgb_to_yiq"]["ms"]), 1),
-                           "frac_hbm": round(gbs(rgb_bytes, 1, stage["rgb_to_yiq"]["ms"]) / PEAK_HBM_GBS, 4),
-                           "fused_with_operand_prepass": fused_rgb},
-            "yiq_to_rgb": {"gbs": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]), 1),
-                           "frac_hbm": round(gbs(24.0, 1, stage["yiq_to_rgb"]["ms"]) / PEAK_HBM_GBS, 4)},
-            # top-k: 4 B/px algorithmic, two selections per step (writer + base reader)
-            "select": {"gbs": round(gbs(4.0, 2, stage["select"]["ms"]), 1),
-                       "frac_hbm": round(gbs(4.0, 2, stage["select"]["ms"]) / PEAK_HBM_GBS, 4)},
-        }
-        if operand:
-            # operand pre-passes: f32 plane in (4 B/px), operand planes out (8 B/px in f64, 4 in f32), once per pass
-            per_pass = 4.0 + esz
-            prep_passes = transforms_per_step * 2 - (3 if fused_rgb else 0)
-            prep_gbs = gbs(per_pass, prep_passes, stage["dct_prep"]["ms"])
-            kernels["dct_prep"] = {"gbs": round(prep_gbs, 1), "frac_hbm": round(prep_gbs / PEAK_HBM_GBS, 4),
-                                   "ms_per_step": round(stage["dct_prep"]["ms"] / steps, 3)}
-        lines_per_launch = chunk_eff * H
-        if operand:
-            # dominant launch: the row GEMM over the odd frequencies (all W/2 of them, K = W/2)
-            main_ms, main_n = stage["dct_row_main"]["ms"], max(stage["dct_row_main"]["launches"], 1)
-            main_flop = 2.0 * lines_per_launch * (W / 2.0) * (W / 2.0)
-            main_tf = main_flop * main_n / (main_ms * 1e-3) / 1e12 if main_ms > 0 else 0.0
-            kernels["dct_rows"]["main_launch"] = {"avg_ms": round(main_ms / main_n, 4), "launches": main_n,
-                                                  "flop_per_launch": main_flop, "tflops": round(main_tf, 2)}
-            cm_ms, cm_n = stage["dct_col_main"]["ms"], max(stage["dct_col_main"]["launches"], 1)
-            cm_flop = 2.0 * chunk_eff * W * (H / 2.0) * (H / 2.0)
-            kernels["dct_cols"]["main_launch"] = {"avg_ms": round(cm_ms / cm_n, 4), "launches": cm_n,
-                                                  "flop_per_launch": cm_flop,
-                                                  "tflops": round(cm_flop * cm_n / (cm_ms * 1e-3) / 1e12, 2) if cm_ms > 0 else 0.0}
-            roofline = {"bound": "mfma",
-                        "kernel": ("pair_gemm_%s_kernel<rows, odd half>" if two_rows else "pair_gemm_%s_kernel<rows>") % prec_name,
-                        "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(main_tf / peak, 4), "traffic": None,
-                        "instance": "ssw::pair_gemm_%s_kernel<false, %d, true, 0>" % (prec_name, 0),
-                        "note": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency "
-                                 "half of the even/odd-folded basis GEMM) / its average duration (forward and inverse "
-                                 "launches; `instance` is the forward one's name in the rocprofv3 kernel stats); "
-                                 "whole-pass rates incl. the even-half launches in kernels.dct_rows")}
-        else:
-            roofline = {"bound": "mfma",
-                        "kernel": ("dct_rows_folded_%s_kernel" if fold_rows else "dct_rows_%s_kernel") % prec_name,
-                        "achieved": round(row_tf, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(row_tf / peak, 4), "traffic": None,
-                        "note": ("executed flop per launch (even/odd-folded basis: half the dense 2*rows*W*W) / average "
-                                 "launch time; dense-effective rate in kernels.dct_rows.effective_dense_tflops")
-                        if fold_rows else "dense flop per launch / average launch time"}
+        kernels = {}
+        for name, key in (("dct_rows", "dct_row"), ("dct_cols", "dct_col")):
+            ms, n = stage[key]["ms"], max(stage[key]["launches"], 1)
+            tf = rate(stage[key]["work"], ms) / 1e12
+            mk = key + "_main"
+            mms, mn = stage[mk]["ms"], max(stage[mk]["launches"], 1)
+            kernels[name] = {"tflops": round(tf, 2), "frac_mfma": round(tf / peak, 4), "ms_per_step": round(ms / steps, 3),
+                             "timed_stages": n, "executed_flop_per_step": stage[key]["work"] / steps,
+                             "main_launch": {"avg_ms": round(mms / mn, 4), "launches": mn,
+                                             "flop_per_launch": stage[mk]["work"] / mn,
+                                             "tflops": round(rate(stage[mk]["work"], mms) / 1e12, 2)}}
+        gemm_ms = stage["dct_row"]["ms"] + stage["dct_col"]["ms"]
+        executed = stage["dct_row"]["work"] + stage["dct_col"]["work"]
+        kernels["dct_all"] = {"executed_fraction_of_dense": round(executed / (dense_flop_per_step * steps), 4) if steps else 0.0,
+                              "effective_dense_tflops": round(rate(dense_flop_per_step * steps, gemm_ms) / 1e12, 2)}
+        kernels.update(hbm_report(stage, ["rgb_to_yiq", "dct_prep", "select", "yiq_to_rgb"]))
+        main = kernels["dct_rows"]["main_launch"]
+        roofline = {"bound": "mfma", "kernel": "pair_gemm_%s_kernel<rows, odd half>" % prec_name,
+                    "instance": "ssw::pair_gemm_%s_kernel<false, 0, true, 0>" % prec_name,
+                    "achieved": main["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(main["tflops"] / peak, 4),
+                    "traffic": None, "avg_ms": main["avg_ms"], "launches": main["launches"],
+                    "flop_per_launch": main["flop_per_launch"],
+                    "note": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency "
+                             "half of the even/odd-folded basis GEMM, counted by the library per launch) / its average "
+                             "duration from a hipEvent pair on the stream it runs on, inside the timed region")}
         # HBM-side traffic of the dominant kernel: PMC counters collected offline exactly as
         # MI355X_MICROARCH.md prescribes (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) and
-        # committed in profiles/r1_pmc_traffic.json; only quoted when this run matches that workload.
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            wl = pmc["workload"]
-            if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, chunk_eff) and roofline["kernel"] in pmc["kernels"]:
-                roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
-                roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
-                if operand:   # D operand plane in (W/2 elements per line), odd half basis, f32 odd outputs
-                    esz = 8 if prec_name == "f64" else 4
-                    roofline["algorithmic_bytes_per_launch"] = int(lines_per_launch * (W // 2) * esz + (W // 2) ** 2 * esz +
-                                                                   lines_per_launch * (W // 2) * 4)
-                else:
-                    roofline["algorithmic_bytes_per_launch"] = int(chunk_eff * H * W * 8 +
-                                                                   2 * (W // 2) ** 2 * (8 if prec_name == "f64" else 4))
-        except (OSError, KeyError, ValueError):
-            pass
+        # committed under profiles/ with the commit they were collected at; quoted only for that workload.
+        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                wl = pmc["workload"]
+                if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, chunk_eff) and roofline["kernel"] in pmc["kernels"]:
+                    roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
+                    roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
+                    roofline["traffic_source"] = f"profiles/{name} (collected at commit {pmc.get('commit', 'r1 final')})"
+                    esz = 8 if prec_name == "f64" else 4     # operand plane in, odd half basis in, f32 odd outputs
+                    lines = chunk_eff * H
+                    roofline["algorithmic_bytes_per_launch"] = int(lines * (W // 2) * esz + (W // 2) ** 2 * esz + lines * (W // 2) * 4)
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         return kernels, roofline, {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
 
-    elapsed, stage, sims_host = measure(args.precision)
-    kernels, roofline, stage_ms = kernel_report(args.precision, stage)
+    own, elapsed, stage, prune, sims_host, ext_host = measure(args.precision)
+    kernels, roofline, stage_ms = kernel_report(args.precision, stage, steps)
+    ranks = rank_report(own)
+    dump(sims_host, ext_host)
+
+    # the same workload with one chunk at a time on one stream: per-kernel timings without co-running kernels
+    serial = None
+    if not args.no_serial_leg:
+        keep = args.steps
+        args.steps = max(1, min(args.steps, 5))
+        s_own, s_elapsed, s_stage, _, s_sims, s_ext = measure(args.precision, overlap=False)
+        s_kernels, s_roofline, s_stage_ms = kernel_report(args.precision, s_stage, args.steps)
+        serial = {"value": round(world * float(B) * W * H * args.steps / 1e6 / s_elapsed, 2), "unit": "Mpix/s",
+                  "ms_per_step": round(s_elapsed / args.steps * 1e3, 3), "steps": args.steps,
+                  "roofline": s_roofline, "kernels": s_kernels, "stage_ms_per_step": s_stage_ms,
+                  "bit_identical_to_overlapped": bool(np.array_equal(s_sims, sims_host) and np.array_equal(s_ext, ext_host))}
+        args.steps = keep
+
+    timers_off = None
+    if not args.no_timers_off_leg and not args.no_stage_timers:
+        keep = (args.steps, args.no_stage_timers)
+        args.steps, args.no_stage_timers = max(1, min(args.steps, 5)), True
+        _, o_elapsed, _, _, _, _ = measure(args.precision)
+        timers_off = {"value": round(world * float(B) * W * H * args.steps / 1e6 / o_elapsed, 2), "unit": "Mpix/s",
+                      "ms_per_step": round(o_elapsed / args.steps * 1e3, 3), "steps": args.steps,
+                      "note": "same workload with the stage timers disabled: what the event pairs in the timed region cost"}
+        args.steps, args.no_stage_timers = keep
+
     alt = None
     if not args.no_alt:
         alt_name = "f32" if args.precision == "f64" else "f64"
-        alt_elapsed, alt_stage, alt_sims = measure(alt_name)
-        alt_kernels, alt_roofline, alt_stage_ms = kernel_report(alt_name, alt_stage)
+        _, alt_elapsed, alt_stage, _, alt_sims, _ = measure(alt_name)
+        alt_kernels, alt_roofline, _ = kernel_report(alt_name, alt_stage, steps)
         alt = {"dtype": alt_name, "value": round(world * px_total / 1e6 / alt_elapsed, 2), "unit": "Mpix/s",
                "ms_per_step": round(alt_elapsed / steps * 1e3, 3), "roofline": alt_roofline,
                "kernels": {k: alt_kernels[k] for k in ("dct_rows", "dct_cols")},
                "sim_mean": round(float(alt_sims.mean()), 4),
                "max_abs_sim_diff_vs_headline": float(np.abs(alt_sims - sims_host).max())}
-        # leave the headline precision's outputs in rgb_out / sims for the parity leg below
-        if rank == 0 and world == 1 and not args.no_cpu_baseline:
-            measure_cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1,
-                                   L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32)
-            check(lib.ssw_batch_embed(ctx.handle, C.byref(measure_cfg), rgb.data_ptr(), 1, W, H, marks.data_ptr(), K,
-                                      rgb_out.data_ptr(), None, None), "ssw_batch_embed")
-            check(lib.ssw_batch_extract(ctx.handle, C.byref(measure_cfg), rgb.data_ptr(), rgb_out.data_ptr(), 1, W, H, K,
-                                        extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
-            ctx.synchronize()
 
     result = None
     if rank == 0:
         mpix = world * px_total / 1e6
+        flow = "embed (Writer::new + mark: DCT2 -> embed -> DCT3 round trip)" if embed_only else "embed+extract+similarity"
         result = {
-            "metric": "Mpixels/sec embed+extract (4K batch)",
+            "metric": "Mpixels/sec embed+extract (4K batch)" if not embed_only else "Mpixels/sec embed + IDCT round trip",
             "value": round(mpix / elapsed, 2),
             "unit": "Mpix/s",
             "n_gpus": world,
@@ -363,26 +499,38 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": f"batch={B}/GPU {W}x{H} f32 frames, {K}-coeff mark, embed+extract+similarity "
-                                   f"(per-GPU shard of configs[3]: batch=2048 3840x2160 across 8 GPUs)",
+            "config": {"workload": f"batch={B}/GPU {W}x{H} f32 frames, {K}-coeff mark, {flow}; {workload_tag}",
                        "frames_per_gpu": B, "width": W, "height": H, "k": K, "alpha": 0.1,
                        "method": "Option2", "ordering": "Energy", "chunk_frames": chunk_eff,
-                       "dct_folding_level": fold_level,
+                       "dct_folding_level": fold_level, "overlap": "two chunks in flight on two streams",
                        "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
             "kernels": kernels,
             "stage_ms_per_step": stage_ms,
+            "pruned_derived_transform": prune,
+            "ranks": ranks,
             "sim_mean": round(float(sims_host.mean()), 4),
         }
+        if serial is not None:
+            result["serialized"] = serial
+        if timers_off is not None:
+            result["timers_off"] = timers_off
         if alt is not None:
             result["alt_precision"] = alt
 
     # ---- CPU baseline: the oracle (faithful mode) on a bounded sample, rank 0 at N=1 only ----------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
+        if alt is not None or serial is not None or timers_off is not None:   # the headline precision's outputs again
+            measure_cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1,
+                                   L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32)
+            check(lib.ssw_batch_embed(ctx.handle, C.byref(measure_cfg), rgb.data_ptr(), B, W, H, marks.data_ptr(), K,
+                                      rgb_out.data_ptr(), None, None), "ssw_batch_embed")
+            check(lib.ssw_batch_extract(ctx.handle, C.byref(measure_cfg), rgb.data_ptr(), rgb_out.data_ptr(), B, W, H, K,
+                                        extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
+            ctx.synchronize()
         frame0 = rgb[0].cpu().numpy()
         mark0 = marks_host[0].numpy()
-        gpu_marked0 = rgb_out[0].cpu().numpy()
         # timed: what the reference does -- f32 FFT-class DCT + full stable sort of all W*H-1 keys
         t0 = time.perf_counter()
         cpu_marked = O.embed_frame(frame0, mark0, backend=O.BACKEND_F32, full_sort=True)
@@ -403,10 +551,17 @@ def main():
             "value": round(W * H / 1e6 / sel_s, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
             "sample": f"same frame, f32 FFT DCT + top-k selection instead of the full sort, single thread, {sel_s:.1f} s",
         }
-        # same work, one frame per thread on the host's cores (the reference itself is single-threaded;
+        # same work, one frame per thread on ALL the host's cores (the reference itself is single-threaded;
         # this is the frame-parallel upper bound of SURVEY 8(d)).  ctypes releases the GIL in the C calls.
+        # Threads are only capped by host memory: ~0.6 GB of planes per 4K frame in flight.
         import concurrent.futures as cf
-        n_thr = max(1, min(os.cpu_count() or 1, 16))
+        n_cores = os.cpu_count() or 1
+        try:
+            avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable:")][0]
+        except (OSError, IndexError, ValueError):
+            avail = 16 << 30
+        per_thread = 80 * W * H                        # bytes: rgb out + planes + sort keys (16 B/coefficient)
+        n_thr = max(1, min(n_cores, int(0.5 * avail / per_thread)))
 
         def one(_):
             m = O.embed_frame(frame0, mark0, backend=O.BACKEND_F32, full_sort=True)
@@ -417,27 +572,32 @@ def main():
         par_s = time.perf_counter() - t0
         result["cpu_baseline_parallel"] = {
             "value": round(n_thr * W * H / 1e6 / par_s, 4), "unit": "Mpix/s", "cores": n_thr, "kind": "port",
-            "sample": f"{n_thr} frames {W}x{H}, one per thread ({os.cpu_count()} logical cores on the host), "
-                      f"same faithful pipeline, {par_s:.1f} s",
+            "sample": f"{n_thr} frames {W}x{H}, one per thread on {n_thr} of the host's {n_cores} logical cores "
+                      f"(limited only by host memory), same faithful pipeline, {par_s:.1f} s",
         }
-        # untimed: the oracle's correctly rounded (f64-backend) pipeline = what the canonical precision must equal
-        ref_marked = O.embed_frame(frame0, mark0, backend=O.BACKEND_F64, full_sort=False)
-        ref_ext, ref_sim = O.extract_frame(frame0, ref_marked, mark0, backend=O.BACKEND_F64, full_sort=False)
-        gpu_ext0 = extracted[0].cpu().numpy()
-        result["parity"] = {
-            "precision": args.precision,
-            "sim_gpu": float(sims_host[0]),
-            "sim_cpu_f32fft": float(cpu_sim), "sim_delta_vs_cpu_f32fft": abs(float(sims_host[0]) - float(cpu_sim)),
-            "sim_cpu_exact": float(ref_sim), "sim_delta_vs_cpu_exact": abs(float(sims_host[0]) - float(ref_sim)),
-            "marked_frame_max_abs_diff_vs_cpu_exact": float(np.abs(gpu_marked0 - ref_marked).max()),
-            "marked_frame_bit_identical_fraction": float(np.mean(gpu_marked0 == ref_marked)),
-        }
-        result["parity"]["extracted_max_abs_diff_vs_cpu_exact"] = float(np.abs(gpu_ext0 - ref_ext).max())
+        # untimed: the oracle's correctly rounded (f64-backend) pipeline = what the canonical precision must equal,
+        # on the first and the last frame of the batch (the last one sits in the last chunk of the pipeline)
+        gpu_ext = extracted.cpu().numpy()
+        sims_now = sims.cpu().numpy()
+        checks = []
+        for f in sorted({0, B - 1}):
+            frame = rgb[f].cpu().numpy()
+            mk = marks_host[f].numpy()
+            marked_f = rgb_out[f].cpu().numpy()
+            ref_marked = O.embed_frame(frame, mk, backend=O.BACKEND_F64, full_sort=False)
+            ref_ext, ref_sim = O.extract_frame(frame, ref_marked, mk, backend=O.BACKEND_F64, full_sort=False)
+            checks.append({"frame": f, "sim_gpu": float(sims_now[f]), "sim_cpu_exact": float(ref_sim),
+                           "sim_delta_vs_cpu_exact": abs(float(sims_now[f]) - float(ref_sim)),
+                           "marked_frame_max_abs_diff_vs_cpu_exact": float(np.abs(marked_f - ref_marked).max()),
+                           "marked_frame_bit_identical_fraction": float(np.mean(marked_f == ref_marked)),
+                           "extracted_max_abs_diff_vs_cpu_exact": float(np.abs(gpu_ext[f] - ref_ext).max())})
+        result["parity"] = {"precision": args.precision, "sim_cpu_f32fft": float(cpu_sim),
+                            "sim_delta_vs_cpu_f32fft": abs(float(sims_now[0]) - float(cpu_sim)), "frames": checks}
 
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
-        dist.destroy_process_group()
+        dist.close()
     ctx.close()
 
 

@@ -127,6 +127,24 @@ int ssw_ctx_record_event(ssw_ctx* ctx, void* hip_event);
    pass (32 4K frames, 129 full-HD frames, 8 8K frames; 9.6 GB of workspace). */
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
 
+/* Batch pipelines (ssw_batch_*): two chunks in flight, each with its own workspace -- the HBM-bound stages
+   of one (operand pre-passes, selection, colour conversion) run on a second internal stream while the
+   basis GEMMs of the other run on the context's stream; the context's stream is ordered after all of it
+   when the call returns.  Default on (2 x 36 B/px of workspace); 0 = one chunk at a time on one stream
+   (what the per-kernel timings of bench.py's roofline leg use).  Results are bit-identical either way. */
+int ssw_ctx_set_overlap(ssw_ctx* ctx, int enable);
+/* ssw_batch_extract*: transform the derived frames only where Reader::extract reads them
+   (src/algorithm.rs:556-561: k coefficients) -- the row pass for the frequency columns that occur in a
+   chunk's index lists, the column pass on that compact plane; same operands, basis rows, kernel and
+   summation order as the full transform, so the extracted values are bit-identical.  Falls back to the
+   full transform per chunk when the columns do not fit 8 sqrt(k) slots, and altogether when that exceeds
+   W/4 or the shape does not take the default GEMM strategy.  Default on; the call then waits once, at
+   its end, for the device.  Handles (Reader::derived exposes coefficients()) always transform fully. */
+int ssw_ctx_set_prune(ssw_ctx* ctx, int enable);
+/* stats[0] chunks that took the pruned path, [1] of those redone with the full transform, [2] frequency
+   columns actually needed (sum over chunks); since the last ssw_ctx_reset_timing. */
+int ssw_ctx_get_prune_stats(ssw_ctx* ctx, uint64_t* stats);
+
 /* Even/odd folding of the basis GEMMs (fewer multiply-adds for the same transform; exact in f64,
    one extra rounding per input pair in f32) where the frame shape allows (W % 8 == 0 / H % 8 == 0).
    Strategy levels:
@@ -170,8 +188,13 @@ int ssw_ctx_reset_timing(ssw_ctx* ctx);
 /* Synchronises, then returns accumulated milliseconds and launch counts per stage
    (arrays of SSW_STAGE_COUNT). */
 int ssw_ctx_get_timing(ssw_ctx* ctx, double* ms, uint64_t* launches);
+/* Work done inside the timed regions, per stage (array of SSW_STAGE_COUNT): executed floating-point
+   operations for the GEMM stages (DCT_ROW, DCT_COL and their *_MAIN launches), algorithmic bytes
+   (what the stage must read and write once) for the HBM-bound ones. */
+int ssw_ctx_get_work(ssw_ctx* ctx, double* work);
 
 /* Device memory helpers for hosts without their own allocator. */
+int ssw_dev_mem_info(ssw_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 int ssw_dev_alloc(ssw_ctx* ctx, size_t bytes, void** dev_ptr);
 int ssw_dev_free(ssw_ctx* ctx, void* dev_ptr);
 int ssw_copy_to_dev(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);

@@ -80,10 +80,32 @@ class Context:
         check(self._lib.ssw_ctx_reset_timing(self.handle), "ssw_ctx_reset_timing")
 
     def timing(self) -> dict:
+        """Per stage: milliseconds, timed regions, and the work done in them (flop for the GEMM stages,
+        algorithmic bytes for the HBM-bound ones)."""
         ms = (C.c_double * len(L.STAGES))()
         n = (C.c_uint64 * len(L.STAGES))()
+        work = (C.c_double * len(L.STAGES))()
         check(self._lib.ssw_ctx_get_timing(self.handle, ms, n), "ssw_ctx_get_timing")
-        return {s: {"ms": ms[i], "launches": int(n[i])} for i, s in enumerate(L.STAGES)}
+        check(self._lib.ssw_ctx_get_work(self.handle, work), "ssw_ctx_get_work")
+        return {s: {"ms": ms[i], "launches": int(n[i]), "work": work[i]} for i, s in enumerate(L.STAGES)}
+
+    def set_overlap(self, on: bool = True):
+        """Two chunks in flight on two streams in the batch entry points (default) or one at a time."""
+        check(self._lib.ssw_ctx_set_overlap(self.handle, int(on)), "ssw_ctx_set_overlap")
+
+    def set_prune(self, on: bool = True):
+        """Batch extract: derived frames transformed only where extract reads them (default) or fully."""
+        check(self._lib.ssw_ctx_set_prune(self.handle, int(on)), "ssw_ctx_set_prune")
+
+    def prune_stats(self) -> dict:
+        st = (C.c_uint64 * 3)()
+        check(self._lib.ssw_ctx_get_prune_stats(self.handle, st), "ssw_ctx_get_prune_stats")
+        return {"pruned_chunks": int(st[0]), "redone_chunks": int(st[1]), "columns_needed": int(st[2])}
+
+    def mem_info(self):
+        free, total = C.c_size_t(), C.c_size_t()
+        check(self._lib.ssw_dev_mem_info(self.handle, C.byref(free), C.byref(total)), "ssw_dev_mem_info")
+        return int(free.value), int(total.value)
 
     # device memory for hosts without their own allocator (tests; the bench uses torch tensors)
     def alloc(self, nbytes: int) -> "DeviceBuffer":

@@ -319,4 +319,24 @@ int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind
     return SSW_OK;
 }
 
+// Forward row pass restricted to a gathered set of frequencies (pruned derived transform, prune.hip): one
+// shared image operand `x` (k-blocked, Kp wide) against a gathered half basis `y` of `cap` rows (k-blocked,
+// [Kp / 16][cap][16]); row j of y produces compact output column off + j of `out` (row stride out_stride).
+// Same kernel, operands and k order as the full transform's launches -> bit-identical values.
+int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const float* y, unsigned cap, unsigned Kp, float* out,
+                                         unsigned out_stride, unsigned off, size_t lines) {
+    if (lines == 0 || cap == 0) return SSW_OK;
+    if (lines > 0xFFFFFFFFull || (cap & 1)) return SSW_ERR_BAD_DIMS;
+    const unsigned L = (unsigned)lines, NP = cap / 2;
+    const unsigned tiles_m = (L + 127) / 128, tiles_n = (NP + 63) / 64;
+    const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if ((unsigned long long)Kp * L * sizeof(float) > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    PairOutF po{out, nullptr, out_stride, 0, 0, off, off + NP, 1};
+    const Epilogue ep{1.f, 1.f};
+    pair_gemm_f32_kernel<false, EPI_FWD, true, 2><<<(unsigned)nblk, QT, 0, st>>>(x, x, y, y + (size_t)NP * 16, po, L, NP, Kp, cap, tiles_m, tiles_n, ep);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
 }  // namespace ssw

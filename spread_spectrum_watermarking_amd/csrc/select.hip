@@ -526,6 +526,36 @@ int launch_extract(hipStream_t st, const float* base, const float* derived, size
     return SSW_OK;
 }
 
+// The same with the derived coefficients taken from the compact plane of the pruned transform (prune.hip):
+// derived value of index j = (u, v) sits at compact[f][u][pos[v]].
+__global__ __launch_bounds__(256) void extract_pruned_kernel(const float* __restrict__ base,
+                                                             const float* __restrict__ compact, size_t plane_len,
+                                                             unsigned W, unsigned H, unsigned cap,
+                                                             const uint32_t* __restrict__ pos,
+                                                             const uint32_t* __restrict__ indices, size_t k,
+                                                             int method, float alpha, float* __restrict__ out) {
+    const size_t f = blockIdx.y;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    const uint32_t j = indices[f * k + i];
+    const uint32_t u = j / W, v = j - u * W;
+    const uint32_t p = pos[v];
+    // p == none only in a chunk whose column set overflowed; the caller redoes that chunk
+    const float d = p != 0xFFFFFFFFu ? compact[(f * H + u) * (size_t)cap + p] : 0.0f;
+    out[f * k + i] = extract_fn(method, alpha, base[f * plane_len + j], d);
+}
+
+int launch_extract_pruned(hipStream_t st, const float* base, const float* compact, size_t n_frames, size_t w, size_t h,
+                          size_t cap, const uint32_t* pos, const uint32_t* indices, size_t k, int method, float alpha,
+                          float* out) {
+    if (n_frames == 0 || k == 0) return SSW_OK;
+    const dim3 grid((unsigned)((k + 255) / 256), (unsigned)n_frames);
+    extract_pruned_kernel<<<grid, 256, 0, st>>>(base, compact, w * h, (unsigned)w, (unsigned)h, (unsigned)cap, pos, indices, k,
+                                                method, alpha, out);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
 // Similarity: Tester::similarity (src/algorithm.rs:702-713).  The reference accumulates both
 // sums sequentially in f32; rounding depends on that order, so it is kept: the products are
 // formed in parallel (each is a single rounding either way), one lane does the two running sums.

@@ -1,0 +1,105 @@
+// Host-side helpers shared by ssw_lib.hip (C ABI, handles) and ssw_pipeline.hip (transform chains and the
+// two-lane batch pipelines).
+#pragma once
+
+#include <functional>
+#include <vector>
+
+#include "ssw_internal.hpp"
+
+namespace ssw {
+namespace host {
+
+// Makes the context's GPU current for the duration of one ABI call and restores the caller's device
+// afterwards (a host thread may drive several contexts, or torch on another GPU).
+struct DeviceGuard {
+    int prev = -1, dev;
+    explicit DeviceGuard(int d) : dev(d) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// Device allocation: a failing hipMalloc is reported as SSW_ERR_OUT_OF_MEMORY whatever code the runtime
+// chose for it, and the runtime's sticky error is cleared so that the next call starts clean.
+int dev_malloc(void** p, size_t bytes);
+#define SSW_ALLOC(pp, bytes) SSW_TRY(::ssw::host::dev_malloc((void**)(pp), (bytes)))
+int grow(ssw_ctx::Buf& b, size_t bytes);
+void release(ssw_ctx::Buf& b);
+int grow_select(hipStream_t st, SelectWorkspace& s, size_t frames, size_t k);
+void release_select(SelectWorkspace& s);
+
+// Stage timer: an event pair around a region on `st`, plus the work the region does (executed flop of the
+// GEMM stages, algorithmic bytes of the HBM-bound ones) -- both only while timing is enabled.
+struct StageTimer {
+    ssw_ctx* ctx;
+    int stage;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work = 0.0);
+    ~StageTimer();
+    StageTimer(const StageTimer&) = delete;
+    StageTimer& operator=(const StageTimer&) = delete;
+};
+int flush_timers(ssw_ctx* ctx);
+
+// kind 0 = dense N x N, 1 / 2 = even / odd half basis, 3 / 4 = the same, k-blocked (operand-ready GEMMs)
+int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const void** out);
+
+bool valid_method(int m);
+bool valid_ordering(int o);
+bool valid_precision(int p);
+int check_config(const ssw_config* cfg);
+size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames);
+
+// ---- chains of stages -------------------------------------------------------------------------------
+// A chain is the ordered list of device stages one chunk goes through.  Every stage is either HBM-bound
+// (pre-passes, selection, colour conversion, O(k) kernels) or a group of basis-GEMM launches; the batch
+// pipelines put the two kinds on different streams, everything else runs a chain on one stream.
+struct Stage {
+    bool hbm;
+    std::function<int(hipStream_t)> run;
+};
+typedef std::vector<Stage> Chain;
+
+// dct2d::dct2_2d on n contiguous planes, `data` in place, `tmp` same-size scratch; `ws` supplies the operand
+// planes.  `rgb` (optional; rows-first forward transforms the fused pre-pass accepts, see can_fuse_rgb):
+// the frames `data` would have been converted from -- the first pass reads them directly and `data` is
+// only written by the last pass; iq_i / iq_q receive the I and Q planes (both or neither).
+struct Xform {
+    int type, precision;
+    size_t n, w, h;
+    float* data;
+    float* tmp;
+    const void* rgb = nullptr;
+    bool rgb_u8 = false;
+    float* iq_i = nullptr;
+    float* iq_q = nullptr;
+};
+int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch);
+bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8);
+// rgb -> Y (+ I, Q) -> forward transform of Y into `y` (Writer::new / Reader::new_impl), fused where possible
+int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t n, size_t w,
+                           size_t h, float* y, float* i, float* q, float* tmp, Chain& ch);
+int run_serial(Chain& ch, hipStream_t st);
+// transform now, on the context's stream, with lane 0's workspace (handles, ssw_dct2d)
+int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size_t h, float* data, float* tmp);
+
+// first k entries of the reference's ordering for n planes (select.hip; full sort beyond its limit)
+int topk(ssw_ctx* ctx, hipStream_t st, SelectWorkspace& sel, const float* coef, size_t n, size_t w, size_t h, int ordering,
+         size_t k, uint32_t* idx);
+
+int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, bool u8_in, size_t n_frames, size_t w,
+                     size_t h, const float* dev_marks, size_t k, void* dev_rgb_out, bool u8_out, float* dev_coef_out,
+                     uint32_t* dev_indices_out);
+int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base_rgb, const void* dev_derived_rgb, bool u8,
+                       size_t n_frames, size_t w, size_t h, size_t k, float* dev_extracted, const float* dev_marks,
+                       float* dev_sims);
+
+}  // namespace host
+}  // namespace ssw

@@ -112,6 +112,26 @@ int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind
                              const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep);
 
+int launch_dct_pair_gemm_rows_subset_f64(hipStream_t st, const double* x, const double* y, unsigned cap, unsigned Kp, float* out,
+                                         unsigned out_stride, unsigned off, size_t lines);
+int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const float* y, unsigned cap, unsigned Kp, float* out,
+                                         unsigned out_stride, unsigned off, size_t lines);
+
+// prune.hip: the derived frame's transform restricted to the frequency columns a chunk's index lists use
+struct PruneClass { unsigned mod, rem, cap, off; };      // v in the class when v % mod == rem; basis row v / mod
+struct PrunePlan {
+    unsigned n_classes = 0;
+    PruneClass c[4];
+    unsigned W = 0, cap_total = 0;
+};
+int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,
+                       uint32_t* flag /*[W]*/, uint32_t* rows /*[cap_total]*/, uint32_t* pos /*[W]*/, uint32_t* info /*[8]*/);
+int launch_prune_gather_basis(hipStream_t st, const uint32_t* rows, unsigned cap, const void* src, size_t src_rows,
+                              size_t kblocks, void* dst);
+int launch_extract_pruned(hipStream_t st, const float* base, const float* compact, size_t n_frames, size_t w, size_t h,
+                          size_t cap, const uint32_t* pos, const uint32_t* indices, size_t k, int method, float alpha,
+                          float* out);
+
 // select.hip
 struct SelectWorkspace {
     uint32_t* hist = nullptr;       // [n_frames][2048] sample histogram
@@ -182,10 +202,29 @@ struct ssw_ctx {
         void* p = nullptr;
         size_t bytes = 0;
     };
-    Buf plane[4];                 // y / i / q / t planes of the current chunk
-    Buf operand[5];               // operand planes of the operand-ready GEMMs (fold_level 3 / 4): S|E, D|O, SS|EE, SD|EO, T
-    Buf idx;                      // [chunk][k] u32
-    ssw::SelectWorkspace sel;
+    // A lane = the workspace of one chunk in flight.  The batch entry points keep two chunks in flight
+    // (ssw_ctx_set_overlap): while one lane's basis GEMMs run on the context's stream, the other lane's
+    // HBM-bound stages (operand pre-passes, selection, colour conversion) run on `aux_stream`.
+    struct Lane {
+        Buf plane[4];             // y / i / q / t planes of the chunk
+        Buf operand[5];           // operand planes of the operand-ready GEMMs: S|E, D|O, SS|EE, SD|EO, T
+        Buf idx;                  // [chunk][k] u32
+        ssw::SelectWorkspace sel;
+        Buf compact[2];           // pruned derived transform: row-pass result, column-pass result [chunk][H][cap]
+        Buf gathered;             // gathered half bases of the chunk's frequency classes
+        Buf prune_u32;            // flag [W] | pos [W] | rows [cap] | info [8]
+        hipStream_t cur = nullptr;   // stream the lane's chain currently runs on
+    };
+    static constexpr int MAX_LANES = 2;
+    Lane lane[MAX_LANES];
+    hipStream_t aux_stream = nullptr;     // HBM-bound stages of the batch pipelines
+    bool overlap = true;                  // two lanes / two streams in the batch entry points
+    bool prune = true;                    // batch extract: derived transform only where the index lists need it
+    std::vector<hipEvent_t> sync_events;  // cross-stream dependencies (ring)
+    size_t sync_next = 0;
+    Buf overflow;                         // [chunks] u32 flags of the pruned path (+ class counts)
+    uint64_t pruned_chunks = 0, redone_chunks = 0;
+    uint64_t pruned_columns = 0;          // sum over pruned chunks of the compact plane width (cap_total)
     Buf small;                    // misc (mark offsets, sims, ...)
     Buf sort_scratch;             // full-order sort (lazy, Reader::indices beyond the top-k limit)
     Buf resize_tmp;               // f32 intermediate of the resize's vertical pass
@@ -195,6 +234,7 @@ struct ssw_ctx {
     bool timing = false;
     double stage_ms[SSW_STAGE_COUNT] = {0};
     uint64_t stage_launches[SSW_STAGE_COUNT] = {0};
+    double stage_work[SSW_STAGE_COUNT] = {0};     // executed flop (GEMM stages) / algorithmic bytes (HBM-bound stages)
     struct Pending {
         int stage;
         hipEvent_t a, b;

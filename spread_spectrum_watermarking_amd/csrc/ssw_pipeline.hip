@@ -1,0 +1,736 @@
+// Orchestration of the reference's call stacks on the device: the 2-D transform as a chain of stages
+// (operand pre-passes = HBM-bound, basis GEMMs = MFMA-bound), the pruned transform of derived frames, and
+// the two-lane pipelines behind ssw_batch_embed / ssw_batch_extract.
+//
+// Two lanes, two streams.  A chunk's stages depend on each other in sequence, and they alternate between
+// HBM-bound and MFMA-bound kernels; a single stream therefore leaves the matrix cores idle during ~13 % of
+// a 4K step (25 % at full HD) and HBM idle for the rest.  The batch pipelines keep two chunks in flight,
+// each with its own workspace ("lane"): every GEMM stage goes to the context's stream, every HBM-bound
+// stage to `aux_stream`, stages are enqueued round-robin over the lanes, and a lane crosses from one
+// stream to the other through an event.  GEMM launches never overlap each other (one stream), so their
+// event timings stay meaningful; what overlaps is one lane's pre-pass / selection / colour conversion with
+// the other lane's GEMMs.  Results are bit-identical to the serial order (same kernels, same chunks).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "ssw_host.hpp"
+
+namespace ssw {
+namespace host {
+
+// ---- small helpers ------------------------------------------------------------------------------------
+int dev_malloc(void** p, size_t bytes) {
+    *p = nullptr;
+    const hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e == hipSuccess) return SSW_OK;
+    (void)hipGetLastError();
+    *p = nullptr;
+    set_last_error(std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+    return SSW_ERR_OUT_OF_MEMORY;
+}
+
+int grow(ssw_ctx::Buf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return SSW_OK;
+    if (b.p) { SSW_HIP_CHECK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }   // hipFree waits for work in flight
+    SSW_ALLOC(&b.p, bytes);
+    b.bytes = bytes ? bytes : 16;
+    return SSW_OK;
+}
+
+void release(ssw_ctx::Buf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+void release_select(SelectWorkspace& s) {
+    if (s.hist) (void)hipFree(s.hist);
+    if (s.ctrl) (void)hipFree(s.ctrl);
+    if (s.cand) (void)hipFree(s.cand);
+    s = SelectWorkspace();
+}
+
+int grow_select(hipStream_t st, SelectWorkspace& s, size_t frames, size_t k) {
+    const size_t want = select_cand_capacity(k);
+    if (s.frames >= frames && s.cap >= want && s.hist) return SSW_OK;
+    const size_t nf = std::max(frames, s.frames), cap = std::max(want, s.cap);
+    release_select(s);
+    SSW_ALLOC(&s.hist, nf * 2048 * sizeof(uint32_t));
+    SSW_ALLOC(&s.ctrl, nf * 4 * sizeof(uint32_t));
+    SSW_ALLOC(&s.cand, nf * cap * sizeof(uint64_t));
+    SSW_HIP_CHECK(hipMemsetAsync(s.hist, 0, nf * 2048 * sizeof(uint32_t), st));   // see select.hip:
+    SSW_HIP_CHECK(hipMemsetAsync(s.ctrl, 0, nf * 4 * sizeof(uint32_t), st));      // zero between uses
+    s.frames = nf;
+    s.cap = cap;
+    return SSW_OK;
+}
+
+StageTimer::StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work) : ctx(c), stage(s), st(stream) {
+    if (!ctx->timing) return;
+    ctx->stage_work[stage] += work;
+    auto get = [&]() {
+        hipEvent_t e = nullptr;
+        if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
+        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+        return e;
+    };
+    a = get(); b = get();
+    if (a) (void)hipEventRecord(a, st);
+}
+StageTimer::~StageTimer() {
+    if (!ctx->timing || !a || !b) return;
+    (void)hipEventRecord(b, st);
+    ctx->pending.push_back({stage, a, b});
+}
+
+int flush_timers(ssw_ctx* ctx) {
+    for (auto& p : ctx->pending) {
+        float ms = 0.f;
+        SSW_HIP_CHECK(hipEventSynchronize(p.b));
+        SSW_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
+        ctx->stage_ms[p.stage] += ms;
+        ctx->stage_launches[p.stage] += 1;
+        ctx->free_events.push_back(p.a);
+        ctx->free_events.push_back(p.b);
+    }
+    ctx->pending.clear();
+    return SSW_OK;
+}
+
+// Bases are generated on the context's stream, the stream every GEMM launch uses.
+int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const void** out) {
+    auto key = std::make_tuple(n, inverse, f64, kind);
+    auto it = ctx->basis.find(key);
+    if (it != ctx->basis.end()) { *out = it->second; return SSW_OK; }
+    void* p = nullptr;
+    const size_t elems = kind == 0 ? n * dense_basis_kpad(n) : kind >= 3 ? (n / 2) * dct_pair_kpad(f64, n) : (n / 2) * half_basis_kpad(n);
+    SSW_ALLOC(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float)));
+    int rc = kind >= 3 ? launch_make_half_basis_blocked(ctx->stream, f64, n, inverse, kind - 3, p)
+             : kind != 0 ? (f64 ? launch_make_half_basis_f64(ctx->stream, n, inverse, kind - 1, (double*)p)
+                              : launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p))
+             : f64     ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
+                       : launch_make_basis_f32(ctx->stream, n, inverse, (float*)p);
+    if (rc != SSW_OK) { (void)hipFree(p); return rc; }
+    ctx->basis[key] = p;
+    *out = p;
+    return SSW_OK;
+}
+
+bool valid_method(int m) { return m == SSW_OPTION1 || m == SSW_OPTION2 || m == SSW_OPTION3; }
+bool valid_ordering(int o) { return o == SSW_ORDER_ENERGY || o == SSW_ORDER_ENERGY_ORTHOGONAL || o == SSW_ORDER_LEGACY; }
+bool valid_precision(int p) { return p == SSW_PRECISION_F32 || p == SSW_PRECISION_F64; }
+
+int check_config(const ssw_config* cfg) {
+    if (!cfg) return SSW_ERR_BAD_ARG;
+    if (cfg->method == SSW_METHOD_CUSTOM || cfg->ordering == SSW_ORDER_CUSTOM) return SSW_ERR_UNSUPPORTED;
+    if (!valid_method(cfg->method) || !valid_ordering(cfg->ordering) || !valid_precision(cfg->precision))
+        return SSW_ERR_BAD_ARG;
+    return SSW_OK;
+}
+
+// Frames per internal pass: the caller's setting, or (0 = automatic, the default) about 2^28 pixels -- 32 4K
+// frames, 129 full-HD ones: the GEMM grids then run ~16 rounds of blocks (a 16-frame pass of 1080p frames
+// only 2.1, 11 % slower) for 36 B/px of workspace per lane (4K: 9.6 GB).
+size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames) {
+    size_t c = ctx->chunk_frames;
+    if (c == 0) c = std::max<size_t>(1, ((size_t)1 << 28) / std::max<size_t>(w * h, 1));
+    return std::min(c, std::max<size_t>(n_frames, 1));
+}
+
+// ---- the 2-D transform as a chain ---------------------------------------------------------------------
+namespace {
+
+int pair_gemm(hipStream_t st, bool f64, bool is_row, bool inverse, int kind, int sub, const void* x1, const void* x2,
+              const void* y1, const void* y2, float* dst, void* tmpE, size_t n, size_t w, size_t h, Epilogue ep) {
+    return f64 ? launch_dct_pair_gemm_f64(st, is_row, inverse, kind, sub, (const double*)x1, (const double*)x2, (const double*)y1,
+                                          (const double*)y2, dst, (double*)tmpE, n, w, h, ep)
+               : launch_dct_pair_gemm_f32(st, is_row, inverse, kind, sub, (const float*)x1, (const float*)x2, (const float*)y1,
+                                          (const float*)y2, dst, (float*)tmpE, n, w, h, ep);
+}
+
+// executed flop of one launch of the operand-ready GEMM (two products of lines x pairs x K multiply-adds)
+double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t h) {
+    const double lines = (double)(is_row ? n * h : n * w);
+    const size_t leff = (is_row ? w : h) >> sub;
+    const double np = (double)(kind == 0 ? leff / 2 : leff / 4), k = (double)(kind == 1 ? leff / 4 : leff / 2);
+    return 4.0 * lines * np * k;
+}
+
+// One pass of the separable transform (src -> dst along rows or columns) appended to `ch`.
+int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass, bool is_row, const float* src, float* dst,
+               Epilogue ep, Chain& ch) {
+    const bool inverse = (x.type == SSW_DCT3);
+    const bool f64 = (x.precision == SSW_PRECISION_F64);
+    const int precision = x.precision;
+    const size_t n = x.n, w = x.w, h = x.h;
+    const size_t len = is_row ? w : h;
+    const double px = (double)n * (double)w * (double)h;
+    const double esz = f64 ? 8.0 : 4.0;
+    const bool fold = ctx->fold && (is_row ? dct_rows_can_fold(w, src, dst) : dct_cols_can_fold(w, h, src, dst));
+    const bool operand = fold && ctx->fold_level >= 3 && dct_pair_can_run(f64, n, w, h, src, dst);
+    const bool from_rgb = x.rgb && first_pass;
+    if (from_rgb && !(operand && is_row && ctx->fold_level >= 4 && dct_pair_can_fold2(len)))
+        return SSW_ERR_BAD_ARG;                                    // can_fuse_rgb() checks the same conditions
+    const int st_pass = is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL;
+    const int st_main = is_row ? SSW_STAGE_DCT_ROW_MAIN : SSW_STAGE_DCT_COL_MAIN;
+    const void* rgb = x.rgb;
+    const bool rgb_u8 = x.rgb_u8;
+    float *iq_i = x.iq_i, *iq_q = x.iq_q;
+    // algorithmic bytes of the pre-pass: the f32 plane (or the RGB frame) in, the operand planes (one
+    // element per pixel in the GEMM's precision, whatever the number of folding levels) and I / Q out
+    const double prep_bytes = from_rgb ? px * ((rgb_u8 ? 3.0 : 12.0) + (iq_i ? 8.0 : 0.0) + esz) : px * (4.0 + esz);
+    const int st_prep = from_rgb ? SSW_STAGE_RGB_TO_YIQ : SSW_STAGE_DCT_PREP;
+    if (operand) {
+        const size_t bytes = dct_pair_operand_elems(f64, n, w, h) * (size_t)esz;
+        const bool two = ctx->fold_level >= 4 && (is_row ? dct_pair_can_fold2(len) : dct_pair_can_fold2_cols(len));
+        const void *b0 = nullptr, *b1 = nullptr;
+        SSW_TRY(get_basis(ctx, len, inverse, f64, 3, &b0));        // k-blocked half bases
+        SSW_TRY(get_basis(ctx, len, inverse, f64, 4, &b1));
+        // a third level pays once the sums are long enough (4K: +1.6 %, 1080p: -3 %); level 6 forces it
+        const bool three = two && !inverse && is_row && dct_pair_can_fold3(len) &&
+                           (ctx->fold_level >= 6 || (ctx->fold_level == 5 && len >= 3072));
+        if (three) {
+            // forward row pass, three levels: x- (odd frequencies), S- (2 mod 4), (SSS, SS-) (0 and 4 mod 8)
+            for (int b = 0; b < 4; ++b) SSW_TRY(grow(ws.operand[b], bytes));
+            void* d1 = ws.operand[1].p;
+            void* d2 = ws.operand[0].p;
+            void* r1 = ws.operand[2].p;
+            void* r2 = ws.operand[3].p;
+            const void *h1 = nullptr, *e0 = nullptr, *e1 = nullptr;
+            SSW_TRY(get_basis(ctx, len / 2, false, f64, 4, &h1));          // odd half basis of len/2
+            SSW_TRY(get_basis(ctx, len / 4, false, f64, 3, &e0));          // half bases of len/4
+            SSW_TRY(get_basis(ctx, len / 4, false, f64, 4, &e1));
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_prep, st, prep_bytes);
+                return launch_dct_pair_prep8_rows(st, f64, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h,
+                                                  r1, r2, d2, d1, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
+            }});
+            const double f_main = pair_gemm_flop(is_row, 2, 0, n, w, h);
+            const double f_all = f_main + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 2, 1, n, w, h);
+            ch.push_back({false, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_pass, st, f_all);
+                SSW_TRY(pair_gemm(st, f64, is_row, inverse, 1, 1, r1, r2, e0, e1, dst, nullptr, n, w, h, ep));
+                SSW_TRY(pair_gemm(st, f64, is_row, inverse, 2, 1, d2, d2, h1, (const char*)h1 + (len / 8) * 64, dst, nullptr, n, w, h, ep));
+                StageTimer tm(ctx, st_main, st, f_main);
+                return pair_gemm(st, f64, is_row, inverse, 2, 0, d1, d1, b1, (const char*)b1 + (len / 4) * 64, dst, nullptr, n, w, h, ep);
+            }});
+        } else if (!two) {
+            for (int b = 0; b < 2; ++b) SSW_TRY(grow(ws.operand[b], bytes));
+            void* x1 = ws.operand[0].p;
+            void* x2 = ws.operand[1].p;
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, SSW_STAGE_DCT_PREP, st, prep_bytes);
+                return launch_dct_pair_prep(st, f64, is_row, inverse, src, n, w, h, x1, x2);
+            }});
+            const double f_main = pair_gemm_flop(is_row, 0, 0, n, w, h);
+            ch.push_back({false, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_pass, st, f_main);
+                StageTimer tm(ctx, st_main, st, f_main);
+                return pair_gemm(st, f64, is_row, inverse, 0, 0, x1, x2, b0, b1, dst, nullptr, n, w, h, ep);
+            }});
+        } else {
+            for (int b = 1; b < (inverse ? 5 : 4); ++b) SSW_TRY(grow(ws.operand[b], bytes));
+            void* x2 = ws.operand[1].p;       // D | O
+            void* xx1 = ws.operand[2].p;      // SS | EE
+            void* xx2 = ws.operand[3].p;      // SD | EO
+            void* tmpE = ws.operand[4].p;     // inverse: the even half E, unrounded
+            const void *q0 = nullptr, *q1 = nullptr;
+            SSW_TRY(get_basis(ctx, len / 2, inverse, f64, 3, &q0));
+            SSW_TRY(get_basis(ctx, len / 2, inverse, f64, 4, &q1));
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_prep, st, prep_bytes);
+                if (from_rgb) return launch_dct_pair_prep4_rows_rgb(st, f64, rgb_u8, rgb, n, w, h, xx1, xx2, x2, iq_i, iq_q);
+                return launch_dct_pair_prep4(st, f64, is_row, inverse, src, n, w, h, xx1, xx2, x2);
+            }});
+            const double f_main = pair_gemm_flop(is_row, 2, 0, n, w, h);
+            const double f_all = f_main + pair_gemm_flop(is_row, 1, 0, n, w, h);
+            ch.push_back({false, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_pass, st, f_all);
+                // even half: a half-length transform of S (forward) / of the even coefficients (inverse), folded again
+                SSW_TRY(pair_gemm(st, f64, is_row, inverse, 1, 0, xx1, xx2, q0, q1, dst, tmpE, n, w, h, ep));
+                // odd half: full half-length sum, the odd basis split into two row blocks (second block:
+                // len/4 lines further inside every k-block of the same plane = 64 bytes per line)
+                StageTimer tm(ctx, st_main, st, f_main);
+                return pair_gemm(st, f64, is_row, inverse, 2, 0, x2, x2, b1, (const char*)b1 + (len / 4) * 64, dst, tmpE, n, w, h, ep);
+            }});
+        }
+        return SSW_OK;
+    }
+    const void *b0 = nullptr, *b1 = nullptr;
+    if (fold) {
+        SSW_TRY(get_basis(ctx, len, inverse, f64, 1, &b0));
+        SSW_TRY(get_basis(ctx, len, inverse, f64, 2, &b1));
+    } else {
+        SSW_TRY(get_basis(ctx, len, inverse, f64, 0, &b0));
+    }
+    const double dense = is_row ? 2.0 * n * h * (double)w * w : 2.0 * n * w * (double)h * h;
+    const double flop = fold ? 0.5 * dense : dense;
+    if (is_row) {
+        ch.push_back({false, [=](hipStream_t st) -> int {
+            StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
+            if (fold && f64) return launch_dct_rows_folded_f64(st, inverse, src, dst, n * h, w, (const double*)b0, (const double*)b1, ep);
+            if (fold) return launch_dct_rows_folded_f32(st, inverse, src, dst, n * h, w, (const float*)b0, (const float*)b1, ep);
+            return launch_dct_rows(st, precision, src, dst, n * h, w, b0, ep);
+        }});
+    } else {
+        ch.push_back({false, [=](hipStream_t st) -> int {
+            StageTimer t(ctx, SSW_STAGE_DCT_COL, st, flop);
+            if (fold && f64) return launch_dct_cols_folded_f64(st, inverse, src, dst, n, w, h, (const double*)b0, (const double*)b1, ep);
+            if (fold) return launch_dct_cols_folded_f32(st, inverse, src, dst, n, w, h, (const float*)b0, (const float*)b1, ep);
+            return launch_dct_cols(st, precision, src, dst, n, w, h, b0, ep);
+        }});
+    }
+    return SSW_OK;
+}
+
+// The operand-ready GEMMs walk an operand plane with 32-bit scalar offsets: a call's planes must stay below
+// 4 GB, so more frames than that are transformed in groups (frames are independent).
+size_t operand_frame_limit(const ssw_ctx* ctx, bool f64, size_t w, size_t h) {
+    if (!(ctx->fold && ctx->fold_level >= 3)) return ~(size_t)0;
+    const size_t per_frame = dct_pair_operand_elems(f64, 1, w, h) * (f64 ? sizeof(double) : sizeof(float));
+    const size_t m = per_frame ? 0xFFFFFFFFull / per_frame : ~(size_t)0;
+    return m >= 1 ? m : ~(size_t)0;
+}
+
+}  // namespace
+
+int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch) {
+    const bool f64 = (x.precision == SSW_PRECISION_F64);
+    const size_t n = x.n, w = x.w, h = x.h;
+    if (n == 0) return SSW_OK;
+    const size_t max_frames = operand_frame_limit(ctx, f64, w, h);
+    if (n > max_frames) {
+        for (size_t f0 = 0; f0 < n; f0 += max_frames) {
+            Xform s = x;
+            s.n = std::min(max_frames, n - f0);
+            s.data = x.data + f0 * w * h;
+            s.tmp = x.tmp + f0 * w * h;
+            if (x.rgb) s.rgb = static_cast<const char*>(x.rgb) + f0 * w * h * 3 * (x.rgb_u8 ? 1 : sizeof(float));
+            if (x.iq_i) s.iq_i = x.iq_i + f0 * w * h;
+            if (x.iq_q) s.iq_q = x.iq_q + f0 * w * h;
+            SSW_TRY(build_transform(ctx, ws, s, ch));
+        }
+        return SSW_OK;
+    }
+    const bool rows_first = (w >= h);                                  // src/dct2d.rs:93-98
+    Epilogue plain{1.f, 1.f};
+    auto ortho = [&](size_t len) {                                      // src/dct2d.rs:154-155
+        Epilogue e{std::sqrt(1.0f / (4.0f * (float)len)), std::sqrt(1.0f / (2.0f * (float)len))};
+        return e;
+    };
+    Epilogue last = plain;
+    if (x.type == SSW_DCT3) last.first = last.base = (float)4 / (float)(w * h);           // :213-217
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool is_row = (pass == 0) ? rows_first : !rows_first;
+        const float* src = (pass == 0) ? x.data : x.tmp;
+        float* dst = (pass == 0) ? x.tmp : x.data;
+        const Epilogue ep = (x.type == SSW_DCT2_ORTHOGONAL) ? ortho(is_row ? w : h) : (pass == 1 ? last : plain);
+        SSW_TRY(build_pass(ctx, ws, x, pass == 0, is_row, src, dst, ep, ch));
+    }
+    return SSW_OK;
+}
+
+bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8) {
+    return ctx->fold && ctx->fold_level >= 4 && dct_pair_can_run(f64, 1, w, h, y, tmp) && dct_pair_can_prep_from_rgb(w, h, rgb, u8);
+}
+
+// Writer::new / Reader::base / Reader::derived: rgb -> Y (+ I, Q) -> forward 2-D DCT of Y into `y`.
+// Where the default GEMM strategy applies (rows first, two folding levels on the row axis) the colour
+// conversion is fused into the first operand pre-pass and the f32 Y plane is never materialised.
+int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t n, size_t w,
+                           size_t h, float* y, float* i, float* q, float* tmp, Chain& ch) {
+    const bool f64 = precision == SSW_PRECISION_F64;
+    Xform x{SSW_DCT2, precision, n, w, h, y, tmp};
+    if (can_fuse_rgb(ctx, f64, w, h, y, tmp, rgb, u8)) {
+        x.rgb = rgb; x.rgb_u8 = u8; x.iq_i = i; x.iq_q = q;
+        return build_transform(ctx, ws, x, ch);
+    }
+    const size_t npix = n * w * h;
+    const double bytes = (double)npix * ((u8 ? 3.0 : 12.0) + (i ? 12.0 : 4.0));
+    ch.push_back({true, [=](hipStream_t st) -> int {
+        StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, bytes);
+        if (u8) return launch_rgb8_to_yiq(st, static_cast<const uint8_t*>(rgb), npix, y, i, q);
+        return launch_rgb_to_yiq(st, static_cast<const float*>(rgb), npix, y, i, q);
+    }});
+    return build_transform(ctx, ws, x, ch);
+}
+
+int run_serial(Chain& ch, hipStream_t st) {
+    for (auto& s : ch) SSW_TRY(s.run(st));
+    return SSW_OK;
+}
+
+int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size_t h, float* data, float* tmp) {
+    Chain ch;
+    Xform x{type, precision, n, w, h, data, tmp};
+    SSW_TRY(build_transform(ctx, ctx->lane[0], x, ch));
+    return run_serial(ch, ctx->stream);
+}
+
+int topk(ssw_ctx* ctx, hipStream_t st, SelectWorkspace& sel, const float* coef, size_t n, size_t w, size_t h, int ordering,
+         size_t k, uint32_t* idx) {
+    const double bytes = 4.0 * (double)n * (double)w * (double)h;
+    if (k > select_max_k()) {
+        // Beyond the in-LDS top-k limit (16384 entries; BASELINE marks are 1000 and 10000 long): a full device
+        // sort of each plane with rocPRIM's radix sort, first k entries kept.  A library call, one frame at
+        // a time, off the hot path: only Reader::indices() with a large k and marks that long reach it.
+        size_t sb = 0;
+        SSW_TRY(full_sort_scratch_bytes(w * h, &sb));
+        SSW_TRY(grow(ctx->sort_scratch, sb));
+        StageTimer t(ctx, SSW_STAGE_SELECT, st, bytes);
+        for (size_t f = 0; f < n; ++f)
+            SSW_TRY(launch_full_sort(st, coef + f * w * h, w, h, ordering, ctx->sort_scratch.p, ctx->sort_scratch.bytes, idx + f * k, k));
+        return SSW_OK;
+    }
+    SSW_TRY(grow_select(st, sel, n, k));
+    StageTimer t(ctx, SSW_STAGE_SELECT, st, bytes);
+    return launch_topk(st, coef, n, w, h, ordering, k, sel, idx);
+}
+
+// ---- two-lane pipeline ----------------------------------------------------------------------------------
+namespace {
+
+int next_sync_event(ssw_ctx* ctx, hipEvent_t* out) {
+    constexpr size_t RING = 256;
+    if (ctx->sync_events.size() < RING) {
+        hipEvent_t e = nullptr;
+        SSW_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        ctx->sync_events.push_back(e);
+        *out = e;
+        return SSW_OK;
+    }
+    *out = ctx->sync_events[ctx->sync_next % RING];
+    ctx->sync_next++;
+    return SSW_OK;
+}
+
+// continue the lane's chain on stream `to`: everything the lane enqueued so far happens before
+int hop(ssw_ctx* ctx, ssw_ctx::Lane& ln, hipStream_t to) {
+    if (ln.cur == to) return SSW_OK;
+    hipEvent_t ev = nullptr;
+    SSW_TRY(next_sync_event(ctx, &ev));
+    SSW_HIP_CHECK(hipEventRecord(ev, ln.cur));
+    SSW_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
+    ln.cur = to;
+    return SSW_OK;
+}
+
+// Runs build(chunk, lane, chain) for every chunk and enqueues the chains: one lane on one stream when
+// overlap is off, else two lanes round-robin with GEMM stages on ctx->stream and HBM-bound stages on
+// ctx->aux_stream.  On return the context's stream is ordered after everything that was enqueued.
+int run_pipeline(ssw_ctx* ctx, size_t n_chunks, const std::function<int(size_t, ssw_ctx::Lane&, Chain&)>& build) {
+    if (n_chunks == 0) return SSW_OK;
+    const bool two = ctx->overlap && n_chunks > 1 && ctx->aux_stream != nullptr;
+    hipStream_t G = ctx->stream, H = two ? ctx->aux_stream : ctx->stream;
+    const int n_lanes = two ? 2 : 1;
+    if (two) {                                     // the caller's earlier work on the context's stream comes first
+        hipEvent_t ev = nullptr;
+        SSW_TRY(next_sync_event(ctx, &ev));
+        SSW_HIP_CHECK(hipEventRecord(ev, G));
+        SSW_HIP_CHECK(hipStreamWaitEvent(H, ev, 0));
+    }
+    Chain chain[ssw_ctx::MAX_LANES];
+    size_t at[ssw_ctx::MAX_LANES] = {0, 0};
+    bool active[ssw_ctx::MAX_LANES] = {false, false};
+    size_t next = 0;
+    auto start = [&](int l) -> int {
+        active[l] = false;
+        while (next < n_chunks) {
+            chain[l].clear();
+            at[l] = 0;
+            SSW_TRY(build(next++, ctx->lane[l], chain[l]));
+            if (!chain[l].empty()) { active[l] = true; break; }
+        }
+        return SSW_OK;
+    };
+    for (int l = 0; l < n_lanes; ++l) {
+        ctx->lane[l].cur = H;
+        SSW_TRY(start(l));
+    }
+    while (active[0] || active[1]) {
+        for (int l = 0; l < n_lanes; ++l) {
+            if (!active[l]) continue;
+            Stage& s = chain[l][at[l]];
+            SSW_TRY(hop(ctx, ctx->lane[l], s.hbm ? H : G));
+            SSW_TRY(s.run(ctx->lane[l].cur));
+            if (++at[l] == chain[l].size()) SSW_TRY(start(l));
+        }
+    }
+    for (int l = 0; l < n_lanes; ++l) SSW_TRY(hop(ctx, ctx->lane[l], G));
+    return SSW_OK;
+}
+
+// ---- pruned transform of the derived frames (prune.hip) ---------------------------------------------------
+struct PruneSetup {
+    bool on = false;
+    PrunePlan plan;
+    int levels = 0;                 // folding levels of the forward row pass: 2 or 3
+};
+
+// capacity of the compact plane in frequency columns: the index lists of natural spectra use ~3 sqrt(k)
+// distinct columns (measured: 80..110 for k = 1000 at full HD and 4K); 8 sqrt(k), split over the classes
+// in proportion to their share of all frequencies, leaves a wide margin, and a chunk that does not fit is
+// redone with the full transform.
+size_t prune_capacity(size_t k) {
+    size_t c = (size_t)std::ceil(8.0 * std::sqrt((double)k));
+    c = (c + 31) / 32 * 32;
+    return std::max<size_t>(c, 64);
+}
+
+PruneSetup make_prune_setup(const ssw_ctx* ctx, bool f64, size_t n, size_t w, size_t h, size_t k, const float* y, const float* tmp,
+                            const void* rgb, bool u8) {
+    PruneSetup ps;
+    if (!ctx->prune || k == 0) return ps;
+    if (!can_fuse_rgb(ctx, f64, w, h, y, tmp, rgb, u8)) return ps;       // rows first, >= two folding levels on the rows
+    if (!dct_pair_can_run(f64, n, w, h, y, tmp)) return ps;               // the chunk's planes within the 4 GB walk
+    const size_t cap = prune_capacity(k);
+    if (cap * 4 > w) return ps;                                           // not worth it: full transform
+    if (!dct_pair_can_run(f64, n, cap, h, y, tmp)) return ps;
+    const bool three = dct_pair_can_fold3(w) && (ctx->fold_level >= 6 || (ctx->fold_level == 5 && w >= 3072));
+    ps.levels = three ? 3 : 2;
+    ps.plan.W = (unsigned)w;
+    ps.plan.cap_total = (unsigned)cap;
+    const unsigned c = (unsigned)cap;
+    if (three) {
+        ps.plan.n_classes = 4;
+        ps.plan.c[0] = {2, 1, c / 2, 0};
+        ps.plan.c[1] = {4, 2, c / 4, c / 2};
+        ps.plan.c[2] = {8, 0, c / 8, c / 2 + c / 4};
+        ps.plan.c[3] = {8, 4, c / 8, c / 2 + c / 4 + c / 8};
+    } else {
+        ps.plan.n_classes = 3;
+        ps.plan.c[0] = {2, 1, c / 2, 0};
+        ps.plan.c[1] = {4, 0, c / 4, c / 2};
+        ps.plan.c[2] = {4, 2, c / 4, c / 2 + c / 4};
+    }
+    ps.on = true;
+    return ps;
+}
+
+// derived rgb frames -> compact coefficient plane ws.compact[1] [n][h][cap_total] holding, for every
+// frequency column the chunk's index lists use, the column the full transform would produce
+int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t n, size_t w,
+                         size_t h, size_t k, const uint32_t* idx, const PruneSetup& ps, uint32_t* info, Chain& ch) {
+    const bool f64 = precision == SSW_PRECISION_F64;
+    const size_t esz = f64 ? 8 : 4;
+    const PrunePlan plan = ps.plan;
+    const size_t cap = plan.cap_total;
+    const size_t bytes = dct_pair_operand_elems(f64, n, w, h) * esz;
+    for (int b = 0; b < 4; ++b) SSW_TRY(grow(ws.operand[b], bytes));
+    for (int b = 0; b < 2; ++b) SSW_TRY(grow(ws.compact[b], n * h * cap * sizeof(float)));
+    SSW_TRY(grow(ws.prune_u32, (2 * w + cap + 64) * sizeof(uint32_t)));
+    uint32_t* flag = (uint32_t*)ws.prune_u32.p;
+    uint32_t* pos = flag + w;
+    uint32_t* rows = pos + w;
+    // class -> image operand plane, cached half basis, padded / true sum length
+    struct ClassSrc { const void* x; const void* basis; size_t src_rows, kp, ktrue; };
+    ClassSrc cs[4];
+    const void *b1 = nullptr;
+    SSW_TRY(get_basis(ctx, w, false, f64, 4, &b1));
+    if (ps.levels == 3) {
+        const void *h1 = nullptr, *e0 = nullptr, *e1 = nullptr;
+        SSW_TRY(get_basis(ctx, w / 2, false, f64, 4, &h1));
+        SSW_TRY(get_basis(ctx, w / 4, false, f64, 3, &e0));
+        SSW_TRY(get_basis(ctx, w / 4, false, f64, 4, &e1));
+        cs[0] = {ws.operand[1].p, b1, w / 2, dct_pair_kpad(f64, w), w / 2};          // x-  : odd
+        cs[1] = {ws.operand[0].p, h1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // S-  : 2 mod 4
+        cs[2] = {ws.operand[2].p, e0, w / 8, dct_pair_kpad(f64, w / 4), w / 8};      // SSS : 0 mod 8
+        cs[3] = {ws.operand[3].p, e1, w / 8, dct_pair_kpad(f64, w / 4), w / 8};      // SS- : 4 mod 8
+    } else {
+        const void *q0 = nullptr, *q1 = nullptr;
+        SSW_TRY(get_basis(ctx, w / 2, false, f64, 3, &q0));
+        SSW_TRY(get_basis(ctx, w / 2, false, f64, 4, &q1));
+        cs[0] = {ws.operand[1].p, b1, w / 2, dct_pair_kpad(f64, w), w / 2};          // D  : odd
+        cs[1] = {ws.operand[2].p, q0, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SS : 0 mod 4
+        cs[2] = {ws.operand[3].p, q1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SD : 2 mod 4
+    }
+    size_t goff[4], gtotal = 0;
+    for (unsigned c = 0; c < plan.n_classes; ++c) { goff[c] = gtotal; gtotal += cs[c].kp * plan.c[c].cap * esz; }
+    SSW_TRY(grow(ws.gathered, gtotal));
+    char* gathered = (char*)ws.gathered.p;
+    float* t_compact = (float*)ws.compact[0].p;
+    void *o0 = ws.operand[0].p, *o1 = ws.operand[1].p, *o2 = ws.operand[2].p, *o3 = ws.operand[3].p;
+    const int levels = ps.levels;
+    const double px = (double)n * (double)w * (double)h;
+    const double prep_bytes = px * ((u8 ? 3.0 : 12.0) + (double)esz);
+    // the set of columns, then Reader::derived's colour conversion + operand pre-pass (same kernels as the full path)
+    ch.push_back({true, [=](hipStream_t st) -> int {
+        SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
+        StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, prep_bytes);
+        if (levels == 3) return launch_dct_pair_prep8_rows(st, f64, u8 ? 2 : 1, rgb, n, w, h, o2, o3, o0, o1, nullptr, nullptr);
+        return launch_dct_pair_prep4_rows_rgb(st, f64, u8, rgb, n, w, h, o2, o3, o1, nullptr, nullptr);
+    }});
+    double flop = 0.0;
+    for (unsigned c = 0; c < plan.n_classes; ++c) flop += 2.0 * (double)(n * h) * plan.c[c].cap * (double)cs[c].ktrue;
+    ch.push_back({false, [=](hipStream_t st) -> int {
+        for (unsigned c = 0; c < plan.n_classes; ++c)
+            SSW_TRY(launch_prune_gather_basis(st, rows + plan.c[c].off, plan.c[c].cap, cs[c].basis, cs[c].src_rows,
+                                              cs[c].kp / (64 / esz), gathered + goff[c]));
+        StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
+        for (unsigned c = 0; c < plan.n_classes; ++c) {
+            if (f64) SSW_TRY(launch_dct_pair_gemm_rows_subset_f64(st, (const double*)cs[c].x, (const double*)(gathered + goff[c]), plan.c[c].cap,
+                                                                  (unsigned)cs[c].kp, t_compact, (unsigned)cap, plan.c[c].off, n * h));
+            else     SSW_TRY(launch_dct_pair_gemm_rows_subset_f32(st, (const float*)cs[c].x, (const float*)(gathered + goff[c]), plan.c[c].cap,
+                                                                  (unsigned)cs[c].kp, t_compact, (unsigned)cap, plan.c[c].off, n * h));
+        }
+        return SSW_OK;
+    }});
+    // column pass on the compact plane: the second pass of the same transform, `cap` columns wide
+    Xform xc{SSW_DCT2, precision, n, cap, h, (float*)ws.compact[1].p, t_compact};
+    return build_pass(ctx, ws, xc, false, false, t_compact, (float*)ws.compact[1].p, Epilogue{1.f, 1.f}, ch);
+}
+
+}  // namespace
+
+// ---- Writer::new + Writer::mark, batched ------------------------------------------------------------------
+int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, bool u8_in, size_t n_frames, size_t w,
+                     size_t h, const float* dev_marks, size_t k, void* dev_rgb_out, bool u8_out, float* dev_coef_out,
+                     uint32_t* dev_indices_out) {
+    if (!ctx || !dev_rgb || !dev_marks || !dev_rgb_out) return SSW_ERR_BAD_ARG;
+    SSW_TRY(check_config(cfg));
+    if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
+    const size_t plane = w * h;
+    const size_t k_eff = std::min(k, plane - 1);                       // zip() truncation, :396: a longer mark is cut silently
+    DeviceGuard g(ctx->device);
+    const size_t chunk = effective_chunk(ctx, w, h, n_frames);
+    const size_t n_chunks = (n_frames + chunk - 1) / chunk;
+    const ssw_config c = *cfg;
+    const size_t in_px = u8_in ? 3 : 3 * sizeof(float), out_px = u8_out ? 3 : 3 * sizeof(float);
+    auto build = [&](size_t ci, ssw_ctx::Lane& ws, Chain& ch) -> int {
+        const size_t f0 = ci * chunk, n = std::min(chunk, n_frames - f0);
+        for (int p = 0; p < 4; ++p) SSW_TRY(grow(ws.plane[p], chunk * plane * sizeof(float)));
+        SSW_TRY(grow(ws.idx, chunk * std::max<size_t>(k_eff, 1) * sizeof(uint32_t)));
+        float* y = (float*)ws.plane[0].p;
+        float* pi = (float*)ws.plane[1].p;
+        float* pq = (float*)ws.plane[2].p;
+        float* tmp = (float*)ws.plane[3].p;
+        const char* rgb = static_cast<const char*>(dev_rgb) + f0 * plane * in_px;
+        char* out = static_cast<char*>(dev_rgb_out) + f0 * plane * out_px;
+        uint32_t* idx = dev_indices_out ? dev_indices_out + f0 * k_eff : (uint32_t*)ws.idx.p;
+        float* coef_out = dev_coef_out ? dev_coef_out + f0 * plane : nullptr;
+        const float* marks = dev_marks + f0 * k;
+        SelectWorkspace* sel = &ws.sel;
+        SSW_TRY(build_forward_from_rgb(ctx, ws, c.precision, rgb, u8_in, n, w, h, y, pi, pq, tmp, ch));   // Writer::new :308-313
+        ch.push_back({true, [=](hipStream_t st) -> int {
+            if (coef_out) SSW_HIP_CHECK(hipMemcpyAsync(coef_out, y, n * plane * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (k_eff == 0) return SSW_OK;
+            SSW_TRY(topk(ctx, st, *sel, y, n, w, h, c.ordering, k_eff, idx));                              // :314 (first k only)
+            StageTimer t(ctx, SSW_STAGE_EMBED, st);                                                       // :356
+            return launch_embed(st, y, n, plane, idx, k_eff, marks, nullptr, nullptr, 1, k_eff, k, c.method, c.alpha);
+        }});
+        SSW_TRY(build_transform(ctx, ws, Xform{SSW_DCT3, c.precision, n, w, h, y, tmp}, ch));              // :368-374
+        const double out_bytes = (double)n * plane * (12.0 + (u8_out ? 3.0 : 12.0));
+        ch.push_back({true, [=](hipStream_t st) -> int {
+            StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB, st, out_bytes);                                       // :377 (+ into_rgb8)
+            if (u8_out) return launch_yiq_to_rgb8(st, y, pi, pq, n * plane, reinterpret_cast<uint8_t*>(out));
+            return launch_yiq_to_rgb(st, y, pi, pq, n * plane, reinterpret_cast<float*>(out));
+        }});
+        return SSW_OK;
+    };
+    return run_pipeline(ctx, n_chunks, build);
+}
+
+// ---- Reader::base + Reader::derived + extract (+ Tester::similarity), batched --------------------------------
+int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base_rgb, const void* dev_derived_rgb, bool u8,
+                       size_t n_frames, size_t w, size_t h, size_t k, float* dev_extracted, const float* dev_marks,
+                       float* dev_sims) {
+    if (!ctx || !dev_base_rgb || !dev_derived_rgb || !dev_extracted) return SSW_ERR_BAD_ARG;
+    if ((dev_marks == nullptr) != (dev_sims == nullptr)) return SSW_ERR_BAD_ARG;
+    SSW_TRY(check_config(cfg));
+    if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
+    const size_t plane = w * h;
+    if (k >= plane) return SSW_ERR_K_TOO_LARGE;                        // :553-555
+    if (n_frames == 0) return SSW_OK;
+    DeviceGuard g(ctx->device);
+    const size_t chunk = effective_chunk(ctx, w, h, n_frames);
+    const size_t n_chunks = (n_frames + chunk - 1) / chunk;
+    const ssw_config c = *cfg;
+    const bool f64 = c.precision == SSW_PRECISION_F64;
+    const size_t px_bytes = u8 ? 3 : 3 * sizeof(float);
+    // planes of lane 0 decide the (alignment-dependent) strategy for all lanes: hipMalloc'd, always 256-byte aligned
+    for (int l = 0; l < ssw_ctx::MAX_LANES; ++l)
+        for (int p : {0, 2}) SSW_TRY(grow(ctx->lane[l].plane[p], chunk * plane * sizeof(float)));
+    const PruneSetup ps = make_prune_setup(ctx, f64, std::min(chunk, n_frames), w, h, k, (const float*)ctx->lane[0].plane[0].p,
+                                           (const float*)ctx->lane[0].plane[2].p, dev_derived_rgb, u8);
+    if (ps.on) SSW_TRY(grow(ctx->overflow, n_chunks * 8 * sizeof(uint32_t)));
+    uint32_t* overflow = (uint32_t*)ctx->overflow.p;
+
+    // extract + similarity of one chunk from full coefficient planes (the un-pruned path and the redo)
+    auto full_derived = [&](ssw_ctx::Lane& ws, size_t f0, size_t n, float* yb, float* tmp, uint32_t* idx, Chain& ch) -> int {
+        SSW_TRY(grow(ws.plane[1], chunk * plane * sizeof(float)));
+        float* yd = (float*)ws.plane[1].p;
+        const char* drgb = static_cast<const char*>(dev_derived_rgb) + f0 * plane * px_bytes;
+        SSW_TRY(build_forward_from_rgb(ctx, ws, c.precision, drgb, u8, n, w, h, yd, nullptr, nullptr, tmp, ch));   // Reader::derived
+        float* ext = dev_extracted + f0 * k;
+        const float* marks = dev_marks ? dev_marks + f0 * k : nullptr;
+        float* sims = dev_sims ? dev_sims + f0 : nullptr;
+        ch.push_back({true, [=](hipStream_t st) -> int {
+            if (k > 0) {
+                StageTimer t(ctx, SSW_STAGE_EXTRACT, st);                           // :529-539
+                SSW_TRY(launch_extract(st, yb, yd, n, plane, idx, k, c.method, c.alpha, ext));
+            }
+            if (marks) {
+                StageTimer t(ctx, SSW_STAGE_SIMILARITY, st);                        // :696-714
+                SSW_TRY(launch_similarity(st, ext, marks, n, k, sims));
+            }
+            return SSW_OK;
+        }});
+        return SSW_OK;
+    };
+    auto build_chunk = [&](size_t ci, ssw_ctx::Lane& ws, Chain& ch, bool pruned) -> int {
+        const size_t f0 = ci * chunk, n = std::min(chunk, n_frames - f0);
+        for (int p : {0, 2}) SSW_TRY(grow(ws.plane[p], chunk * plane * sizeof(float)));
+        SSW_TRY(grow(ws.idx, chunk * std::max<size_t>(k, 1) * sizeof(uint32_t)));
+        float* yb = (float*)ws.plane[0].p;
+        float* tmp = (float*)ws.plane[2].p;
+        uint32_t* idx = (uint32_t*)ws.idx.p;
+        const char* brgb = static_cast<const char*>(dev_base_rgb) + f0 * plane * px_bytes;
+        SelectWorkspace* sel = &ws.sel;
+        // Reader::base (:474-480): only the Y plane is ever used by a reader
+        SSW_TRY(build_forward_from_rgb(ctx, ws, c.precision, brgb, u8, n, w, h, yb, nullptr, nullptr, tmp, ch));
+        if (k > 0)
+            ch.push_back({true, [=](hipStream_t st) -> int { return topk(ctx, st, *sel, yb, n, w, h, c.ordering, k, idx); }});   // :493
+        if (!pruned) return full_derived(ws, f0, n, yb, tmp, idx, ch);
+        const char* drgb = static_cast<const char*>(dev_derived_rgb) + f0 * plane * px_bytes;
+        SSW_TRY(build_pruned_derived(ctx, ws, c.precision, drgb, u8, n, w, h, k, idx, ps, overflow + ci * 8, ch));
+        const float* compact = (const float*)ws.compact[1].p;
+        const uint32_t* pos = (const uint32_t*)ws.prune_u32.p + w;
+        const size_t cap = ps.plan.cap_total;
+        float* ext = dev_extracted + f0 * k;
+        const float* marks = dev_marks ? dev_marks + f0 * k : nullptr;
+        float* sims = dev_sims ? dev_sims + f0 : nullptr;
+        ch.push_back({true, [=](hipStream_t st) -> int {
+            {
+                StageTimer t(ctx, SSW_STAGE_EXTRACT, st);                           // :529-539, derived values from the compact plane
+                SSW_TRY(launch_extract_pruned(st, yb, compact, n, w, h, cap, pos, idx, k, c.method, c.alpha, ext));
+            }
+            if (marks) {
+                StageTimer t(ctx, SSW_STAGE_SIMILARITY, st);                        // :696-714
+                SSW_TRY(launch_similarity(st, ext, marks, n, k, sims));
+            }
+            return SSW_OK;
+        }});
+        return SSW_OK;
+    };
+    SSW_TRY(run_pipeline(ctx, n_chunks, [&](size_t ci, ssw_ctx::Lane& ws, Chain& ch) { return build_chunk(ci, ws, ch, ps.on); }));
+    if (!ps.on) return SSW_OK;
+    // Chunks whose column set did not fit the compact plane are redone with the full transform.  This is
+    // the one place a batch call waits for the device.
+    std::vector<uint32_t> info(n_chunks * 8);
+    SSW_HIP_CHECK(hipMemcpyAsync(info.data(), overflow, info.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t ci = 0; ci < n_chunks; ++ci) {
+        ctx->pruned_chunks++;
+        for (unsigned q = 0; q < ps.plan.n_classes; ++q) ctx->pruned_columns += info[ci * 8 + 1 + q];
+        if (info[ci * 8] == 0) continue;
+        ctx->redone_chunks++;
+        Chain ch;
+        SSW_TRY(build_chunk(ci, ctx->lane[0], ch, false));
+        SSW_TRY(run_serial(ch, ctx->stream));
+    }
+    return SSW_OK;
+}
+
+}  // namespace host
+}  // namespace ssw

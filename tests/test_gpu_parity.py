@@ -628,6 +628,118 @@ def test_4k_size_independent_properties():
     assert np.abs(ext - marks).max() < 0.05                      # Option2, alpha 0.1: clamp / round-off of the round trip
 
 
+def _whole_pipeline_vs_oracle(w, h, k, seed, frame):
+    """One frame through ssw_batch_embed + ssw_batch_extract (canonical precision, default strategy incl.
+    the pruned derived transform) against the oracle's exact pipeline: coefficients, the index list,
+    the marked frame, the extracted mark and the similarity."""
+    rgb = G.synth(seed, frame, 1, w, h)
+    assert np.array_equal(rgb[0], O.synth_frame(seed, frame, w, h))
+    mark = np.random.default_rng(seed * 100 + frame).standard_normal((1, k)).astype(np.float32)
+    res = G.batch_embed(rgb, mark, want_coef=True, want_idx=True)
+    ref_coef = O.dct2d(O.rgb_to_yiq(rgb[0])[0])
+    assert np.mean(res["coef"][0] == ref_coef) > 0.9995
+    assert np.abs(res["coef"][0].astype(np.float64) - ref_coef).max() <= 2e-7 * ac_max(ref_coef)
+    assert np.array_equal(res["idx"][0], O.indices(ref_coef, k=k).astype(np.uint32))
+    ref_marked = O.embed_frame(rgb[0], mark[0])
+    assert np.abs(res["rgb"][0] - ref_marked).max() <= 2e-7 and np.mean(res["rgb"][0] == ref_marked) > 0.999
+    ext, sims = G.batch_extract(rgb, res["rgb"], k, mark)
+    ref_ext, ref_sim = O.extract_frame(rgb[0], ref_marked, mark[0])
+    assert np.abs(ext[0] - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert abs(float(sims[0]) - ref_sim) < 1e-4
+    # the oracle's own marked frame as the derived input: identical inputs on both sides, so extraction is
+    # bit-exact wherever the 2 k coefficients it reads are (a canonical-precision coefficient differs from the
+    # oracle's by one ulp with probability ~1e-6: allow a handful, each worth <= ulp / alpha in the mark)
+    ext_o, sims_o = G.batch_extract(rgb, ref_marked[None], k, mark)
+    assert np.mean(ext_o[0] == ref_ext) >= 0.999 and np.abs(ext_o[0] - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert abs(float(sims_o[0]) - ref_sim) < 1e-5 * abs(ref_sim)
+    return rgb, mark, res
+
+
+def test_4k_pipeline_parity_with_oracle():
+    """BASELINE configs[1] / configs[3] frame size (3840x2160), k = 1000: the whole embed -> extract ->
+    similarity path of one frame against the oracle (the reference flow of algorithm.rs:295-379, :462-562)."""
+    _whole_pipeline_vs_oracle(3840, 2160, 1000, 21, 3)
+
+
+def test_8k_pipeline_and_resize_attack_parity_with_oracle():
+    """BASELINE configs[4]: a 7680x4320 frame with a 10000-coefficient mark -- coefficient, index, extracted
+    mark and similarity parity; then the flow of tests/attack_resize.rs:17-66 at that size (embed ->
+    into_rgb8 -> CatmullRom resize to 12.5 % and back -> extract) against the oracle's run of the same flow."""
+    w, h, k = 7680, 4320, 10000
+    rgb, mark, res = _whole_pipeline_vs_oracle(w, h, k, 31, 1)
+    frame8 = O.f32_to_u8(rgb[0])
+    del rgb, res
+    wm8 = G.batch_embed_rgb8(frame8[None], mark)
+    o_wm8 = O.f32_to_u8(O.embed_frame(O.u8_to_f32(frame8), mark[0]))
+    assert np.mean(wm8[0] == o_wm8) > 0.9999                           # 1-ulp differences of the f32 frame flip few roundings
+    small = G.resize_rgb8(o_wm8, w // 8, h // 8)
+    o_small = O.resize_rgb8(o_wm8, w // 8, h // 8)
+    assert np.array_equal(small, o_small)                               # resize kernels bit-exact at 8K
+    back = G.resize_rgb8(o_small, w, h)
+    o_back = O.resize_rgb8(o_small, w, h)
+    assert np.array_equal(back, o_back)
+    ext, sims = G.batch_extract_rgb8(frame8[None], o_back[None], k, mark)
+    o_ext, o_sim = O.extract_frame(O.u8_to_f32(frame8), O.u8_to_f32(o_back), mark[0])
+    # same 8-bit inputs on both sides: bit-exact extraction (up to the rare 1-ulp coefficient, see above)
+    assert np.mean(ext[0] == o_ext) >= 0.999 and np.abs(ext[0] - o_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(o_ext)).max()
+    assert abs(float(sims[0]) - o_sim) < 1e-5 * abs(o_sim) + 1e-5
+    # and the all-device flow from the device's own marked frame
+    back_d = G.resize_rgb8(G.resize_rgb8(wm8[0], w // 8, h // 8), w, h)
+    ext_d, sims_d = G.batch_extract_rgb8(frame8[None], back_d[None], k, mark)
+    assert abs(float(sims_d[0]) - o_sim) < 0.05 and sims_d[0] > 6.0
+
+
+def test_full_hd_batch_with_automatic_chunking_equals_handles():
+    """BASELINE configs[2] frame size, one automatic chunk (129 frames of 1920x1080) plus a ragged one of 3:
+    every frame's index list and extracted mark against per-frame Reader handles (full transforms), the
+    marked frames of both chunks against Writer handles."""
+    w, h, k = 1920, 1080, 1000
+    n = ((1 << 28) // (w * h)) + 3
+    rgb = G.synth(12, 0, n, w, h)
+    marks = np.random.default_rng(13).standard_normal((n, k)).astype(np.float32)
+    res = G.batch_embed(rgb, marks, want_idx=True)
+    ext, sims = G.batch_extract(rgb, res["rgb"], k, marks)
+    stats = G.ctx().prune_stats()
+    assert stats["redone_chunks"] == 0
+    for f in range(n):
+        rd = wm.Reader.base(rgb[f])
+        assert np.array_equal(res["idx"][f], rd.indices(k).astype(np.uint32)), f
+        e = rd.extract(wm.Reader.derived(res["rgb"][f]), k)
+        assert np.array_equal(ext[f], e), f
+        assert sims[f] == np.float32(wm.Tester(e).similarity(marks[f]).similarity)
+    for f in (0, 64, 128, 129, n - 1):
+        assert np.array_equal(res["rgb"][f], wm.Writer(rgb[f]).mark([marks[f]])), f
+    o_marked = O.embed_frame(rgb[n - 1], marks[n - 1])                  # last frame of the ragged chunk vs the oracle
+    o_ext, o_sim = O.extract_frame(rgb[n - 1], o_marked, marks[n - 1])
+    assert np.abs(res["rgb"][n - 1] - o_marked).max() <= 2e-7 and abs(float(sims[n - 1]) - o_sim) < 1e-4
+
+
+def test_operand_planes_beyond_4gb_are_sliced():
+    """ssw_dct2d on 520 full-HD planes in ONE pass (set_chunk_frames(520)): the f64 operand planes would be
+    4.3 GB, past the 32-bit scalar offsets of the GEMM's k-walk, so the call transforms the frames in
+    groups; the result must equal transforming hand-made slices, bit for bit, forward and inverse."""
+    w, h, n = 1920, 1080, 520
+    ctx, lib = G.ctx(), G.lib()
+    plane = w * h
+    rng = np.random.default_rng(5)
+    base = rng.random((8, h, w)).astype(np.float32)
+    planes = np.concatenate([base * np.float32(1.0 - 0.001 * r) for r in range(n // 8)])      # 520 distinct planes
+    assert planes.shape == (n, h, w)
+    for dct_type in (L.DCT2, L.DCT3):
+        d = ctx.to_device(planes)
+        ctx.set_chunk_frames(n)
+        try:
+            rc = lib.ssw_dct2d(ctx.handle, dct_type, F64, n, w, h, d.ptr)
+            assert rc == L.SSW_OK
+            whole = d.to_host(np.float32, planes.shape)
+        finally:
+            ctx.set_chunk_frames(0)
+            d.free()
+        for lo, hi in ((0, 100), (100, 357), (357, n)):
+            assert np.array_equal(whole[lo:hi], G.dct2d(planes[lo:hi], dct_type, F64)), (dct_type, lo)
+        del whole
+
+
 def test_empty_and_degenerate_calls():
     lib, ctx = G.lib(), G.ctx()
     cfg = G.default_config()

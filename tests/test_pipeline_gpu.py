@@ -1,0 +1,266 @@
+"""GPU tests of the host-side machinery around the kernels: context lifetime, the two-lane / two-stream
+batch pipelines, the pruned transform of derived frames, stream hand-off, error mapping, and the
+multi-rank wiring of bench.py.  Everything goes through the C ABI; the oracle is the checker."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import gpu_util as G
+from conftest import ROOT
+from oracle import oracle as O
+from spread_spectrum_watermarking_amd import _lib as L
+import spread_spectrum_watermarking_amd as wm
+from spread_spectrum_watermarking_amd.api import check
+
+pytestmark = pytest.mark.gpu
+F32, F64 = L.PRECISION_F32, L.PRECISION_F64
+
+
+# ---- context lifetime / error mapping ------------------------------------------------------------------
+def test_context_create_destroy_releases_device_memory():
+    """ssw_ctx_destroy frees every workspace buffer (operand planes, lanes, selection, bases)."""
+    probe = wm.Context(0)
+    rgb = G.synth(1, 0, 6, 512, 288)
+    marks = np.random.default_rng(0).standard_normal((6, 100)).astype(np.float32)
+    cfg = G.default_config()
+
+    def cycle():
+        ctx = wm.Context(0)
+        ctx.set_chunk_frames(2)
+        lib = ctx._lib
+        d, dm = ctx.to_device(rgb), ctx.to_device(marks)
+        out, ext, sims = ctx.alloc(rgb.nbytes), ctx.alloc(6 * 100 * 4), ctx.alloc(6 * 4)
+        check(lib.ssw_batch_embed(ctx.handle, C.byref(cfg), d.ptr, 6, 512, 288, dm.ptr, 100, out.ptr, None, None), "embed")
+        check(lib.ssw_batch_extract(ctx.handle, C.byref(cfg), d.ptr, out.ptr, 6, 512, 288, 100, ext.ptr, dm.ptr, sims.ptr), "extract")
+        ctx.synchronize()
+        for b in (d, dm, out, ext, sims):
+            b.free()
+        ctx.close()
+
+    cycle()                                   # first cycle: code objects, runtime pools
+    free0, _ = probe.mem_info()
+    for _ in range(3):
+        cycle()
+    free1, _ = probe.mem_info()
+    assert free0 - free1 < 8 << 20, f"device memory leaked across context cycles: {(free0 - free1) / 2**20:.1f} MiB"
+    probe.close()
+
+
+def test_alloc_failure_is_out_of_memory_and_recoverable():
+    ctx = G.ctx()
+    p = C.c_void_p()
+    _, total = ctx.mem_info()
+    assert ctx._lib.ssw_dev_alloc(ctx.handle, total * 4, C.byref(p)) == L.SSW_ERR_OUT_OF_MEMORY
+    assert b"hipMalloc" in ctx._lib.ssw_last_error()
+    buf = ctx.alloc(1024)                     # the runtime's error state was cleared
+    buf.free()
+
+
+def test_second_embed_ranks_the_original_coefficients():
+    """Writer::new fixes the ordering once (algorithm.rs:314); embed() twice must not re-rank the
+    modified plane."""
+    rgb = O.synth_frame(3, 0, 160, 96)
+    rng = np.random.default_rng(7)
+    m1 = (rng.standard_normal(50) * 4).astype(np.float32)          # strong marks: re-ranking would differ
+    m2 = (rng.standard_normal(80) * 4).astype(np.float32)
+    w = wm.Writer(rgb, wm.WriteConfig(insertion=wm.Insertion.Option2(0.5)))
+    c0 = w.coefficient_image()
+    idx = O.indices(c0, k=80)
+    w.embed([m1])
+    c1 = w.coefficient_image()
+    assert np.array_equal(c1, O.embed(c0, idx[:50], [m1], O.OPTION2, 0.5))
+    w.embed([m2])
+    c2 = w.coefficient_image()
+    assert np.array_equal(c2, O.embed(c1, idx, [m2], O.OPTION2, 0.5))
+    assert not np.array_equal(O.indices(c1, k=80), idx)            # the test would notice a re-rank
+
+
+def test_batch_embed_truncates_a_long_mark_like_zip():
+    """algorithm.rs:396: a mark longer than w*h-1 is cut silently -- also in the batch entry points."""
+    rgb = np.random.default_rng(1).random((2, 3, 4, 3)).astype(np.float32)       # 12 coefficients, 11 usable
+    marks = np.random.default_rng(2).standard_normal((2, 40)).astype(np.float32)
+    res = G.batch_embed(rgb, marks)
+    for f in range(2):
+        assert np.array_equal(res["rgb"][f], wm.Writer(rgb[f]).mark([marks[f]]))
+
+
+def test_caller_stream_and_events():
+    """ssw_ctx_set_stream / wait_event / record_event: chaining with a torch stream, no host sync in between."""
+    torch = pytest.importorskip("torch")
+    ctx = wm.Context(0)
+    dev = torch.device("cuda", 0)
+    x = torch.rand((3, 72, 136), device=dev)
+    ref = G.dct2d(x.cpu().numpy(), L.DCT2, F64)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        y = x * 1.0                                       # produced on the caller's stream
+        ctx.set_stream(s.cuda_stream)
+        check(ctx._lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 3, 136, 72, y.data_ptr()), "ssw_dct2d")
+        z = y + 0.0                                       # consumed on the caller's stream
+    s.synchronize()
+    assert np.array_equal(z.cpu().numpy(), ref)
+    ctx.set_stream(None)
+    # private stream + events
+    y2 = x.clone()
+    produced, done = torch.cuda.Event(), torch.cuda.Event()
+    produced.record()
+    ctx.wait_event(produced.cuda_event)
+    check(ctx._lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 3, 136, 72, y2.data_ptr()), "ssw_dct2d")
+    done.record()                                         # make the handle exist, then re-record on the ctx stream
+    ctx.record_event(done.cuda_event)
+    done.synchronize()
+    assert np.array_equal(y2.cpu().numpy(), ref)
+    ctx.close()
+
+
+# ---- two lanes / two streams ---------------------------------------------------------------------------------
+def _run_batch(rgb, marks, cfg, overlap, prune, chunk, u8=False):
+    ctx = G.ctx()
+    ctx.set_overlap(overlap)
+    ctx.set_prune(prune)
+    ctx.set_chunk_frames(chunk)
+    try:
+        k = marks.shape[1]
+        if u8:
+            wm8 = G.batch_embed_rgb8(rgb, marks, cfg)
+            ext, sims = G.batch_extract_rgb8(rgb, wm8, k, marks, cfg)
+            return wm8, None, None, ext, sims
+        res = G.batch_embed(rgb, marks, cfg, want_coef=True, want_idx=True)
+        ext, sims = G.batch_extract(rgb, res["rgb"], k, marks, cfg)
+        return res["rgb"], res["coef"], res["idx"], ext, sims
+    finally:
+        ctx.set_overlap(True)
+        ctx.set_prune(True)
+        ctx.set_chunk_frames(0)
+
+
+@pytest.mark.parametrize("precision", [F32, F64])
+@pytest.mark.parametrize("shape", [(108, 192), (144, 1040), (90, 160)])
+def test_overlapped_pipeline_is_bit_identical_to_serial(precision, shape):
+    """7 frames in chunks of 2 (ragged last chunk): two chunks in flight on two streams must give
+    exactly what one chunk at a time on one stream gives -- frames, coefficients, indices, marks, sims."""
+    h, w = shape
+    n, k = 7, 150
+    rgb = G.synth(6, 2, n, w, h)
+    marks = np.random.default_rng(4).standard_normal((n, k)).astype(np.float32)
+    cfg = G.default_config(precision)
+    a = _run_batch(rgb, marks, cfg, True, True, 2)
+    b = _run_batch(rgb, marks, cfg, False, True, 2)
+    c = _run_batch(rgb, marks, cfg, False, False, 7)
+    for x, y, z in zip(a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z)
+    assert np.all(a[4] > 0.9 * np.linalg.norm(marks, axis=1))
+    rgb8 = O.f32_to_u8(rgb)
+    a8 = _run_batch(rgb8, marks, cfg, True, True, 3, u8=True)
+    b8 = _run_batch(rgb8, marks, cfg, False, False, 7, u8=True)
+    assert np.array_equal(a8[0], b8[0]) and np.array_equal(a8[3], b8[3]) and np.array_equal(a8[4], b8[4])
+
+
+# ---- pruned derived transform -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", [F32, F64])
+@pytest.mark.parametrize("case", [((144, 1040), 5, 200), ((80, 1056), 6, 150), ((1080, 1920), 5, 1000)])
+def test_pruned_derived_transform_is_bit_identical_to_full(precision, case):
+    """Reader::extract reads k coefficients of the derived plane (algorithm.rs:556-561): transforming only
+    the frequency columns the index lists use must give the same bits as the full transform -- with two
+    folding levels on the rows (1040 / 1920 columns) and three (1056 at level 6), and against the handles,
+    whose Reader::derived always transforms fully."""
+    (h, w), level, k = case
+    n = 5 if w < 1500 else 3
+    rgb = G.synth(8, 4, n, w, h)
+    marks = np.random.default_rng(9).standard_normal((n, k)).astype(np.float32)
+    cfg = G.default_config(precision)
+    ctx = G.ctx()
+    ctx.set_dct_folding(level)
+    wm.default_context().set_dct_folding(level)
+    try:
+        ctx.reset_timing()
+        pruned = _run_batch(rgb, marks, cfg, True, True, 2)
+        stats = ctx.prune_stats()
+        full = _run_batch(rgb, marks, cfg, True, False, 2)
+        assert stats["pruned_chunks"] == (n + 1) // 2 and stats["redone_chunks"] == 0
+        assert 0 < stats["columns_needed"] < stats["pruned_chunks"] * w // 4
+        assert np.array_equal(pruned[3], full[3]) and np.array_equal(pruned[4], full[4])
+        rd = wm.Reader.base(rgb[0], wm.ReadConfig(precision=precision))
+        assert np.array_equal(pruned[3][0], rd.extract(wm.Reader.derived(pruned[0][0], precision=precision), k))
+    finally:
+        ctx.set_dct_folding(True)
+        wm.default_context().set_dct_folding(True)
+
+
+def test_pruned_path_falls_back_when_the_columns_do_not_fit():
+    """White-noise frames spread their largest coefficients over all frequency columns: the compact plane
+    overflows, the chunk is redone with the full transform, and the result still equals the full path."""
+    h, w, n, k = 144, 1040, 4, 200
+    rng = np.random.default_rng(12)
+    rgb = rng.random((n, h, w, 3)).astype(np.float32)
+    rgb[2:] = G.synth(8, 0, 2, w, h)                                  # second chunk: natural spectrum, fits
+    marks = rng.standard_normal((n, k)).astype(np.float32)
+    cfg = G.default_config(F64)
+    ctx = G.ctx()
+    ctx.reset_timing()
+    pruned = _run_batch(rgb, marks, cfg, True, True, 2)
+    stats = ctx.prune_stats()
+    full = _run_batch(rgb, marks, cfg, False, False, 2)
+    assert stats["pruned_chunks"] == 2 and stats["redone_chunks"] == 1
+    assert np.array_equal(pruned[3], full[3]) and np.array_equal(pruned[4], full[4])
+
+
+# ---- bench.py: ranks and launcher -----------------------------------------------------------------------------
+SMALL = ["--steps", "1", "--warmup", "1", "--width", "512", "--height", "288", "--k", "100", "--no-alt",
+         "--no-cpu-baseline", "--no-serial-leg", "--no-timers-off-leg"]
+
+
+def _bench(extra, env_extra=None, expect_ok=True):
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(v, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, env=env,
+                       timeout=900)
+    if expect_ok:
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout                                # exactly ONE JSON line, from rank 0
+        return json.loads(lines[0])
+    return r
+
+
+def test_bench_two_ranks_equal_one_process(tmp_path):
+    """`bench.py --gpus 2` run plainly spawns two rank processes (env-based rank set-up, one context per
+    rank, barrier, MAX-reduce, gathers).  Both ranks share device 0 here (the test box has one GPU), so
+    the coordination backend is gloo -- RCCL refuses two ranks on one device; the data path is the same.
+    The gathered per-frame results must equal a single-process run of the same 6 frames."""
+    two, one = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
+    j2 = _bench(["--gpus", "2", "--batch", "3", "--dump", two] + SMALL,
+                {"SSW_BENCH_SHARE_DEVICE": "1", "SSW_BENCH_DIST_BACKEND": "gloo"})
+    j1 = _bench(["--gpus", "1", "--batch", "6", "--dump", one] + SMALL)
+    assert j2["n_gpus"] == 2 and j2["ranks"]["ranks_seen"] == [0, 1] and len(j2["ranks"]["mpix_per_s_per_rank"]) == 2
+    assert j1["n_gpus"] == 1 and j1["ranks"]["ranks_seen"] == [0]
+    a, b = np.load(two), np.load(one)
+    assert a["sims"].shape == (6,) and np.array_equal(a["sims"], b["sims"]) and np.array_equal(a["extracted"], b["extracted"])
+    assert j2["value"] > 0 and j2["scaling"] == "weak"
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    import torch
+    n = torch.cuda.device_count()
+    r = _bench(["--gpus", str(n + 1), "--batch", "2"] + SMALL, expect_ok=False)
+    assert r.returncode != 0 and f"has {n} GPU" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]          # no result line from a refused run
+    # torchrun-style environment that does not match --gpus is refused as well
+    r = _bench(["--gpus", "2", "--batch", "2"] + SMALL, {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, expect_ok=False)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_bench_rccl_path_world_size_one():
+    """The nccl (= RCCL) process group of the real multi-GPU run -- init with device_id, barrier, all_reduce,
+    all_gather -- exercised with one rank on the one GPU of the test box."""
+    j = _bench(["--gpus", "1", "--batch", "4"] + SMALL,
+               {"SSW_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": "29617"})
+    assert j["ranks"]["dist_backend"] == "nccl" and j["ranks"]["ranks_seen"] == [0]
