@@ -214,6 +214,7 @@ struct ssw_ctx {
         Buf gathered;             // gathered half bases of the chunk's frequency classes
         Buf prune_u32;            // flag [W] | pos [W] | rows [cap] | info [8]
         hipStream_t cur = nullptr;   // stream the lane's chain currently runs on
+        hipEvent_t done = nullptr;   // recorded right after the lane's latest stage (borrowed from sync_events)
     };
     static constexpr int MAX_LANES = 2;
     Lane lane[MAX_LANES];

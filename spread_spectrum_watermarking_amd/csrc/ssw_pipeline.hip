@@ -405,13 +405,19 @@ int next_sync_event(ssw_ctx* ctx, hipEvent_t* out) {
     return SSW_OK;
 }
 
-// continue the lane's chain on stream `to`: everything the lane enqueued so far happens before
+// A lane's stage has just been enqueued on ln.cur: remember that point (an event recorded NOW -- recorded
+// later it would also cover what the other lane has enqueued on the same stream in the meantime, and the
+// lanes would serialise each other).
+int mark_done(ssw_ctx* ctx, ssw_ctx::Lane& ln) {
+    SSW_TRY(next_sync_event(ctx, &ln.done));
+    SSW_HIP_CHECK(hipEventRecord(ln.done, ln.cur));
+    return SSW_OK;
+}
+
+// continue the lane's chain on stream `to`: the lane's last stage happens before
 int hop(ssw_ctx* ctx, ssw_ctx::Lane& ln, hipStream_t to) {
     if (ln.cur == to) return SSW_OK;
-    hipEvent_t ev = nullptr;
-    SSW_TRY(next_sync_event(ctx, &ev));
-    SSW_HIP_CHECK(hipEventRecord(ev, ln.cur));
-    SSW_HIP_CHECK(hipStreamWaitEvent(to, ev, 0));
+    if (ln.done) SSW_HIP_CHECK(hipStreamWaitEvent(to, ln.done, 0));
     ln.cur = to;
     return SSW_OK;
 }
@@ -446,6 +452,7 @@ int run_pipeline(ssw_ctx* ctx, size_t n_chunks, const std::function<int(size_t, 
     };
     for (int l = 0; l < n_lanes; ++l) {
         ctx->lane[l].cur = H;
+        ctx->lane[l].done = nullptr;
         SSW_TRY(start(l));
     }
     while (active[0] || active[1]) {
@@ -454,6 +461,7 @@ int run_pipeline(ssw_ctx* ctx, size_t n_chunks, const std::function<int(size_t, 
             Stage& s = chain[l][at[l]];
             SSW_TRY(hop(ctx, ctx->lane[l], s.hbm ? H : G));
             SSW_TRY(s.run(ctx->lane[l].cur));
+            if (two) SSW_TRY(mark_done(ctx, ctx->lane[l]));
             if (++at[l] == chain[l].size()) SSW_TRY(start(l));
         }
     }

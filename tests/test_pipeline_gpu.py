@@ -89,33 +89,56 @@ def test_batch_embed_truncates_a_long_mark_like_zip():
         assert np.array_equal(res["rgb"][f], wm.Writer(rgb[f]).mark([marks[f]]))
 
 
-def test_caller_stream_and_events():
-    """ssw_ctx_set_stream / wait_event / record_event: chaining with a torch stream, no host sync in between."""
-    torch = pytest.importorskip("torch")
-    ctx = wm.Context(0)
-    dev = torch.device("cuda", 0)
-    x = torch.rand((3, 72, 136), device=dev)
-    ref = G.dct2d(x.cpu().numpy(), L.DCT2, F64)
-    s = torch.cuda.Stream()
-    with torch.cuda.stream(s):
-        y = x * 1.0                                       # produced on the caller's stream
-        ctx.set_stream(s.cuda_stream)
-        check(ctx._lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 3, 136, 72, y.data_ptr()), "ssw_dct2d")
-        z = y + 0.0                                       # consumed on the caller's stream
-    s.synchronize()
-    assert np.array_equal(z.cpu().numpy(), ref)
-    ctx.set_stream(None)
-    # private stream + events
-    y2 = x.clone()
-    produced, done = torch.cuda.Event(), torch.cuda.Event()
-    produced.record()
-    ctx.wait_event(produced.cuda_event)
-    check(ctx._lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 3, 136, 72, y2.data_ptr()), "ssw_dct2d")
-    done.record()                                         # make the handle exist, then re-record on the ctx stream
-    ctx.record_event(done.cuda_event)
-    done.synchronize()
-    assert np.array_equal(y2.cpu().numpy(), ref)
-    ctx.close()
+_STREAM_SCRIPT = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+dev = torch.device("cuda", 0)
+x = torch.rand((3, 72, 136), device=dev)          # torch initialises HIP first (its bundled runtime and the
+torch.cuda.synchronize()                           # library's then share one ROCr, as in bench.py)
+import spread_spectrum_watermarking_amd as wm
+from spread_spectrum_watermarking_amd import _lib as L
+from spread_spectrum_watermarking_amd.api import check
+ctx = wm.Context(0)
+F64 = L.PRECISION_F64
+ref = x.clone()
+check(ctx._lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 3, 136, 72, ref.data_ptr()), "ssw_dct2d")
+ctx.synchronize()
+ref = ref.cpu().numpy()
+# (1) the library on the caller's stream: producer -> library -> consumer, no host synchronisation in between
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    y = x * 1.0
+    ctx.set_stream(s.cuda_stream)
+    check(ctx._lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 3, 136, 72, y.data_ptr()), "ssw_dct2d")
+    z = y + 0.0
+s.synchronize()
+assert np.array_equal(z.cpu().numpy(), ref)
+ctx.set_stream(None)
+# (2) private stream, chained through the caller's events
+y2 = x.clone()
+produced, done = torch.cuda.Event(), torch.cuda.Event()
+produced.record()
+ctx.wait_event(produced.cuda_event)
+check(ctx._lib.ssw_dct2d(ctx.handle, L.DCT2, F64, 3, 136, 72, y2.data_ptr()), "ssw_dct2d")
+done.record()                                      # creates the handle; re-recorded on the context's stream next
+ctx.record_event(done.cuda_event)
+done.synchronize()
+assert np.array_equal(y2.cpu().numpy(), ref)
+assert int(ctx._lib.ssw_ctx_stream(ctx.handle) or 0) != s.cuda_stream
+ctx.close()
+print("stream-ok")
+"""
+
+
+def test_caller_stream_and_events(tmp_path):
+    """ssw_ctx_set_stream / wait_event / record_event: chaining with a torch stream without host
+    synchronisation.  In a fresh interpreter, so that torch brings up HIP before the library does."""
+    script = tmp_path / "stream_check.py"
+    script.write_text(_STREAM_SCRIPT)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "stream-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 # ---- two lanes / two streams ---------------------------------------------------------------------------------
