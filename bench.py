@@ -269,6 +269,7 @@ def main():
     ap.add_argument("--no-fold", action="store_true", help="dense basis GEMMs instead of the even/odd-folded ones")
     ap.add_argument("--no-timers-off-leg", action="store_true", help="skip the short re-measurement with the stage timers off")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the short re-measurement with one chunk at a time on one stream")
+    ap.add_argument("--no-overlap", action="store_true", help="headline with one chunk at a time on one stream")
     ap.add_argument("--no-stage-timers", action="store_true", help="no hipEvent pairs in the timed region (no roofline numbers)")
     ap.add_argument("--dump", default=None, help="rank 0 writes the gathered per-frame sims / extracted marks here (.npz)")
     args = ap.parse_args()
@@ -358,7 +359,7 @@ def main():
 
     embed_only = args.embed_only
 
-    def measure(prec_name, overlap=True):
+    def measure(prec_name, overlap=not args.no_overlap):
         """One timed region in the given precision; returns (own s, max-over-ranks s, stage timings, prune stats, sims, extracted)."""
         cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, L.PRECISION_F64 if prec_name == "f64" else L.PRECISION_F32)
         ctx.set_overlap(overlap)
@@ -371,7 +372,7 @@ def main():
                                             extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
 
         own, elapsed, stage, prune = timed_region(args, ctx, dist, step)
-        ctx.set_overlap(True)
+        ctx.set_overlap(not args.no_overlap)
         if embed_only:                     # configs[1]: verify the round trip with one untimed extraction
             check(lib.ssw_batch_extract(ctx.handle, C.byref(cfg), rgb.data_ptr(), rgb_out.data_ptr(), B, W, H, K,
                                         extracted.data_ptr(), marks.data_ptr(), sims.data_ptr()), "ssw_batch_extract")
@@ -502,7 +503,8 @@ def main():
             "config": {"workload": f"batch={B}/GPU {W}x{H} f32 frames, {K}-coeff mark, {flow}; {workload_tag}",
                        "frames_per_gpu": B, "width": W, "height": H, "k": K, "alpha": 0.1,
                        "method": "Option2", "ordering": "Energy", "chunk_frames": chunk_eff,
-                       "dct_folding_level": fold_level, "overlap": "two chunks in flight on two streams",
+                       "dct_folding_level": fold_level,
+                       "overlap": "one chunk at a time on one stream" if args.no_overlap else "two chunks in flight on two streams",
                        "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
             "kernels": kernels,

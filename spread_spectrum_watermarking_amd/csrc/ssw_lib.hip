@@ -98,16 +98,9 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
     ctx->stream = ctx->own_stream;
     // second stream of the batch pipelines (ssw_pipeline.hip): the HBM-bound stages of one chunk run here
     // while the basis GEMMs of the other chunk in flight run on the context's stream.
-    // SSW_AUX_CUS=<n> (experiments): restrict it to the first n compute units of the CU mask.
-    const char* cus = std::getenv("SSW_AUX_CUS");
-    const int n_cus = cus ? std::atoi(cus) : 0;
-    if (n_cus > 0) {
-        uint32_t mask[16] = {0};
-        for (int b = 0; b < n_cus && b < 512; ++b) mask[b / 32] |= 1u << (b % 32);
-        e = hipExtStreamCreateWithCUMask(&ctx->aux_stream, 16, mask);
-    } else {
-        e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
-    }
+    // (Measured: restricting this stream to 16 .. 128 CUs with a CU mask only slows the step down -- the
+    // chunk's GEMMs wait for its pre-pass -- so it is a plain stream.)
+    e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; set_last_error(hipGetErrorString(e)); return SSW_ERR_HIP; }
     const char* ov = std::getenv("SSW_OVERLAP");
     if (ov) ctx->overlap = std::atoi(ov) != 0;
