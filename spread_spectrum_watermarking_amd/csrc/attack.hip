@@ -207,10 +207,339 @@ __global__ __launch_bounds__(256) void resize_horizontal_kernel(const float* __r
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused resize: one block = one tile of OYB x OXB output pixels of one frame.
+//   1. the input pixels the tile's taps reach (rows [r0, r1) x bytes [a0, b1)) are loaded once into LDS,
+//   2. vertical pass  LDS u8 -> LDS f32 strip (OYB rows), sequential f32 sum per element like the crate,
+//   3. horizontal pass LDS f32 -> u8 pixels (clamp + round half away from zero), staged in LDS,
+//   4. the tile's rows are written with 32-bit stores.
+// The f32 intermediate of the two-pass kernels above (12 B per intermediate pixel written and re-read
+// through HBM / L2, with byte-strided accesses on the narrow side) never leaves the CU.  Arithmetic and
+// summation order are those of the two-pass kernels: bit-identical results.
+// Needs 4-byte aligned rows (w * 3 % 4 == 0, nw * 3 % 4 == 0, OXB % 4 == 0).
+// ---------------------------------------------------------------------------------------------
+struct ResizeTile {
+    unsigned oyb, oxb;            // output tile (powers of two, oxb >= 4)
+    unsigned pitch;               // elements (bytes of s_in, floats of s_v) per LDS row, multiple of 4
+    unsigned in_rows;             // LDS rows of the input tile
+    unsigned tiles_x, tiles_y;
+    unsigned oxb_log2;
+};
+
+typedef float rz_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4r __attribute__((ext_vector_type(4)));
+
+// round(clamp(t, 0, 255)) with halves away from zero, as an integer -- exactly: scaling by 2^16 is exact, the
+// conversion truncates, and floor(c * 2^16) still tells whether the fraction reaches 1/2
+__device__ inline uint32_t resize_to_u8(float t) {
+    const float c = __builtin_amdgcn_fmed3f(t, 0.0f, 255.0f);     // = clamp for the finite sums this sees
+    return ((uint32_t)(c * 65536.0f) + 0x8000u) >> 16;
+}
+
+// vertical pass of one block: pieces of NW 32-bit words (4 NW bytes) per thread
+template <int NW>
+__device__ inline void resize_vertical_pieces(const unsigned char* s_in, float* s_v, const float* s_wv, const uint32_t* s_lv,
+                                              const uint32_t* s_cv, unsigned r0, unsigned noy, unsigned pieces, unsigned vmax,
+                                              unsigned pitch, unsigned tid) {
+    typedef unsigned int uvec __attribute__((ext_vector_type(NW)));
+    for (unsigned it = tid; it < noy * pieces; it += 256) {
+        const unsigned j = it / pieces, ck = it - j * pieces;
+        const unsigned n = s_cv[j];
+        const unsigned char* col = s_in + (s_lv[j] - r0) * pitch + 4 * NW * ck;
+        const float* wv = s_wv + j * vmax;
+        rz_f32x2 t[2 * NW];
+#pragma unroll
+        for (int u = 0; u < 2 * NW; ++u) t[u] = (rz_f32x2){0.0f, 0.0f};
+#pragma unroll 2
+        for (unsigned i = 0; i < n; ++i) {
+            const uvec v = *reinterpret_cast<const uvec*>(col + i * pitch);
+            const float wi = wv[i];
+            const rz_f32x2 ww = {wi, wi};
+#pragma unroll
+            for (int u = 0; u < NW; ++u) {
+                const rz_f32x2 a = {(float)(v[u] & 0xFF), (float)((v[u] >> 8) & 0xFF)};
+                const rz_f32x2 b = {(float)((v[u] >> 16) & 0xFF), (float)(v[u] >> 24)};
+                t[2 * u] += a * ww;
+                t[2 * u + 1] += b * ww;
+            }
+        }
+        f32x4* o = reinterpret_cast<f32x4*>(s_v + j * pitch + 4 * NW * ck);
+#pragma unroll
+        for (int u = 0; u < NW; ++u) o[u] = (f32x4){t[2 * u][0], t[2 * u][1], t[2 * u + 1][0], t[2 * u + 1][1]};
+    }
+}
+
+// HMODE (horizontal pass): 0 = one lane per (output pixel, channel) -- down-scaling along x, few outputs, long taps;
+// 1 = one thread per aligned quad of output pixels that share their taps' positions (left, count <= 5: integer
+// up-scaling) -- the <= 15 strip values are loaded once and feed 12 output bytes; 2 = one thread per output pixel.
+template <int HMODE>
+__global__ __launch_bounds__(256) void resize_fused_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                           unsigned w, unsigned h, unsigned nw, unsigned nh,
+                                                           const uint32_t* __restrict__ vleft, const uint32_t* __restrict__ vcount,
+                                                           const float* __restrict__ vweights, unsigned vmax,
+                                                           const uint32_t* __restrict__ hleft, const uint32_t* __restrict__ hcount,
+                                                           const float* __restrict__ hweights, unsigned hmax, ResizeTile tl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: s_v f32 [oyb][pitch] | s_wh f32 [hmax][oxb] (tap-major) | s_wv f32 [oyb][vmax] | meta u32 [2 oyb + 2 oxb] |
+    //         s_in u8 [in_rows][pitch];  pitch is a multiple of 16: 16-byte LDS accesses throughout
+    float* s_v = reinterpret_cast<float*>(smem);
+    float* s_wh = s_v + (size_t)tl.oyb * tl.pitch;
+    float* s_wv = s_wh + (size_t)tl.oxb * hmax;
+    uint32_t* s_lv = reinterpret_cast<uint32_t*>(s_wv + (size_t)tl.oyb * vmax);
+    uint32_t* s_cv = s_lv + tl.oyb;
+    uint32_t* s_lh = s_cv + tl.oyb;
+    uint32_t* s_ch = s_lh + tl.oxb;
+    // (offset arithmetic on `smem` itself: a pointer rebuilt from an integer loses its LDS address space and every
+    //  access through it becomes a flat load)
+    const unsigned in_off = ((tl.oyb * tl.pitch + tl.oxb * hmax + tl.oyb * vmax + 2 * tl.oyb + 2 * tl.oxb) * 4 + 15) & ~15u;
+    unsigned char* s_in = smem + in_off;
+    unsigned char* s_out = s_in;                       // reused after the vertical pass: [oyb][oxb * 3]
+
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+    const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tx = blockIdx.x % tl.tiles_x, ty = blockIdx.x / tl.tiles_x, f = blockIdx.y;
+    const unsigned oy0 = ty * tl.oyb, ox0 = tx * tl.oxb;
+    const unsigned noy = nh - oy0 < tl.oyb ? nh - oy0 : tl.oyb;
+    const unsigned nox = nw - ox0 < tl.oxb ? nw - ox0 : tl.oxb;
+
+    // The tile's reach: left / right bounds grow with the output index, so it is first left .. last right
+    // (block-uniform scalar loads; everything below is addressed from them).
+    const unsigned r0 = vleft[oy0], r1 = vleft[oy0 + noy - 1] + vcount[oy0 + noy - 1];
+    const unsigned b0 = hleft[ox0] * 3, b1 = (hleft[ox0 + nox - 1] + hcount[ox0 + nox - 1]) * 3;
+    const unsigned a0 = b0 & ~3u;                                   // rows are 4-byte aligned: aligned word loads
+    const unsigned words = (b1 - a0 + 3) / 4;
+    const unsigned nrows = r1 - r0;
+    {   // 1. tap tables and input tile -> LDS.  A block lives for a handful of memory latencies, so every global
+        //    load that does not depend on another is issued before the first LDS write: the tables (<= 4 + 4 + 4
+        //    values per thread) and the first six 16-byte pieces of the tile together, then the rest of the tile.
+        float hw[4], vw[4];
+        uint32_t meta[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = tid + 256 * u;
+            hw[u] = i < nox * hmax ? hweights[(size_t)ox0 * hmax + i] : 0.0f;
+            vw[u] = i < noy * vmax ? vweights[(size_t)oy0 * vmax + i] : 0.0f;
+        }
+        if (tid < noy) { meta[0] = vleft[oy0 + tid]; meta[1] = vcount[oy0 + tid]; }
+        if (tid < nox) { meta[2] = hleft[ox0 + tid]; meta[3] = hcount[ox0 + tid]; }
+        const uint8_t* src = in + ((size_t)f * h + r0) * w * 3 + a0;
+        const size_t row_bytes = (size_t)w * 3;
+        const unsigned chunks = (words + 3) / 4;
+        const unsigned avail = w * 3 - a0;                              // bytes from a0 to the end of the image row
+        const unsigned total = nrows * chunks;
+        constexpr int NB = 6;
+        for (unsigned base = 0; base < total || base == 0; base += 256 * NB) {
+            u32x4r v[NB];
+            unsigned dst[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const unsigned it = base + u * 256 + tid;
+                dst[u] = 0xFFFFFFFFu;
+                if (it < total) {
+                    const unsigned r = it / chunks, ck = it - r * chunks;
+                    const uint8_t* p = src + r * row_bytes + 16 * ck;
+                    dst[u] = r * tl.pitch + 16 * ck;
+                    if (16 * ck + 16 <= avail) {
+                        v[u] = *reinterpret_cast<const u32x4r*>(p);
+                    } else {                                            // last piece of an image row: stay inside the row
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[u][e] = (16 * ck + 4 * e + 4 <= avail) ? *reinterpret_cast<const uint32_t*>(p + 4 * e) : 0u;
+                    }
+                }
+            }
+            if (base == 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned i = tid + 256 * u;
+                    if (i < nox * hmax) { const unsigned x = i / hmax, tp = i - x * hmax; s_wh[tp * tl.oxb + x] = hw[u]; }   // tap-major
+                    if (i < noy * vmax) s_wv[i] = vw[u];
+                }
+                if (tid < noy) { s_lv[tid] = meta[0]; s_cv[tid] = meta[1]; }
+                if (tid < nox) { s_lh[tid] = meta[2]; s_ch[tid] = meta[3]; }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                if (dst[u] != 0xFFFFFFFFu) *reinterpret_cast<u32x4r*>(s_in + dst[u]) = v[u];
+        }
+    }
+    __syncthreads();
+    // 2. vertical pass (vertical_sample of the crate): t = sum_i (float)in[left + i][e] * w[i], i ascending, mul and
+    //    add rounded separately.  One thread = 16 (or, when that leaves half the block idle, 8) consecutive bytes of
+    //    one output row: that many independent sums per LDS read.
+    {
+        // whole LDS rows, slack included: every strip element the horizontal pass may touch is then a finite sum
+        const unsigned chunks16 = tl.pitch / 16;
+        if (noy * chunks16 >= 192) resize_vertical_pieces<4>(s_in, s_v, s_wv, s_lv, s_cv, r0, noy, chunks16, vmax, tl.pitch, tid);
+        else                       resize_vertical_pieces<2>(s_in, s_v, s_wv, s_lv, s_cv, r0, noy, tl.pitch / 8, vmax, tl.pitch, tid);
+    }
+    __syncthreads();
+    // 3. horizontal pass (horizontal_sample): t = sum_i strip[left + i][c] * w[i]; clamp, round; staged in LDS
+    const unsigned out_pitch = tl.oxb * 3;
+    if (HMODE == 0) {
+        for (unsigned j = wave; j < noy; j += 4)
+            for (unsigned e = lane; e < nox * 3; e += 64) {
+                const unsigned x = e / 3, c = e - 3 * x;
+                const unsigned n = s_ch[x];
+                const float* src = s_v + j * tl.pitch + (s_lh[x] * 3 - a0) + c;
+                const float* wh = s_wh + x;
+                float t = 0.0f;
+#pragma unroll 4
+                for (unsigned i = 0; i < n; ++i) t += src[3 * i] * wh[i * tl.oxb];
+                s_out[j * out_pitch + e] = (unsigned char)resize_to_u8(t);
+            }
+    } else if (HMODE == 1) {
+        const unsigned nq_log2 = tl.oxb_log2 - 2, nq = nox / 4;
+        for (unsigned it = tid; it < (noy << nq_log2); it += 256) {
+            const unsigned j = it >> nq_log2, q = it & ((1u << nq_log2) - 1);
+            if (q >= nq) continue;
+            const unsigned x0 = 4 * q;
+            const float* src = s_v + j * tl.pitch + (s_lh[x0] * 3 - a0);
+            // Five taps are read whatever n is: the tap tables are zero-padded beyond n (hmax >= 5 rows exist), and the
+            // strip beyond the reach holds finite values (sums of bytes times weights), so 0 * value adds nothing.
+            float p[5][3];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) p[i][c] = src[3 * i + c];
+            f32x4 wq[5];                                           // tap i of the quad's four outputs: one 16-byte read
+#pragma unroll
+            for (int i = 0; i < 5; ++i) wq[i] = *reinterpret_cast<const f32x4*>(s_wh + i * tl.oxb + x0);
+            uint32_t by[12];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                rz_f32x2 t01 = {0.0f, 0.0f};
+                float t2 = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {      // taps beyond n: 0 * 0 added to the sum leaves it unchanged
+                    const float wi = wq[i][k];
+                    t01 += (rz_f32x2){p[i][0], p[i][1]} * (rz_f32x2){wi, wi};
+                    t2 += p[i][2] * wi;
+                }
+                by[3 * k + 0] = resize_to_u8(t01[0]);
+                by[3 * k + 1] = resize_to_u8(t01[1]);
+                by[3 * k + 2] = resize_to_u8(t2);
+            }
+            uint32_t* o = reinterpret_cast<uint32_t*>(s_out + j * out_pitch + 12 * q);
+#pragma unroll
+            for (int u = 0; u < 3; ++u) o[u] = by[4 * u] | (by[4 * u + 1] << 8) | (by[4 * u + 2] << 16) | (by[4 * u + 3] << 24);
+        }
+    } else {
+        const unsigned nx_log2 = tl.oxb_log2;
+        for (unsigned it = tid; it < (noy << nx_log2); it += 256) {
+            const unsigned j = it >> nx_log2, x = it & ((1u << nx_log2) - 1);
+            if (x >= nox) continue;
+            const unsigned n = s_ch[x];
+            const float* src = s_v + j * tl.pitch + (s_lh[x] * 3 - a0);
+            const float* wh = s_wh + x;
+            float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;
+#pragma unroll 4
+            for (unsigned i = 0; i < n; ++i) {
+                const float wi = wh[i * tl.oxb];
+                t0 += src[3 * i + 0] * wi;
+                t1 += src[3 * i + 1] * wi;
+                t2 += src[3 * i + 2] * wi;
+            }
+            unsigned char* o = s_out + j * out_pitch + x * 3;
+            o[0] = (unsigned char)resize_to_u8(t0);
+            o[1] = (unsigned char)resize_to_u8(t1);
+            o[2] = (unsigned char)resize_to_u8(t2);
+        }
+    }
+    __syncthreads();
+    {   // 4. tile rows -> global: 16-byte stores when the tile's rows start on 16-byte boundaries, else 4-byte ones
+        const unsigned obytes = nox * 3;
+        uint8_t* dst = out + (((size_t)f * nh + oy0) * nw + ox0) * 3;
+        const size_t orow = (size_t)nw * 3;
+        if ((obytes & 15) == 0 && (orow & 15) == 0 && ((ox0 * 3) & 15) == 0 && (out_pitch & 15) == 0) {
+            const unsigned per_row = obytes / 16;
+            for (unsigned it = tid; it < noy * per_row; it += 256) {
+                const unsigned j = it / per_row, c = it - j * per_row;
+                *reinterpret_cast<u32x4r*>(dst + j * orow + 16 * c) = *reinterpret_cast<const u32x4r*>(s_out + j * out_pitch + 16 * c);
+            }
+        } else {
+            const unsigned owords = obytes / 4;
+            for (unsigned j = wave; j < noy; j += 4)
+                for (unsigned wd = lane; wd < owords; wd += 64)
+                    *reinterpret_cast<uint32_t*>(dst + j * orow + 4 * wd) = *reinterpret_cast<const uint32_t*>(s_out + j * out_pitch + 4 * wd);
+        }
+    }
+}
+
+// tile shape: the cheapest one (input bytes loaded + vertical taps per output pixel) whose LDS footprint lets two
+// blocks share a CU; spans = reach (in input samples) of 1, 2, 4, ... 128 consecutive outputs (DeviceTaps::span)
+static bool pick_resize_tile(const DeviceTaps& vt, const DeviceTaps& ht, size_t w, size_t h, size_t nw, size_t nh, ResizeTile* out,
+                             size_t* lds_bytes) {
+    double best = 1e300;
+    bool found = false;
+    const double vtaps = (double)(vt.span[0] ? vt.span[0] : 1);
+    for (int ey = 0; ey < 8; ++ey)
+        for (int ex = 2; ex < 8; ++ex) {                                // OXB >= 4 (a multiple of 4)
+            const unsigned oyb = 1u << ey, oxb = 1u << ex;
+            if (oyb > 2 * nh || oxb > 2 * nw) continue;
+            const unsigned rows = vt.span[ey], px = ht.span[ex];
+            if (!rows || !px) continue;
+            const unsigned pitch = (px * 3 + 3 + 6 + 15) / 16 * 16;     // + up to 3 bytes of alignment slack + 2 pixels the quad path may read past the reach; 16-byte LDS accesses
+            const size_t out_tile = (size_t)oyb * oxb * 3;
+            const size_t in_tile = (size_t)rows * pitch;
+            const size_t lds = (size_t)oyb * pitch * 4 + ((size_t)oxb * ht.max_taps + (size_t)oyb * vt.max_taps) * 4 +
+                               (2 * (size_t)oyb + 2 * (size_t)oxb) * 4 + (in_tile > out_tile ? in_tile : out_tile) + 16;
+            if ((size_t)oxb * ht.max_taps > 1024 || (size_t)oyb * vt.max_taps > 1024) continue;   // tap tables: <= 4 values per thread
+            if (lds > 78 * 1024) continue;                               // two blocks per CU (160 KB of LDS)
+            const double cost = ((double)rows * pitch + (double)oyb * pitch * vtaps) / ((double)oyb * oxb);
+            if (cost < best) {
+                best = cost;
+                found = true;
+                *out = ResizeTile{oyb, oxb, pitch, rows, (unsigned)((nw + oxb - 1) / oxb), (unsigned)((nh + oyb - 1) / oyb), (unsigned)ex};
+                *lds_bytes = lds;
+            }
+        }
+    (void)w; (void)h;
+    return found;
+}
+
+static bool resize_can_fuse(const uint8_t* in, size_t n_frames, size_t w, size_t h, size_t nw, size_t nh, const DeviceTaps& vt,
+                            const DeviceTaps& ht, const uint8_t* out, ResizeTile* tl, size_t* lds) {
+    const bool rows_aligned = (w * 3) % 4 == 0 && (nw * 3) % 4 == 0 &&
+                              ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 3) == 0;
+    return rows_aligned && n_frames <= 65535 && pick_resize_tile(vt, ht, w, h, nw, nh, tl, lds);
+}
+
+// f32 intermediate the two-pass fallback needs (0 when the fused kernel takes the call)
+size_t resize_tmp_bytes(const uint8_t* in, size_t n_frames, size_t w, size_t h, size_t nw, size_t nh, const DeviceTaps& vt,
+                        const DeviceTaps& ht, const uint8_t* out) {
+    ResizeTile tl;
+    size_t lds = 0;
+    return resize_can_fuse(in, n_frames, w, h, nw, nh, vt, ht, out, &tl, &lds) ? 0 : n_frames * nh * w * 3 * sizeof(float);
+}
+
 int launch_resize_rgb8(hipStream_t st, const uint8_t* in, size_t n_frames, size_t w, size_t h, size_t nw, size_t nh,
                        const DeviceTaps& vt, const DeviceTaps& ht, float* tmp, uint8_t* out) {
     if (!n_frames) return SSW_OK;
     const unsigned row_elems = (unsigned)(w * 3);
+    ResizeTile tl;
+    size_t lds = 0;
+    if (resize_can_fuse(in, n_frames, w, h, nw, nh, vt, ht, out, &tl, &lds)) {
+        const dim3 grid(tl.tiles_x * tl.tiles_y, (unsigned)n_frames);
+        {   // tiles above 64 KB of dynamic LDS need the per-device function attribute: set it once per device
+            static bool attr_set[64] = {false};
+            int dev = 0;
+            SSW_HIP_CHECK(hipGetDevice(&dev));
+            if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+                SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                if (dev >= 0 && dev < 64) attr_set[dev] = true;
+            }
+        }
+#define SSW_RESIZE_FUSED(MODE) resize_fused_kernel<MODE><<<grid, 256, lds, st>>>(in, out, (unsigned)w, (unsigned)h, (unsigned)nw, (unsigned)nh, \
+        vt.left, vt.count, vt.weights, vt.max_taps, ht.left, ht.count, ht.weights, ht.max_taps, tl)
+        if (nw < w) SSW_RESIZE_FUSED(0);
+        else if (ht.quad_uniform) SSW_RESIZE_FUSED(1);
+        else SSW_RESIZE_FUSED(2);
+#undef SSW_RESIZE_FUSED
+        SSW_HIP_CHECK(hipGetLastError());
+        return SSW_OK;
+    }
     const bool vec = (row_elems % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 3) == 0) &&
                      ((reinterpret_cast<uintptr_t>(tmp) & 15) == 0);
     if (vec) {

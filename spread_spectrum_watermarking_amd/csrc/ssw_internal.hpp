@@ -154,12 +154,16 @@ struct DeviceTaps {
     uint32_t* count = nullptr;
     float* weights = nullptr;
     uint32_t max_taps = 0;
+    uint32_t span[8] = {0};     // reach in input samples of 1, 2, 4 .. 128 consecutive outputs (host-side, for tiling)
+    bool quad_uniform = false;  // every aligned group of 4 outputs shares left and count, count <= 5 (integer up-scaling)
 };
 void build_resize_taps(size_t in_len, size_t out_len, ResizeTaps& t);
 int launch_u8_to_f32(hipStream_t st, const uint8_t* in, size_t n, float* out);
 int launch_f32_to_u8(hipStream_t st, const float* in, size_t n, uint8_t* out);
 int launch_rgb8_to_yiq(hipStream_t st, const uint8_t* rgb, size_t npix, float* y, float* i, float* q);
 int launch_yiq_to_rgb8(hipStream_t st, const float* y, const float* i, const float* q, size_t npix, uint8_t* rgb);
+size_t resize_tmp_bytes(const uint8_t* in, size_t n_frames, size_t w, size_t h, size_t nw, size_t nh, const DeviceTaps& vt,
+                        const DeviceTaps& ht, const uint8_t* out);
 int launch_resize_rgb8(hipStream_t st, const uint8_t* in, size_t n_frames, size_t w, size_t h, size_t nw, size_t nh,
                        const DeviceTaps& vt, const DeviceTaps& ht, float* tmp, uint8_t* out);
 

@@ -375,6 +375,18 @@ int get_taps(ssw_ctx* ctx, size_t in_len, size_t out_len, DeviceTaps* out) {
     build_resize_taps(in_len, out_len, host);
     DeviceTaps d;
     d.max_taps = host.max_taps;
+    for (int e = 0; e < 8; ++e) {                       // reach of 2^e consecutive outputs, maximum over all aligned groups
+        const size_t g = (size_t)1 << e;
+        uint32_t m = 0;
+        for (size_t o = 0; o < out_len; o += g) {
+            const size_t last = std::min(o + g, out_len) - 1;
+            m = std::max(m, host.left[last] + host.count[last] - host.left[o]);
+        }
+        d.span[e] = m;
+    }
+    d.quad_uniform = out_len % 4 == 0;
+    for (size_t o = 0; o < out_len && d.quad_uniform; ++o)
+        d.quad_uniform = host.count[o] <= 5 && host.left[o] == host.left[o & ~(size_t)3] && host.count[o] == host.count[o & ~(size_t)3];
     SSW_ALLOC(&d.left, out_len * sizeof(uint32_t));
     SSW_ALLOC(&d.count, out_len * sizeof(uint32_t));
     SSW_ALLOC(&d.weights, host.weights.size() * sizeof(float));
@@ -442,10 +454,11 @@ int ssw_resize_rgb8(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_frames, size_t
     SSW_TRY(get_taps(ctx, h, nh, &vt));
     SSW_TRY(get_taps(ctx, w, nw, &ht));
     const size_t chunk = effective_chunk(ctx, w, h, n_frames);
-    SSW_TRY(grow(ctx->resize_tmp, chunk * nh * w * 3 * sizeof(float)));
+    const size_t tmp_bytes = resize_tmp_bytes(dev_in, std::min(chunk, n_frames), w, h, nw, nh, vt, ht, dev_out);
+    if (tmp_bytes) SSW_TRY(grow(ctx->resize_tmp, tmp_bytes));       // two-pass fallback only (unaligned rows)
     for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
         const size_t n = std::min(chunk, n_frames - f0);
-        StageTimer t(ctx, SSW_STAGE_RESIZE, ctx->stream);
+        StageTimer t(ctx, SSW_STAGE_RESIZE, ctx->stream, (double)n * 3.0 * ((double)w * h + (double)nw * nh));
         SSW_TRY(launch_resize_rgb8(ctx->stream, dev_in + f0 * w * h * 3, n, w, h, nw, nh, vt, ht,
                                    (float*)ctx->resize_tmp.p, dev_out + f0 * nw * nh * 3));
     }

@@ -87,6 +87,22 @@ def test_gpu_resize_bit_exact(cat_images, scale):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [(640, 444, 300, 200), (640, 444, 960, 666), (640, 444, 320, 888), (640, 444, 1280, 111),
+                                  (640, 444, 4, 3), (64, 48, 512, 384), (640, 444, 636, 440), (16, 12, 8, 6)])
+def test_gpu_fused_resize_bit_exact_on_aligned_rows(cat_images, case):
+    """Rows that are a multiple of 4 bytes take the fused LDS-tiled kernel (vertical + horizontal pass in one
+    launch): every ratio -- down, up, mixed, near 1, extreme -- must reproduce the oracle bit for bit, also on
+    a batch of distinct frames."""
+    import gpu_util as G
+    w, h, nw, nh = case
+    cat = cat_images["cat"]
+    frames = np.stack([cat[:h, :w], cat[444 - h:, 640 - w:][::-1].copy(), cat[:h, 640 - w:][:, ::-1].copy()])
+    got = G.resize_rgb8(frames, nw, nh)
+    for f in range(3):
+        assert np.array_equal(got[f], O.resize_rgb8(frames[f], nw, nh)), (case, f)
+
+
+@pytest.mark.gpu
 def test_gpu_rgb8_batch_paths_equal_f32_paths_and_oracle(marks, cat_images):
     """Fused u8 entry points == host-converted f32 entry points == oracle (canonical precision)."""
     import gpu_util as G
