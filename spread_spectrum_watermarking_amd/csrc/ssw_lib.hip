@@ -100,6 +100,7 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
     // while the basis GEMMs of the other chunk in flight run on the context's stream.
     // (Measured: restricting this stream to 16 .. 128 CUs with a CU mask only slows the step down -- the
     // chunk's GEMMs wait for its pre-pass -- so it is a plain stream.)
+    // Stream priorities (either way round) change nothing either.
     e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; set_last_error(hipGetErrorString(e)); return SSW_ERR_HIP; }
     const char* ov = std::getenv("SSW_OVERLAP");
