@@ -257,7 +257,7 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--k", type=int, default=None)
     ap.add_argument("--chunk", type=int, default=0,
-                    help="frames per internal pass (0 = the library's automatic choice, ~2^28 pixels; bounds the workspace)")
+                    help="frames per internal pass (0 = the library's automatic choice, ~2^30 pixels; bounds the workspace)")
     ap.add_argument("--precision", choices=["f32", "f64"], default="f64",
                     help="headline precision: f64 = canonical (bit-parity with the CPU path), f32 = fast")
     ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other precision")
@@ -312,8 +312,9 @@ def main():
     ctx.set_chunk_frames(args.chunk)
     fold_level = 0 if args.no_fold else int(os.environ.get("SSW_FOLD_LEVEL", str(L.DCT_FOLDING_DEFAULT)))
     ctx.set_dct_folding(fold_level)
+    ctx.set_overlap(not args.no_overlap)
     W, H, K, B = args.width, args.height, args.k, args.batch
-    chunk_eff = min(args.chunk if args.chunk > 0 else max(1, (1 << 28) // (W * H)), B)   # mirrors effective_chunk() in the library
+    chunk_eff = ctx.pass_frames(B, W, H)          # frames per internal pass (automatic: ~2^30 pixels)
     workload_tag = (f"configs[{args.config or 3}] of BASELINE.json: \"{preset['quote']}\"" if (args.config is not None or
                     (B, W, H, K) == (preset["batch"], preset["width"], preset["height"], preset["k"])) else "custom shape")
 

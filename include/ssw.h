@@ -123,14 +123,19 @@ int ssw_ctx_set_stream(ssw_ctx* ctx, void* hip_stream);
 int ssw_ctx_wait_event(ssw_ctx* ctx, void* hip_event);
 int ssw_ctx_record_event(ssw_ctx* ctx, void* hip_event);
 /* Frames processed per internal pass of the batch entry points (bounds the workspace: 36 bytes per
-   pixel of a pass in the default GEMM strategy).  0 = automatic, the default: about 2^28 pixels per
-   pass (32 4K frames, 129 full-HD frames, 8 8K frames; 9.6 GB of workspace). */
+   pixel of a pass in the default GEMM strategy, per lane -- see ssw_ctx_set_overlap).  0 = automatic, the
+   default: about 2^30 pixels per pass (129 4K frames, 517 full-HD frames, 32 8K frames; 38.7 GB of
+   workspace per lane): sized for the 288 GB of an MI355X, where longer GEMM launches amortise their tails
+   (2^28 pixels cost 2.8 % at 4K, 1.8 % at full HD).  Smaller devices / co-tenants: set it explicitly. */
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
+/* Frames per pass a batch call over n_frames frames of w x h would use with the current setting. */
+size_t ssw_ctx_pass_frames(ssw_ctx* ctx, size_t n_frames, size_t w, size_t h);
 
 /* Batch pipelines (ssw_batch_*): two chunks in flight, each with its own workspace -- the HBM-bound stages
    of one (operand pre-passes, selection, colour conversion) run on a second internal stream while the
    basis GEMMs of the other run on the context's stream; the context's stream is ordered after all of it
-   when the call returns.  Default on (2 x 36 B/px of workspace); 0 = one chunk at a time on one stream
+   when the call returns.  Default on, used from three passes per call upwards (2 x 36 B/px of workspace
+   then); 0 = one chunk at a time on one stream
    (what the per-kernel timings of bench.py's roofline leg use).  Results are bit-identical either way. */
 int ssw_ctx_set_overlap(ssw_ctx* ctx, int enable);
 /* ssw_batch_extract*: transform the derived frames only where Reader::extract reads them

@@ -50,6 +50,7 @@ SIGNATURES = {
     "ssw_ctx_wait_event": (C.c_int, [_vp, _vp]),
     "ssw_ctx_record_event": (C.c_int, [_vp, _vp]),
     "ssw_ctx_set_chunk_frames": (C.c_int, [_vp, _sz]),
+    "ssw_ctx_pass_frames": (_sz, [_vp, _sz, _sz, _sz]),
     "ssw_ctx_set_dct_folding": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_enable_timing": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_reset_timing": (C.c_int, [_vp]),

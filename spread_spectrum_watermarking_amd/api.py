@@ -65,6 +65,10 @@ class Context:
     def set_chunk_frames(self, n: int):
         check(self._lib.ssw_ctx_set_chunk_frames(self.handle, n), "ssw_ctx_set_chunk_frames")
 
+    def pass_frames(self, n_frames: int, w: int, h: int) -> int:
+        """Frames per internal pass a batch call over n_frames frames of w x h would use."""
+        return int(self._lib.ssw_ctx_pass_frames(self.handle, n_frames, w, h))
+
     def set_dct_folding(self, level=True):
         """Basis-GEMM strategy (include/ssw.h): False / 0 dense; 1 (= 2) one folding level inside the GEMM
         kernel; 3 / 4 operand-ready GEMMs with one / two

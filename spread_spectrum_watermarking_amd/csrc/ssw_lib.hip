@@ -178,6 +178,10 @@ int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames) {
     return SSW_OK;
 }
 
+size_t ssw_ctx_pass_frames(ssw_ctx* ctx, size_t n_frames, size_t w, size_t h) {
+    return ctx ? effective_chunk(ctx, w, h, n_frames) : 0;
+}
+
 int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int enable) {
     if (!ctx) return SSW_ERR_BAD_ARG;
     if (enable < 0 || enable > 6) return SSW_ERR_BAD_ARG;

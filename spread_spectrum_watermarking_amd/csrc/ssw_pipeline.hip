@@ -129,12 +129,18 @@ int check_config(const ssw_config* cfg) {
     return SSW_OK;
 }
 
-// Frames per internal pass: the caller's setting, or (0 = automatic, the default) about 2^28 pixels -- 32 4K
-// frames, 129 full-HD ones: the GEMM grids then run ~16 rounds of blocks (a 16-frame pass of 1080p frames
-// only 2.1, 11 % slower) for 36 B/px of workspace per lane (4K: 9.6 GB).
+// Frames per internal pass: the caller's setting, or (0 = automatic, the default) about 2^30 pixels -- 129 4K
+// frames, 517 full-HD ones, 32 8K ones -- capped where the f64 operand planes of a pass would pass 4 GB (the
+// operand-ready GEMMs walk them with 32-bit offsets).  The GEMM grids then run ~64 rounds of blocks: against
+// 2^28 pixels (16 rounds, the r1 default) the tails and first-tile latencies weigh 2.8 % less at 4K, 1.8 % at
+// full HD, 1.4 % at 8K.  Workspace: 36 B/px of a pass per lane (38.7 GB), sized for 288 GB of HBM.
 size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames) {
     size_t c = ctx->chunk_frames;
-    if (c == 0) c = std::max<size_t>(1, ((size_t)1 << 28) / std::max<size_t>(w * h, 1));
+    if (c == 0) {
+        c = std::max<size_t>(1, ((size_t)1 << 30) / std::max<size_t>(w * h, 1));
+        const size_t per_frame = dct_pair_operand_elems(true, 1, w, h) * sizeof(double);
+        if (per_frame) c = std::max<size_t>(1, std::min(c, (size_t)0xFFFFFFFFull / per_frame));
+    }
     return std::min(c, std::max<size_t>(n_frames, 1));
 }
 
@@ -427,7 +433,8 @@ int hop(ssw_ctx* ctx, ssw_ctx::Lane& ln, hipStream_t to) {
 // ctx->aux_stream.  On return the context's stream is ordered after everything that was enqueued.
 int run_pipeline(ssw_ctx* ctx, size_t n_chunks, const std::function<int(size_t, ssw_ctx::Lane&, Chain&)>& build) {
     if (n_chunks == 0) return SSW_OK;
-    const bool two = ctx->overlap && n_chunks > 1 && ctx->aux_stream != nullptr;
+    // two lanes pay from three chunks on (with two, each lane would run a single chunk: measured equal to one lane)
+    const bool two = ctx->overlap && n_chunks > 2 && ctx->aux_stream != nullptr;
     hipStream_t G = ctx->stream, H = two ? ctx->aux_stream : ctx->stream;
     const int n_lanes = two ? 2 : 1;
     if (two) {                                     // the caller's earlier work on the context's stream comes first

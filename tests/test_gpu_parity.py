@@ -689,16 +689,32 @@ def test_8k_pipeline_and_resize_attack_parity_with_oracle():
     assert abs(float(sims_d[0]) - o_sim) < 0.05 and sims_d[0] > 6.0
 
 
-def test_full_hd_batch_with_automatic_chunking_equals_handles():
-    """BASELINE configs[2] frame size, one automatic chunk (129 frames of 1920x1080) plus a ragged one of 3:
-    every frame's index list and extracted mark against per-frame Reader handles (full transforms), the
-    marked frames of both chunks against Writer handles."""
+def test_automatic_pass_size():
+    """~2^30 pixels per internal pass, capped where the f64 operand planes of a pass would pass 4 GB."""
+    ctx = G.ctx()
+    assert ctx.pass_frames(10 ** 6, 3840, 2160) == 129 and ctx.pass_frames(10 ** 6, 1920, 1080) == 517
+    assert ctx.pass_frames(10 ** 6, 7680, 4320) == 32 and ctx.pass_frames(5, 3840, 2160) == 5
+    ctx.set_chunk_frames(7)
+    try:
+        assert ctx.pass_frames(100, 1920, 1080) == 7
+    finally:
+        ctx.set_chunk_frames(0)
+
+
+def test_full_hd_batch_in_several_passes_equals_handles():
+    """BASELINE configs[2] frame size through the chunk loop with two lanes: 132 frames of 1920x1080 in passes of
+    43 (three full ones and a ragged one of 3): every frame's index list and extracted mark against per-frame
+    Reader handles (full transforms), marked frames of every pass against Writer handles."""
     w, h, k = 1920, 1080, 1000
-    n = ((1 << 28) // (w * h)) + 3
+    n = 132
     rgb = G.synth(12, 0, n, w, h)
     marks = np.random.default_rng(13).standard_normal((n, k)).astype(np.float32)
-    res = G.batch_embed(rgb, marks, want_idx=True)
-    ext, sims = G.batch_extract(rgb, res["rgb"], k, marks)
+    G.ctx().set_chunk_frames(43)
+    try:
+        res = G.batch_embed(rgb, marks, want_idx=True)
+        ext, sims = G.batch_extract(rgb, res["rgb"], k, marks)
+    finally:
+        G.ctx().set_chunk_frames(0)
     stats = G.ctx().prune_stats()
     assert stats["redone_chunks"] == 0
     for f in range(n):
