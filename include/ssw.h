@@ -124,7 +124,7 @@ int ssw_ctx_wait_event(ssw_ctx* ctx, void* hip_event);
 int ssw_ctx_record_event(ssw_ctx* ctx, void* hip_event);
 /* Frames processed per internal pass of the batch entry points (bounds the workspace: 36 bytes per
    pixel of a pass in the default GEMM strategy, per lane -- see ssw_ctx_set_overlap).  0 = automatic, the
-   default: about 2^30 pixels per pass (129 4K frames, 517 full-HD frames, 32 8K frames; 38.7 GB of
+   default: about 2^30 pixels per pass (128 4K frames, 514 full-HD frames, 32 8K frames; 38.7 GB of
    workspace per lane): sized for the 288 GB of an MI355X, where longer GEMM launches amortise their tails
    (2^28 pixels cost 2.8 % at 4K, 1.8 % at full HD).  Smaller devices / co-tenants: set it explicitly. */
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);

@@ -129,8 +129,8 @@ int check_config(const ssw_config* cfg) {
     return SSW_OK;
 }
 
-// Frames per internal pass: the caller's setting, or (0 = automatic, the default) about 2^30 pixels -- 129 4K
-// frames, 517 full-HD ones, 32 8K ones -- capped where the f64 operand planes of a pass would pass 4 GB (the
+// Frames per internal pass: the caller's setting, or (0 = automatic, the default) about 2^30 pixels -- 128 4K
+// frames, 514 full-HD ones, 32 8K ones -- capped where the f64 operand planes of a pass would pass 4 GB (the
 // operand-ready GEMMs walk them with 32-bit offsets).  The GEMM grids then run ~64 rounds of blocks: against
 // 2^28 pixels (16 rounds, the r1 default) the tails and first-tile latencies weigh 2.8 % less at 4K, 1.8 % at
 // full HD, 1.4 % at 8K.  Workspace: 36 B/px of a pass per lane (38.7 GB), sized for 288 GB of HBM.
