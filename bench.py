@@ -554,9 +554,11 @@ def main():
             "value": round(W * H / 1e6 / sel_s, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
             "sample": f"same frame, f32 FFT DCT + top-k selection instead of the full sort, single thread, {sel_s:.1f} s",
         }
-        # same work, one frame per thread on ALL the host's cores (the reference itself is single-threaded;
-        # this is the frame-parallel upper bound of SURVEY 8(d)).  ctypes releases the GIL in the C calls.
-        # Threads are only capped by host memory: ~0.6 GB of planes per 4K frame in flight.
+        # same work, one frame per thread (the reference itself is single-threaded; this is the frame-parallel
+        # upper bound of SURVEY 8(d)).  ctypes releases the GIL in the C calls.  Thread counts: 16, a quarter of the
+        # cores, and ALL the host's logical cores (capped only by host memory: ~0.7 GB of planes and sort keys per
+        # 4K frame in flight); the full sort is memory-bound, so "all cores" is not always the fastest -- every
+        # count is reported, the best one is the figure.
         import concurrent.futures as cf
         n_cores = os.cpu_count() or 1
         try:
@@ -564,19 +566,23 @@ def main():
         except (OSError, IndexError, ValueError):
             avail = 16 << 30
         per_thread = 80 * W * H                        # bytes: rgb out + planes + sort keys (16 B/coefficient)
-        n_thr = max(1, min(n_cores, int(0.5 * avail / per_thread)))
+        cap = max(1, int(0.5 * avail / per_thread))
 
         def one(_):
             m = O.embed_frame(frame0, mark0, backend=O.BACKEND_F32, full_sort=True)
             O.extract_frame(frame0, m, mark0, backend=O.BACKEND_F32, full_sort=True)
-        t0 = time.perf_counter()
-        with cf.ThreadPoolExecutor(n_thr) as ex:
-            list(ex.map(one, range(n_thr)))
-        par_s = time.perf_counter() - t0
+        sweep = []
+        for n_thr in sorted({min(16, n_cores, cap), min(max(n_cores // 4, 1), cap), min(n_cores, cap)}):
+            t0 = time.perf_counter()
+            with cf.ThreadPoolExecutor(n_thr) as ex:
+                list(ex.map(one, range(n_thr)))
+            par_s = time.perf_counter() - t0
+            sweep.append({"threads": n_thr, "value": round(n_thr * W * H / 1e6 / par_s, 4), "seconds": round(par_s, 1)})
+        best = max(sweep, key=lambda e: e["value"])
         result["cpu_baseline_parallel"] = {
-            "value": round(n_thr * W * H / 1e6 / par_s, 4), "unit": "Mpix/s", "cores": n_thr, "kind": "port",
-            "sample": f"{n_thr} frames {W}x{H}, one per thread on {n_thr} of the host's {n_cores} logical cores "
-                      f"(limited only by host memory), same faithful pipeline, {par_s:.1f} s",
+            "value": best["value"], "unit": "Mpix/s", "cores": best["threads"], "kind": "port",
+            "sample": f"{best['threads']} frames {W}x{H}, one per thread, same faithful pipeline, {best['seconds']} s; "
+                      f"host has {n_cores} logical cores", "sweep": sweep,
         }
         # untimed: the oracle's correctly rounded (f64-backend) pipeline = what the canonical precision must equal,
         # on the first and the last frame of the batch (the last one sits in the last chunk of the pipeline)
