@@ -27,7 +27,12 @@ __host__ __device__ inline size_t blk_index(size_t line, unsigned k, size_t rows
 //   EPI_INV_E  T[pair] = acc1 + acc2, T[n/2-1-pair] = acc1 - acc2, unrounded (inverse level 2: the even half E)
 //   EPI_INV_O  with n1 = pair, n2 = pair + n/4:  out[n1] = T[n1] + acc1, out[n-1-n1] = T[n1] - acc1,
 //              out[n2] = T[n2] + acc2, out[n-1-n2] = T[n2] - acc2          (inverse level 2: odd part + combine)
-enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4 };
+//   EPI_INV_O_RGB  EPI_INV_O on the last pass of Writer::result (a column pass): instead of storing the Y sample it
+//              converts (Y, I, Q) of that pixel to RGB like From<&YIQ32FImage> for Rgb32FImage (src/yiq.rs:187-197:
+//              (y + m1 i) + m2 q per channel, clamped to [0, 1]) and stores the interleaved pixel -- f32, or
+//              8-bit like into_rgb8() (round(clamp * 255)).  The colour conversion's HBM traffic (I, Q in, RGB out)
+//              then runs in the shadow of the other resident block's MFMAs and the Y plane is never written.
+enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4, EPI_INV_O_RGB = 5 };
 
 template <typename T>
 struct PairOutT {
@@ -36,7 +41,49 @@ struct PairOutT {
     unsigned W, H;       // plane dims
     unsigned n;          // transform length (W for a row pass, H for a column pass)
     unsigned c1, c2, cs; // EPI_FWD
+    // EPI_INV_O_RGB: the I and Q planes of the frames (same layout as `out`) and the interleaved RGB output
+    const float* iq_i = nullptr;
+    const float* iq_q = nullptr;
+    void* rgb = nullptr;
+    unsigned rgb_u8 = 0;
 };
+
+// yiq.rs:139-147 (f32::clamp) and :163-165, :173-175: the arithmetic of color.hip / attack.hip, per pixel
+__device__ inline float pair_clamp01(float x) {
+    if (x < 0.0f) return 0.0f;
+    if (x > 1.0f) return 1.0f;
+    return x;
+}
+// NB samples y[t] of pixels px[t] (where ok[t]): all I / Q loads are issued before the first store -- one memory
+// latency per batch instead of one per pixel (the stores to `rgb` may alias the loads as far as the compiler knows)
+// (px[t]: offset from pixel `base`, below W * H < 2^32)
+template <typename T, int NB>
+__device__ inline void pair_store_rgb_batch(const PairOutT<T>& po, size_t base, const unsigned (&px)[NB], const float (&y)[NB], bool ok) {
+    if (!ok) return;
+    const float* __restrict__ ip = po.iq_i + base;
+    const float* __restrict__ qp = po.iq_q + base;
+    float iv[NB], qv[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        iv[t] = ip[px[t]];
+        qv[t] = qp[px[t]];
+    }
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+        const float r = pair_clamp01(1.0f * y[t] + 0.948262f * iv[t] + 0.624013f * qv[t]);
+        const float g = pair_clamp01(1.0f * y[t] + -0.276066f * iv[t] + -0.639810f * qv[t]);
+        const float b = pair_clamp01(1.0f * y[t] + -1.105450f * iv[t] + 1.729860f * qv[t]);
+        if (po.rgb_u8) {
+            uint8_t* o = static_cast<uint8_t*>(po.rgb) + 3 * (base + px[t]);
+            o[0] = (uint8_t)roundf(pair_clamp01(r) * 255.0f);
+            o[1] = (uint8_t)roundf(pair_clamp01(g) * 255.0f);
+            o[2] = (uint8_t)roundf(pair_clamp01(b) * 255.0f);
+        } else {
+            float* o = static_cast<float*>(po.rgb) + 3 * (base + px[t]);
+            o[0] = r; o[1] = g; o[2] = b;
+        }
+    }
+}
 
 // row stride (in elements) of the operand planes / half bases of a length-n axis for precision T:
 // n/2 rounded up so that the GEMM runs an even number of k-steps (f64: 8 per step, f32: 16)

@@ -288,6 +288,41 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             const unsigned z = line / W, col = line - z * W;
             float* lp = po.out + (size_t)z * H * W + col;
             double* tp = po.tmp + (size_t)z * (n / 2) * W + col;
+            if (EPI == EPI_INV_O_RGB) {
+                // Writer::result in the last pass: per pair, its 4 output rows -- the even-half values of two pairs, then
+                // I and Q of a pair's four pixels, are loaded together (deeper batches spill: 198 VGPRs as it is);
+                // offsets from the frame's pixel (row 0, col) address I, Q and RGB alike
+                const size_t base = (size_t)z * H * W + col;
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        double e1[2], e2[2];
+                        bool okp[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const unsigned pair = p0 + wn + 16 * jn + lq + 4 * (r + q);
+                            okp[q] = pair < NP;
+                            const unsigned pc = okp[q] ? pair : 0;
+                            e1[q] = tp[(size_t)pc * W];
+                            e2[q] = tp[(size_t)(pc + n / 4) * W];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const unsigned pair = p0 + wn + 16 * jn + lq + 4 * (r + q);
+                            const unsigned n1 = okp[q] ? pair : 0, n2 = n1 + n / 4;
+                            const double a1 = acc1[i][jn][r + q], a2 = acc2[i][jn][r + q];
+                            const unsigned idx[4] = {n1, n - 1 - n1, n2, n - 1 - n2};
+                            const float v[4] = {(float)(e1[q] + a1), (float)(e1[q] - a1), (float)(e2[q] + a2), (float)(e2[q] - a2)};
+                            unsigned px[4];
+                            float yv[4];
+#pragma unroll
+                            for (int o = 0; o < 4; ++o) { px[o] = idx[o] * W; yv[o] = apply_epilogue(ep, v[o], idx[o]); }
+                            pair_store_rgb_batch<double, 4>(po, base, px, yv, okp[q]);
+                        }
+                    }
+                continue;
+            }
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
@@ -313,7 +348,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 // applies to the even part (its frequencies are multiples of 2^sub of the full transform's).
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
-                             size_t h, Epilogue ep) {
+                             size_t h, Epilogue ep, const RgbSink* sink) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t lines = is_row ? n_frames * h : n_frames * w;
@@ -345,6 +380,11 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     } else {
         if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV, false); else SSW_LAUNCH_PAIR(true, EPI_INV, false); }
         else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_E, false); else SSW_LAUNCH_PAIR(true, EPI_INV_E, false); }
+        else if (sink && sink->rgb) {      // last pass of Writer::result: colour conversion in the epilogue
+            if (is_row || sub != 0) return SSW_ERR_BAD_ARG;
+            po.iq_i = sink->iq_i; po.iq_q = sink->iq_q; po.rgb = sink->rgb; po.rgb_u8 = sink->u8 ? 1u : 0u;
+            SSW_LAUNCH_PAIR(true, EPI_INV_O_RGB, true);
+        }
         else { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, true); else SSW_LAUNCH_PAIR(true, EPI_INV_O, true); }
     }
 #undef SSW_LAUNCH_PAIR

@@ -80,8 +80,12 @@ struct Xform {
     bool rgb_u8 = false;
     float* iq_i = nullptr;
     float* iq_q = nullptr;
+    // inverse transforms (Writer::result): where the last pass may deliver RGB pixels instead of the Y plane
+    // (iq_i / iq_q are then inputs); build_transform reports through `fused_rgb` whether it did
+    void* rgb_out = nullptr;
+    bool rgb_out_u8 = false;
 };
-int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch);
+int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch, bool* fused_rgb = nullptr);
 bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8);
 // rgb -> Y (+ I, Q) -> forward transform of Y into `y` (Writer::new / Reader::new_impl), fused where possible
 int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t n, size_t w,

@@ -104,13 +104,21 @@ int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, bool u8, const void
 bool dct_pair_can_fold3(size_t len);
 int launch_dct_pair_prep8_rows(hipStream_t st, bool f64, int src_kind, const void* src, size_t n_frames, size_t w, size_t h,
                                void* r1, void* r2, void* m, void* p, float* ip, float* qp);
-// kind 0: one folding level; 1 / 2: the even / odd half of two levels; sub: see dct_pair_f64.hip
+// Writer::result fused into the last inverse pass (EPI_INV_O_RGB): the frames' I / Q planes and the RGB output
+struct RgbSink {
+    const float* iq_i = nullptr;
+    const float* iq_q = nullptr;
+    void* rgb = nullptr;          // [n][h][w][3] f32, or u8 when `u8`
+    bool u8 = false;
+};
+// kind 0: one folding level; 1 / 2: the even / odd half of two levels; sub: see dct_pair_f64.hip;
+// sink (inverse column pass, kind 2 only): colour conversion in the epilogue instead of storing Y
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
-                             size_t h, Epilogue ep);
+                             size_t h, Epilogue ep, const RgbSink* sink = nullptr);
 int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const float* x1, const float* x2,
                              const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
-                             size_t h, Epilogue ep);
+                             size_t h, Epilogue ep, const RgbSink* sink = nullptr);
 
 int launch_dct_pair_gemm_rows_subset_f64(hipStream_t st, const double* x, const double* y, unsigned cap, unsigned Kp, float* out,
                                          unsigned out_stride, unsigned off, size_t lines);

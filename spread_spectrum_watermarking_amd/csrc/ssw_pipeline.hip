@@ -148,11 +148,12 @@ size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames) 
 namespace {
 
 int pair_gemm(hipStream_t st, bool f64, bool is_row, bool inverse, int kind, int sub, const void* x1, const void* x2,
-              const void* y1, const void* y2, float* dst, void* tmpE, size_t n, size_t w, size_t h, Epilogue ep) {
+              const void* y1, const void* y2, float* dst, void* tmpE, size_t n, size_t w, size_t h, Epilogue ep,
+              const RgbSink* sink = nullptr) {
     return f64 ? launch_dct_pair_gemm_f64(st, is_row, inverse, kind, sub, (const double*)x1, (const double*)x2, (const double*)y1,
-                                          (const double*)y2, dst, (double*)tmpE, n, w, h, ep)
+                                          (const double*)y2, dst, (double*)tmpE, n, w, h, ep, sink)
                : launch_dct_pair_gemm_f32(st, is_row, inverse, kind, sub, (const float*)x1, (const float*)x2, (const float*)y1,
-                                          (const float*)y2, dst, (float*)tmpE, n, w, h, ep);
+                                          (const float*)y2, dst, (float*)tmpE, n, w, h, ep, sink);
 }
 
 // executed flop of one launch of the operand-ready GEMM (two products of lines x pairs x K multiply-adds)
@@ -165,7 +166,7 @@ double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t
 
 // One pass of the separable transform (src -> dst along rows or columns) appended to `ch`.
 int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass, bool is_row, const float* src, float* dst,
-               Epilogue ep, Chain& ch) {
+               Epilogue ep, Chain& ch, bool* fused_rgb = nullptr) {
     const bool inverse = (x.type == SSW_DCT3);
     const bool f64 = (x.precision == SSW_PRECISION_F64);
     const int precision = x.precision;
@@ -251,6 +252,13 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             }});
             const double f_main = pair_gemm_flop(is_row, 2, 0, n, w, h);
             const double f_all = f_main + pair_gemm_flop(is_row, 1, 0, n, w, h);
+            // Writer::result: the last pass of an inverse transform (a column pass) converts to RGB in its epilogue
+            RgbSink sink;
+            if (inverse && !first_pass && !is_row && x.rgb_out && x.iq_i && x.iq_q) {
+                sink.iq_i = x.iq_i; sink.iq_q = x.iq_q; sink.rgb = x.rgb_out; sink.u8 = x.rgb_out_u8;
+                if (fused_rgb) *fused_rgb = true;
+            }
+            const bool with_sink = sink.rgb != nullptr;
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 // even half: a half-length transform of S (forward) / of the even coefficients (inverse), folded again
@@ -258,7 +266,8 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 // odd half: full half-length sum, the odd basis split into two row blocks (second block:
                 // len/4 lines further inside every k-block of the same plane = 64 bytes per line)
                 StageTimer tm(ctx, st_main, st, f_main);
-                return pair_gemm(st, f64, is_row, inverse, 2, 0, x2, x2, b1, (const char*)b1 + (len / 4) * 64, dst, tmpE, n, w, h, ep);
+                return pair_gemm(st, f64, is_row, inverse, 2, 0, x2, x2, b1, (const char*)b1 + (len / 4) * 64, dst, tmpE, n, w, h, ep,
+                                 with_sink ? &sink : nullptr);
             }});
         }
         return SSW_OK;
@@ -301,7 +310,7 @@ size_t operand_frame_limit(const ssw_ctx* ctx, bool f64, size_t w, size_t h) {
 
 }  // namespace
 
-int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch) {
+int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch, bool* fused_rgb) {
     const bool f64 = (x.precision == SSW_PRECISION_F64);
     const size_t n = x.n, w = x.w, h = x.h;
     if (n == 0) return SSW_OK;
@@ -315,7 +324,8 @@ int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch) 
             if (x.rgb) s.rgb = static_cast<const char*>(x.rgb) + f0 * w * h * 3 * (x.rgb_u8 ? 1 : sizeof(float));
             if (x.iq_i) s.iq_i = x.iq_i + f0 * w * h;
             if (x.iq_q) s.iq_q = x.iq_q + f0 * w * h;
-            SSW_TRY(build_transform(ctx, ws, s, ch));
+            if (x.rgb_out) s.rgb_out = static_cast<char*>(x.rgb_out) + f0 * w * h * 3 * (x.rgb_out_u8 ? 1 : sizeof(float));
+            SSW_TRY(build_transform(ctx, ws, s, ch, fused_rgb));
         }
         return SSW_OK;
     }
@@ -332,7 +342,7 @@ int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch) 
         const float* src = (pass == 0) ? x.data : x.tmp;
         float* dst = (pass == 0) ? x.tmp : x.data;
         const Epilogue ep = (x.type == SSW_DCT2_ORTHOGONAL) ? ortho(is_row ? w : h) : (pass == 1 ? last : plain);
-        SSW_TRY(build_pass(ctx, ws, x, pass == 0, is_row, src, dst, ep, ch));
+        SSW_TRY(build_pass(ctx, ws, x, pass == 0, is_row, src, dst, ep, ch, fused_rgb));
     }
     return SSW_OK;
 }
@@ -634,7 +644,11 @@ int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, b
             StageTimer t(ctx, SSW_STAGE_EMBED, st);                                                       // :356
             return launch_embed(st, y, n, plane, idx, k_eff, marks, nullptr, nullptr, 1, k_eff, k, c.method, c.alpha);
         }});
-        SSW_TRY(build_transform(ctx, ws, Xform{SSW_DCT3, c.precision, n, w, h, y, tmp}, ch));              // :368-374
+        Xform inv{SSW_DCT3, c.precision, n, w, h, y, tmp};                                                // :368-374
+        inv.iq_i = pi; inv.iq_q = pq; inv.rgb_out = out; inv.rgb_out_u8 = u8_out;                        // + :377 in the last pass
+        bool fused_rgb = false;
+        SSW_TRY(build_transform(ctx, ws, inv, ch, &fused_rgb));
+        if (fused_rgb) return SSW_OK;
         const double out_bytes = (double)n * plane * (12.0 + (u8_out ? 3.0 : 12.0));
         ch.push_back({true, [=](hipStream_t st) -> int {
             StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB, st, out_bytes);                                       // :377 (+ into_rgb8)
