@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Builds profiles/<tag>_pmc_traffic.json from the per-kernel PMC summaries of tools/collect_profiles.sh
+(<dir>/<tag>_pmc_fetch.txt and <tag>_pmc_write.txt, written by tools/pmc_summary.py).
+
+HBM-side bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024: on gfx950 FETCH_SIZE reports half
+the bytes of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are
+included (memory-side L2 requests), so this is an upper bound on DRAM traffic.
+usage: pmc_traffic_json.py <dir> <tag> <width> <height> <chunk_frames> <commit>"""
+import ast
+import json
+import sys
+
+d, tag, W, H, chunk, commit = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+
+
+def load(path):
+    out = {}
+    for line in open(path):
+        if "{" not in line:
+            continue
+        name, rest = line.split(" {", 1)
+        body, n = rest.rsplit("} n=", 1)
+        out[name.strip()] = (ast.literal_eval("{" + body + "}"), int(n))
+    return out
+
+
+fetch, write = load(f"{d}/{tag}_pmc_fetch.txt"), load(f"{d}/{tag}_pmc_write.txt")
+lines_r, lines_c = chunk * H, chunk * W
+esz = 8
+names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESIGN.md, algorithmic bytes per launch, note)
+    "pair_gemm_f64_kernel<false, 0, true, 0>": ("pair_gemm_f64_kernel<rows, odd half>",
+        lines_r * (W // 2) * esz + (W // 2) ** 2 * esz + lines_r * (W // 2) * 4,
+        "x- operand plane (k-blocked f64) x odd half basis -> the W/2 odd frequencies (f32)"),
+    "pair_gemm_f64_kernel<false, 0, true, 1>": ("pair_gemm_f64_kernel<rows, S- launch>",
+        lines_r * (W // 4) * esz + (W // 4) ** 2 * esz + lines_r * (W // 4) * 4, "frequencies 2 mod 4 (third folding level)"),
+    "pair_gemm_f64_kernel<false, 0, false, 1>": ("pair_gemm_f64_kernel<rows, (SSS, SS-) launch>",
+        2 * lines_r * (W // 8) * esz + 2 * (W // 8) ** 2 * esz + lines_r * (W // 4) * 4, "frequencies 0 and 4 mod 8"),
+    "pair_gemm_f64_kernel<true, 0, true, 0>": ("pair_gemm_f64_kernel<cols, odd half>",
+        lines_c * (H // 2) * esz + (H // 2) ** 2 * esz + lines_c * (H // 2) * 4, "forward column pass, odd frequencies"),
+    "pair_gemm_f64_kernel<true, 0, false, 0>": ("pair_gemm_f64_kernel<cols, even half>",
+        2 * lines_c * (H // 4) * esz + 2 * (H // 4) ** 2 * esz + lines_c * (H // 2) * 4, "forward column pass, even frequencies (two levels)"),
+    "pair_gemm_f64_kernel<true, 5, true, 0>": ("pair_gemm_f64_kernel<cols, inverse odd half + yiq->rgb>",
+        lines_c * (H // 2) * esz + (H // 2) ** 2 * esz + lines_c * (H // 2) * esz + lines_c * H * (8 + 12),
+        "last pass of Writer::result: O operand + unrounded even half in, I and Q in, RGB f32 out"),
+    "pair_prep8_rows_kernel<double, 1, false>": ("pair_prep8_rows_kernel<double, rgb>", lines_r * W * (12 + esz),
+        "reader: RGB f32 in, three-level f64 operand planes out"),
+    "pair_prep8_rows_kernel<double, 1, true>": ("pair_prep8_rows_kernel<double, rgb, with I/Q>", lines_r * W * (12 + 8 + esz),
+        "writer: RGB f32 in, operand planes + I, Q planes out"),
+    "pair_prep4_cols_kernel<double, false>": ("pair_prep4_cols_kernel<double, forward>", lines_r * W * (4 + esz),
+        "f32 plane in, transposed two-level f64 operand planes out (mean over launches incl. the narrow pruned ones)"),
+    "pair_prep4_rows_kernel<double, true>": ("pair_prep4_rows_kernel<double, inverse>", lines_r * W * (4 + esz), "coefficient plane in, (EE, EO, O) out"),
+    "select_compact_kernel<true>": ("select_compact_kernel<energy>", lines_r * W * 4, "the one full pass of the top-k selection"),
+}
+out = {"_how": __doc__.strip().split("usage:")[0].strip(), "commit": commit,
+       "workload": {"width": W, "height": H, "chunk_frames": chunk}, "kernels": {}}
+for inst, (label, alg, note) in names.items():
+    if inst not in fetch or inst not in write:
+        continue
+    f, w = fetch[inst][0]["FETCH_SIZE"], write[inst][0]
+    hbm = int(2 * f * 1024 + w["WRITE_SIZE"] * 1024)
+    hit, miss = w.get("TCC_HIT_sum", 0.0), w.get("TCC_MISS_sum", 0.0)
+    out["kernels"][label] = {"instance": inst, "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w["WRITE_SIZE"], "TCC_HIT": hit, "TCC_MISS": miss,
+                             "launches_averaged": fetch[inst][1], "hbm_bytes_per_launch": hbm,
+                             "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None,
+                             "algorithmic_bytes_per_launch": int(alg), "traffic_over_algorithmic": round(hbm / alg, 2), "note": note}
+json.dump(out, sys.stdout, indent=1)
+print()
