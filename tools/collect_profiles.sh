@@ -46,8 +46,8 @@ stats config3_serial --steps 3 --warmup 1 --no-overlap $SHORT
 stats config2 --config 2 --steps 3 --warmup 1 $SHORT
 stats config1 --config 1 --steps 5 --warmup 2 $SHORT
 stats config4 --config 4 --steps 1 --warmup 1 $SHORT
-# 3. PMC passes on one serial 4K step of 64 frames (32-frame passes)
-PM="--batch 64 --steps 1 --warmup 1 --no-overlap $SHORT"
+# 3. PMC passes on one serial 4K step of 128 frames (one pass)
+PM="--batch 128 --steps 1 --warmup 1 --no-overlap $SHORT"      # one 128-frame pass: the automatic pass size of the default run
 pmc fetch FETCH_SIZE -- $PM
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $PM
 pmc valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $PM
@@ -56,4 +56,7 @@ PA="--config 4 --batch 8 --steps 1 --warmup 1 --no-overlap $SHORT"
 pmc attack_valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- $PA
 pmc attack_fetch FETCH_SIZE -- $PA
 pmc attack_write WRITE_SIZE -- $PA
+python3 "$R/tools/pmc_traffic_json.py" "$OUT" "$TAG" 3840 2160 128 "$COMMIT" > "$OUT/${TAG}_pmc_traffic.json"
+python3 "$R/tools/handle_bench.py" > "$OUT/${TAG}_handle_api.txt" 2>&1
+python3 "$R/tools/resize_bench.py" > "$OUT/${TAG}_resize_bench.txt" 2>&1
 ls -la "$OUT"
