@@ -41,14 +41,16 @@ typedef PairOutT<double> PairOut;
 // (one product's image operand feeds both basis operands; it is staged and read once).
 // (A 256-line x 32-pair block tile for pair counts that 64 divides badly -- 540 at 4K -- was measured:
 // equal on the shared-X launches, 10 % slower on the two-operand ones; not kept.)
-// SUB only names the instance (launches that serve a deeper folding level show up separately in profiles)
-template <bool COLS, int EPI, bool SAMEX, int SUB = 0>
+// SUB only names the instance (launches that serve a deeper folding level show up separately in profiles).
+// BM: lines per block tile.  128 is the tile of every large launch; 64 serves launches whose 128-line grid
+// would leave the chip half empty (a single 4K frame: 17 x 15 = 255 tiles for 512 block slots).
+template <bool COLS, int EPI, bool SAMEX, int SUB = 0, int BM = 128>
 __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     const double* __restrict__ X1g, const double* __restrict__ X2g, const double* __restrict__ Y1g,
     const double* __restrict__ Y2g, PairOut po, unsigned L /*lines*/, unsigned NP /*pairs*/,
     unsigned Kp, unsigned yrows /*lines of the basis planes*/, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
     constexpr int NX = SAMEX ? 1 : 2;
-    constexpr int BM = 128, BN = 64, XQ = 2;                               // XQ: X lines per staging thread
+    constexpr int BN = 64, XQ = BM / 64;                                   // XQ: X lines per staging thread
     __shared__ __attribute__((aligned(16))) double sX[2][NX][BM * PBK];    // [buffer][product]
     __shared__ __attribute__((aligned(16))) double sY[2][2][BN * PBK];
 
@@ -109,12 +111,13 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         put(&sY[buf][0][0], ry1);
         put(&sY[buf][1][0], ry2);
     };
-    // The wave grid is 2 x 2 (each wave 64 lines x 32 pairs: NI = 4 line tiles) unless the tile holds at
+    // The wave grid is 2 x 2 (each wave BM/2 lines x 32 pairs: NI = BM/32 line tiles) unless the tile holds at
     // most 32 valid pairs -- the last tile column of e.g. 540 pairs -- where it is 4 x 1 (each wave
-    // 32 lines x 32 pairs: NI = 2) and the tile takes half the MFMAs instead of computing padding.
+    // BM/4 lines x 32 pairs: NI = BM/64) and the tile takes half the MFMAs instead of computing padding.
     auto run = [&](auto nic) {
     constexpr int NI = decltype(nic)::value;
-    const unsigned wm = NI == 4 ? (wave >> 1) * 64 : wave * 32, wn = NI == 4 ? (wave & 1) * 32 : 0;
+    constexpr bool FULL = NI == BM / 32;
+    const unsigned wm = FULL ? (wave >> 1) * (BM / 2) : wave * (BM / 4), wn = FULL ? (wave & 1) * 32 : 0;
     f64x4 acc1[NI][2], acc2[NI][2];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
@@ -334,8 +337,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         }
     }
     };
-    if (NP - p0 <= 32) run(std::integral_constant<int, 2>{});
-    else               run(std::integral_constant<int, 4>{});
+    if (NP - p0 <= 32) run(std::integral_constant<int, BM / 64>{});
+    else               run(std::integral_constant<int, BM / 32>{});
 }
 
 
@@ -360,8 +363,12 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
     const unsigned NP = (unsigned)(kind == 0 ? leff / 2 : leff / 4);
     const unsigned Kp = (unsigned)(kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
-    const unsigned BM = 128, BN = 64;
-    const unsigned tiles_m = (L + BM - 1) / BM, tiles_n = (NP + BN - 1) / BN;
+    const unsigned BN = 64;
+    const unsigned tiles_n = (NP + BN - 1) / BN;
+    // 64-line tiles when 128-line ones would not fill the 512 block slots of the chip (2 per CU)
+    const bool small = (unsigned long long)((L + 127) / 128) * tiles_n < 448;
+    const unsigned BM = small ? 64 : 128;
+    const unsigned tiles_m = (L + BM - 1) / BM;
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)len, 0, 1, 2};
@@ -369,9 +376,11 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     if ((unsigned long long)Kp * L * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
+#define SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, SUBV, BMV) \
+        pair_gemm_f64_kernel<COLS, EPI, SAMEX, SUBV, BMV><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep)
 #define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) do { \
-        if (sub == 0) pair_gemm_f64_kernel<COLS, EPI, SAMEX, 0><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep); \
-        else          pair_gemm_f64_kernel<COLS, EPI, SAMEX, 1><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep); \
+        if (small) { if (sub == 0) SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, 0, 64); else SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, 1, 64); } \
+        else       { if (sub == 0) SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, 0, 128); else SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, 1, 128); } \
     } while (0)
     if (!inverse) {
         if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD_ADJ, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
@@ -388,6 +397,7 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
         else { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, true); else SSW_LAUNCH_PAIR(true, EPI_INV_O, true); }
     }
 #undef SSW_LAUNCH_PAIR
+#undef SSW_LAUNCH_PAIR_BM
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
