@@ -414,6 +414,92 @@ __global__ __launch_bounds__(256) void pair_prep8_rows_kernel(const void* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Three folding levels on a forward COLUMN pass (H % 32 == 0; pays from ~3000 rows: 8K frames): the same
+// folds as pair_prep8_rows_kernel, per column, transposed through LDS.  Lines = (frame, column); one block =
+// 32 eighth-indices e x 32 columns; per (e, column) the 8 rows that meet in e:
+//   rows  e, Hq-1-e, Hq+e, Hh-1-e, Hh+e, 3Hq-1-e, 3Hq+e, H-1-e      (Hq = H/4, Hh = H/2; row u mirrors row 7-u)
+//   S[u] = x[u] + x[7-u], P(pos u) = x[u] - x[7-u]   (u < 4: positions e, Hq-1-e, Hq+e, Hh-1-e of the half axis)
+//   SS[0] = S[0] + S[3], SS[1] = S[1] + S[2];  M(e) = S[0] - S[3], M(Hq-1-e) = S[1] - S[2]
+//   R1(e) = SS[0] + SS[1], R2(e) = SS[0] - SS[1]
+// R1, R2: K8 = kpad(H/4) wide; M: Kq = kpad(H/2); P: Kp = kpad(H); k-blocked, zero padded.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pair_prep8_cols_kernel(const float* __restrict__ IN, T* __restrict__ R1,
+                                                             T* __restrict__ R2, T* __restrict__ M, T* __restrict__ P,
+                                                             unsigned W, unsigned H, unsigned K8, unsigned Kq, unsigned Kp,
+                                                             unsigned n_frames, unsigned tiles_e, unsigned tiles_c) {
+    __shared__ T s[4][32][33];            // first R1, R2, M(e), M(Hq-1-e); then the four positions of P (34 KB in f64)
+    const unsigned Hh = H / 2, Hq = H / 4, He = H / 8;
+    const unsigned z = blockIdx.x / (tiles_e * tiles_c);
+    const unsigned tt = blockIdx.x % (tiles_e * tiles_c);
+    const unsigned e0 = (tt % tiles_e) * 32, c0 = (tt / tiles_e) * 32;
+    const float* __restrict__ Pz = IN + (size_t)z * H * W;
+    const unsigned tid = threadIdx.x;
+    const unsigned er = tid >> 3, cq = (tid & 7) * 4;              // load side: one e, 4 columns
+    const unsigned cl = tid & 31, kq = (tid >> 5) * 4;             // store side: one column, 4 consecutive e
+    const unsigned cw = c0 + cl, ew = e0 + kq;
+    const bool wr = cw < W && ew < K8;
+    const size_t line = (size_t)z * W + cw, lines = (size_t)n_frames * W;
+    auto fwd = [&](int a) { return (vec4_t<T>){s[a][cl][kq], s[a][cl][kq + 1], s[a][cl][kq + 2], s[a][cl][kq + 3]}; };
+    auto rev = [&](int a) { return (vec4_t<T>){s[a][cl][kq + 3], s[a][cl][kq + 2], s[a][cl][kq + 1], s[a][cl][kq]}; };
+    T d1[4][4];                                                     // P values of this thread's (e, 4 columns), kept for the second round
+    {
+        const unsigned e = e0 + er;
+        unsigned c = c0 + cq;
+        c = c + 4 <= W ? c : W - 4;                               // W % 4 == 0; duplicates are never written out
+        f32x4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (e < He) {
+            const unsigned rows[8] = {e, Hq - 1 - e, Hq + e, Hh - 1 - e, Hh + e, 3 * Hq - 1 - e, 3 * Hq + e, H - 1 - e};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(Pz + (size_t)rows[u] * W + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T S[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                S[u] = (T)x[u][i] + (T)x[7 - u][i];
+                d1[u][i] = (T)x[u][i] - (T)x[7 - u][i];
+            }
+            const T ss0 = S[0] + S[3], ss1 = S[1] + S[2];
+            s[0][cq + i][er] = ss0 + ss1;
+            s[1][cq + i][er] = ss0 - ss1;
+            s[2][cq + i][er] = S[0] - S[3];
+            s[3][cq + i][er] = S[1] - S[2];
+        }
+    }
+    __syncthreads();
+    if (wr) {
+        *reinterpret_cast<vec4_t<T>*>(R1 + blk_index<T>(line, ew, lines)) = fwd(0);      // zero beyond He (x was zero)
+        *reinterpret_cast<vec4_t<T>*>(R2 + blk_index<T>(line, ew, lines)) = fwd(1);
+        if (ew < He) {                                              // He % 4 == 0: whole quads
+            *reinterpret_cast<vec4_t<T>*>(M + blk_index<T>(line, ew, lines)) = fwd(2);
+            *reinterpret_cast<vec4_t<T>*>(M + blk_index<T>(line, Hq - 4 - ew, lines)) = rev(3);
+        }
+        if (ew == 0)
+            for (unsigned zz = Hq; zz < Kq; zz += 4) *reinterpret_cast<vec4_t<T>*>(M + blk_index<T>(line, zz, lines)) = (vec4_t<T>){0, 0, 0, 0};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[u][cq + i][er] = d1[u][i];
+    __syncthreads();
+    if (wr) {
+        if (ew < He) {
+            *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, ew, lines)) = fwd(0);
+            *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, Hq - 4 - ew, lines)) = rev(1);
+            *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, Hq + ew, lines)) = fwd(2);
+            *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, Hh - 4 - ew, lines)) = rev(3);
+        }
+        if (ew == 0)
+            for (unsigned zz = Hh; zz < Kp; zz += 4) *reinterpret_cast<vec4_t<T>*>(P + blk_index<T>(line, zz, lines)) = (vec4_t<T>){0, 0, 0, 0};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
 size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h) {
@@ -550,6 +636,26 @@ int launch_dct_pair_prep8_rows(hipStream_t st, bool f64, int src_kind, const voi
                                void* r1, void* r2, void* m, void* p, float* ip, float* qp) {
     return f64 ? prep8_impl<double>(st, src_kind, src, n_frames, w, h, (double*)r1, (double*)r2, (double*)m, (double*)p, ip, qp)
                : prep8_impl<float>(st, src_kind, src, n_frames, w, h, (float*)r1, (float*)r2, (float*)m, (float*)p, ip, qp);
+}
+
+template <typename T>
+static int prep8_cols_impl(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, T* r1, T* r2, T* m, T* p) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned Kp = (unsigned)pair_kpad<T>(h), Kq = (unsigned)pair_kpad<T>(h / 2), K8 = (unsigned)pair_kpad<T>(h / 4);
+    const unsigned tiles_e = (K8 + 31) / 32, tiles_c = (unsigned)((w + 31) / 32);
+    const unsigned long long nblk = (unsigned long long)tiles_e * tiles_c * n_frames;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    pair_prep8_cols_kernel<T><<<(unsigned)nblk, 256, 0, st>>>(in, r1, r2, m, p, (unsigned)w, (unsigned)h, K8, Kq, Kp, (unsigned)n_frames, tiles_e, tiles_c);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// three levels on a forward column pass (H % 32 == 0): (SSS, SS-) [kpad(h/4) wide], S- [kpad(h/2)], x- [kpad(h)]
+int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t n_frames, size_t w, size_t h,
+                               void* r1, void* r2, void* m, void* p) {
+    return f64 ? prep8_cols_impl<double>(st, in, n_frames, w, h, (double*)r1, (double*)r2, (double*)m, (double*)p)
+               : prep8_cols_impl<float>(st, in, n_frames, w, h, (float*)r1, (float*)r2, (float*)m, (float*)p);
 }
 
 }  // namespace ssw

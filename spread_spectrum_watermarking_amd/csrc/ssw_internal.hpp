@@ -111,6 +111,8 @@ struct RgbSink {
     void* rgb = nullptr;          // [n][h][w][3] f32, or u8 when `u8`
     bool u8 = false;
 };
+int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t n_frames, size_t w, size_t h,
+                               void* r1, void* r2, void* m, void* p);
 // kind 0: one folding level; 1 / 2: the even / odd half of two levels; sub: see dct_pair_f64.hip;
 // sink (inverse column pass, kind 2 only): colour conversion in the epilogue instead of storing Y
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,

@@ -195,10 +195,11 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
         SSW_TRY(get_basis(ctx, len, inverse, f64, 3, &b0));        // k-blocked half bases
         SSW_TRY(get_basis(ctx, len, inverse, f64, 4, &b1));
         // a third level pays once the sums are long enough (4K: +1.6 %, 1080p: -3 %); level 6 forces it
-        const bool three = two && !inverse && is_row && dct_pair_can_fold3(len) &&
+        const bool three = two && !inverse && dct_pair_can_fold3(len) &&
                            (ctx->fold_level >= 6 || (ctx->fold_level == 5 && len >= 3072));
         if (three) {
-            // forward row pass, three levels: x- (odd frequencies), S- (2 mod 4), (SSS, SS-) (0 and 4 mod 8)
+            // forward pass, three levels: x- (odd frequencies), S- (2 mod 4), (SSS, SS-) (0 and 4 mod 8); on a column
+            // pass (8K: 4320 rows) the pre-pass transposes like the two-level one
             for (int b = 0; b < 4; ++b) SSW_TRY(grow(ws.operand[b], bytes));
             void* d1 = ws.operand[1].p;
             void* d2 = ws.operand[0].p;
@@ -210,6 +211,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             SSW_TRY(get_basis(ctx, len / 4, false, f64, 4, &e1));
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
+                if (!is_row) return launch_dct_pair_prep8_cols(st, f64, src, n, w, h, r1, r2, d2, d1);
                 return launch_dct_pair_prep8_rows(st, f64, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h,
                                                   r1, r2, d2, d1, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
             }});

@@ -145,7 +145,8 @@ def test_dct_folded_equals_dense(shape, dct_type, precision):
 
 
 @pytest.mark.parametrize("shape", [(16, 16), (24, 40), (40, 128), (72, 136), (136, 72), (200, 328), (264, 8),
-                                   (64, 64), (80, 208), (208, 80), (144, 1040), (72, 128), (40, 160), (1080, 1920)])
+                                   (64, 64), (80, 208), (208, 80), (144, 1040), (72, 128), (40, 160), (1080, 1920),
+                                   (128, 256), (160, 192), (288, 136), (256, 128)])
 @pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
 @pytest.mark.parametrize("level", [3, 4, 6])
 def test_dct_operand_ready_path_matches(shape, dct_type, level):
@@ -169,7 +170,7 @@ def test_dct_operand_ready_path_matches(shape, dct_type, level):
     assert np.abs(three.astype(np.float64) - ref).max() <= 2e-7 * max(ac_max(ref), 1.0)
 
 
-@pytest.mark.parametrize("shape", [(24, 40), (72, 136), (136, 72), (80, 208), (144, 1040), (1080, 1920)])
+@pytest.mark.parametrize("shape", [(24, 40), (72, 136), (136, 72), (80, 208), (144, 1040), (1080, 1920), (128, 256), (288, 136)])
 @pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
 @pytest.mark.parametrize("level", [1, 3, 4, 6])
 def test_dct_f32_every_strategy_within_tolerance(shape, dct_type, level):
@@ -541,7 +542,7 @@ def test_batch_path_equals_handles_and_oracle(precision):
 
 
 @pytest.mark.parametrize("precision", [F32, F64])
-@pytest.mark.parametrize("shape", [(80, 208), (144, 1040), (72, 128)])
+@pytest.mark.parametrize("shape", [(80, 208), (144, 1040), (72, 128), (160, 1056), (128, 256)])
 @pytest.mark.parametrize("level", [5, 6])
 def test_batch_path_fused_colour_prepass_equals_handles(precision, shape, level):
     """Shapes that take the default GEMM strategy (W >= H, W % 16 == 0, H % 8 == 0): the batch entry
