@@ -286,6 +286,27 @@ def test_bench_two_ranks_equal_one_process(tmp_path):
     assert j2["value"] > 0 and j2["scaling"] == "weak"
 
 
+def test_bench_under_torchrun_two_ranks(tmp_path):
+    """The driver's multi-GPU command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...` -- bench.py is then one rank (RANK / LOCAL_RANK / WORLD_SIZE come
+    from torchrun).  Two ranks on the test box's one GPU (gloo coordination, see above); ONE JSON line, from rank 0."""
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, SSW_BENCH_SHARE_DEVICE="1", SSW_BENCH_DIST_BACKEND="gloo")
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(v, None)
+    dumpf = str(tmp_path / "tr.npz")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "3", "--dump", dumpf] + SMALL,
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks"]["ranks_seen"] == [0, 1] and j["ranks"]["dist_backend"] == "gloo"
+    assert np.load(dumpf)["sims"].shape == (6,)
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     import torch
     n = torch.cuda.device_count()
