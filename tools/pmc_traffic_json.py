@@ -24,7 +24,16 @@ def load(path):
     return out
 
 
-fetch, write = load(f"{d}/{tag}_pmc_fetch.txt"), load(f"{d}/{tag}_pmc_write.txt")
+def strip_tile(table):      # instance names carry the block-tile template argument: "<..., 0, 128>" -> "<..., 0>"
+    out = {}
+    for name, v in table.items():
+        if name.startswith("pair_gemm_") and name.endswith(", 128>"):
+            name = name[:-len(", 128>")] + ">"
+        out[name] = v
+    return out
+
+
+fetch, write = strip_tile(load(f"{d}/{tag}_pmc_fetch.txt")), strip_tile(load(f"{d}/{tag}_pmc_write.txt"))
 lines_r, lines_c = chunk * H, chunk * W
 esz = 8
 names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESIGN.md, algorithmic bytes per launch, note)
