@@ -266,6 +266,7 @@ def main():
     ap.add_argument("--embed-only", action="store_true", help="configs[1] flow: Writer::new + mark only (DCT2 -> embed -> DCT3)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true", help="frame-parallel CPU baseline also on all host cores (minutes)")
     ap.add_argument("--no-fold", action="store_true", help="dense basis GEMMs instead of the even/odd-folded ones")
     ap.add_argument("--no-timers-off-leg", action="store_true", help="skip the short re-measurement with the stage timers off")
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the short re-measurement with one chunk at a time on one stream")
@@ -555,10 +556,12 @@ def main():
             "sample": f"same frame, f32 FFT DCT + top-k selection instead of the full sort, single thread, {sel_s:.1f} s",
         }
         # same work, one frame per thread (the reference itself is single-threaded; this is the frame-parallel
-        # upper bound of SURVEY 8(d)).  ctypes releases the GIL in the C calls.  Thread counts: 16, a quarter of the
-        # cores, and ALL the host's logical cores (capped only by host memory: ~0.7 GB of planes and sort keys per
-        # 4K frame in flight); the full sort is memory-bound, so "all cores" is not always the fastest -- every
-        # count is reported, the best one is the figure.
+        # upper bound of SURVEY 8(d)).  ctypes releases the GIL in the C calls.  Thread counts: 16 and a quarter of
+        # the cores by default; --cpu-all-cores adds ALL the host's logical cores (capped only by host memory:
+        # ~0.7 GB of planes and sort keys per 4K frame in flight).  The full sort is memory-bound: on the 256-thread
+        # host of the GPU boxes all cores take 145 s for 14.6 Mpix/s where 16 threads reach 25.7 in 5 s
+        # (profiles/r2_bench_config3_n1.json holds that sweep), so the long leg is opt-in.  Every count measured is
+        # reported, the best one is the figure.
         import concurrent.futures as cf
         n_cores = os.cpu_count() or 1
         try:
@@ -572,7 +575,10 @@ def main():
             m = O.embed_frame(frame0, mark0, backend=O.BACKEND_F32, full_sort=True)
             O.extract_frame(frame0, m, mark0, backend=O.BACKEND_F32, full_sort=True)
         sweep = []
-        for n_thr in sorted({min(16, n_cores, cap), min(max(n_cores // 4, 1), cap), min(n_cores, cap)}):
+        counts = {min(16, n_cores, cap), min(max(n_cores // 4, 1), cap)}
+        if args.cpu_all_cores:
+            counts.add(min(n_cores, cap))
+        for n_thr in sorted(counts):
             t0 = time.perf_counter()
             with cf.ThreadPoolExecutor(n_thr) as ex:
                 list(ex.map(one, range(n_thr)))

@@ -35,7 +35,7 @@ pmc() {         # name, counters..., then "--" and bench args
 }
 
 # 1. bench lines (driver-style steps for the headline, shorter for the rest)
-run_bench config3_n1 --steps 20 --warmup 5
+run_bench config3_n1 --steps 20 --warmup 5 --cpu-all-cores
 run_bench config2_n1 --config 2 --steps 10 --warmup 3
 run_bench config1_n1 --config 1 --steps 20 --warmup 5
 run_bench config4_n1 --config 4 --steps 3 --warmup 1
