@@ -275,6 +275,24 @@ def test_reader_indices_full_list_and_long_mark(cat_images):
     assert np.array_equal(w.coefficient_image(), O.embed(c0, O.indices(c0, k=20000), [mark]))
 
 
+def test_long_index_lists_at_full_hd():
+    """Beyond the in-LDS top-k limit (16384 entries) at a BASELINE frame size: Reader::indices(k) and a 20000-long mark
+    on a 1920x1080 frame take the full device sort (sort_full.hip) -- same list as the oracle's stable sort."""
+    rgb = O.synth_frame(21, 2, 1920, 1080)
+    reader = wm.Reader.base(rgb)
+    coef = reader.coefficients().reshape(1080, 1920)
+    ref = O.indices(coef, k=40000)
+    assert np.array_equal(reader.indices(40000), ref)
+    assert np.array_equal(reader.indices(16385), ref[:16385])
+    mark = np.random.default_rng(8).standard_normal(20000).astype(np.float32)
+    marks = np.stack([mark, mark[::-1].copy()])
+    frames = np.stack([rgb, O.synth_frame(21, 3, 1920, 1080)])
+    res = G.batch_embed(frames, marks, want_idx=True)                  # batch path, two frames, k > 16384
+    assert np.array_equal(res["idx"][0], ref[:20000].astype(np.uint32))
+    ext, sims = G.batch_extract(frames, res["rgb"], 20000, marks)
+    assert np.all(sims > 0.97 * np.linalg.norm(marks, axis=1)) and np.abs(ext - marks).max() < 0.1
+
+
 def test_topk_degenerate_planes():
     z = np.zeros((2, 9, 13), np.float32)                               # every key ties: index order
     assert np.array_equal(G.topk(z, 50)[0], np.arange(1, 51))
