@@ -490,7 +490,8 @@ def main():
         mpix = world * px_total / 1e6
         flow = "embed (Writer::new + mark: DCT2 -> embed -> DCT3 round trip)" if embed_only else "embed+extract+similarity"
         result = {
-            "metric": "Mpixels/sec embed+extract (4K batch)" if not embed_only else "Mpixels/sec embed + IDCT round trip",
+            "metric": ("Mpixels/sec embed + IDCT round trip" if embed_only else
+                       "Mpixels/sec embed+extract (4K batch)" if (W, H) == (3840, 2160) else f"Mpixels/sec embed+extract ({W}x{H} batch)"),
             "value": round(mpix / elapsed, 2),
             "unit": "Mpix/s",
             "n_gpus": world,
