@@ -32,7 +32,7 @@ class Error : public std::runtime_error {
 public:
     Error(int status, const std::string& where)
         : std::runtime_error(where + ": " + ssw_status_string(status) +
-                             (status == SSW_ERR_HIP ? std::string(" [") + ssw_last_error() + "]" : std::string())),
+                             (status == SSW_ERR_HIP || status == SSW_ERR_OUT_OF_MEMORY ? std::string(" [") + ssw_last_error() + "]" : std::string())),
           status_(status) {}
     int status() const { return status_; }
 
@@ -53,6 +53,16 @@ public:
     Context& operator=(const Context&) = delete;
     ssw_ctx* get() const { return ctx_; }
     void synchronize() { check(ssw_ctx_synchronize(ctx_), "ssw_ctx_synchronize"); }
+    // Stream hand-off for hosts that drive the device-pointer entry points (see the stream contract in ssw.h):
+    // hipStream_t / hipEvent_t as opaque pointers, so that this header needs no HIP headers.
+    void set_stream(void* hip_stream) { check(ssw_ctx_set_stream(ctx_, hip_stream), "ssw_ctx_set_stream"); }
+    void wait_event(void* hip_event) { check(ssw_ctx_wait_event(ctx_, hip_event), "ssw_ctx_wait_event"); }
+    void record_event(void* hip_event) { check(ssw_ctx_record_event(ctx_, hip_event), "ssw_ctx_record_event"); }
+    // Batch entry points: frames per internal pass (0 = automatic), two passes in flight, pruned derived transform.
+    void set_chunk_frames(size_t n) { check(ssw_ctx_set_chunk_frames(ctx_, n), "ssw_ctx_set_chunk_frames"); }
+    size_t pass_frames(size_t n_frames, size_t w, size_t h) const { return ssw_ctx_pass_frames(ctx_, n_frames, w, h); }
+    void set_overlap(bool on) { check(ssw_ctx_set_overlap(ctx_, on ? 1 : 0), "ssw_ctx_set_overlap"); }
+    void set_prune(bool on) { check(ssw_ctx_set_prune(ctx_, on ? 1 : 0), "ssw_ctx_set_prune"); }
 
 private:
     ssw_ctx* ctx_ = nullptr;
