@@ -250,6 +250,45 @@ def test_pruned_path_falls_back_when_the_columns_do_not_fit():
     assert np.array_equal(pruned[3], full[3]) and np.array_equal(pruned[4], full[4])
 
 
+def test_two_contexts_in_one_process_shard_like_two_ranks():
+    """One context per shard, driven by two host threads at the same time (a context is used by one thread at a time;
+    different contexts are independent): the contiguous split of bench.shard_frames must reproduce the one-context run
+    frame for frame -- the single-process form of the multi-GPU path."""
+    import threading
+    import bench
+    n, w, h, k = 6, 512, 288, 120
+    rgb = G.synth(14, 0, n, w, h)
+    marks = np.random.default_rng(15).standard_normal((n, k)).astype(np.float32)
+    cfg = G.default_config()
+    whole = _run_batch(rgb, marks, cfg, True, True, 2)
+    out = [None, None]
+
+    def shard(r):
+        lo, hi = bench.shard_frames(n, 2, r)
+        ctx = wm.Context(0)
+        try:
+            ctx.set_chunk_frames(2)
+            lib = ctx._lib
+            d, dm = ctx.to_device(rgb[lo:hi]), ctx.to_device(marks[lo:hi])
+            m = hi - lo
+            o, e, s_ = ctx.alloc(rgb[lo:hi].nbytes), ctx.alloc(m * k * 4), ctx.alloc(m * 4)
+            check(lib.ssw_batch_embed(ctx.handle, C.byref(cfg), d.ptr, m, w, h, dm.ptr, k, o.ptr, None, None), "embed")
+            check(lib.ssw_batch_extract(ctx.handle, C.byref(cfg), d.ptr, o.ptr, m, w, h, k, e.ptr, dm.ptr, s_.ptr), "extract")
+            out[r] = (o.to_host(np.float32, rgb[lo:hi].shape), e.to_host(np.float32, (m, k)), s_.to_host(np.float32, (m,)))
+        finally:
+            ctx.close()
+
+    threads = [threading.Thread(target=shard, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert out[0] is not None and out[1] is not None
+    assert np.array_equal(np.concatenate([out[0][0], out[1][0]]), whole[0])
+    assert np.array_equal(np.concatenate([out[0][1], out[1][1]]), whole[3])
+    assert np.array_equal(np.concatenate([out[0][2], out[1][2]]), whole[4])
+
+
 # ---- bench.py: ranks and launcher -----------------------------------------------------------------------------
 SMALL = ["--steps", "1", "--warmup", "1", "--width", "512", "--height", "288", "--k", "100", "--no-alt",
          "--no-cpu-baseline", "--no-serial-leg", "--no-timers-off-leg"]
