@@ -140,8 +140,30 @@ def hbm_report(stage, names):
     return out
 
 
+def attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff):
+    """HBM-side traffic of the dominant kernel: PMC counters collected offline exactly as MI355X_MICROARCH.md
+    prescribes (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) and committed under profiles/ with the
+    commit they were collected at; quoted only for the workload they were collected on."""
+    import glob
+    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True)
+    for path in names:
+        try:
+            pmc = json.load(open(path))
+            wl = pmc["workload"]
+            if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, chunk_eff) and roofline["kernel"] in pmc["kernels"]:
+                roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
+                roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
+                roofline["traffic_source"] = f"profiles/{os.path.basename(path)} (collected at commit {pmc.get('commit', '?')})"
+                esz = 8 if prec_name == "f64" else 4     # operand plane in, odd half basis in, f32 odd outputs
+                lines = chunk_eff * H
+                roofline["algorithmic_bytes_per_launch"] = int(lines * (W // 2) * esz + (W // 2) ** 2 * esz + lines * (W // 2) * 4)
+                return
+        except (OSError, KeyError, ValueError):
+            pass
+
+
 def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb_out, marks, marks_host,
-                      extracted, sims, B, W, H, K, workload_tag, rank_report, dump):
+                      extracted, sims, B, total_frames, W, H, K, workload_tag, rank_report, dump):
     """SURVEY 8(f) rank 1 / configs[4]: Writer::mark -> into_rgb8 -> resize to 1/8 (CatmullRom) and back
     -> Reader::extract + similarity, all on 8-bit device-resident frames (tests/attack_resize.rs)."""
     cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32)
@@ -169,30 +191,157 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
     sims_host = sims.cpu().numpy()
     ranks = rank_report(own)
     dump(sims_host, extracted.cpu().numpy())
+    result = None
     if rank == 0:
-        px = float(B) * W * H * args.steps
         main_ms, main_n = stage["dct_row_main"]["ms"], max(stage["dct_row_main"]["launches"], 1)
         peak = PEAK_F64_MFMA_TFLOPS if args.precision == "f64" else PEAK_F32_MFMA_TFLOPS
         main_tf = rate(stage["dct_row_main"]["work"], main_ms) / 1e12
-        print(json.dumps({
-            "metric": "Mpixels/sec embed + resize attack (12.5 %) + extract", "value": round(world * px / 1e6 / elapsed, 2),
+        chunk_eff = ctx.pass_frames(B, W, H)
+        roofline = {"bound": "mfma", "kernel": "pair_gemm_%s_kernel<rows, odd half>" % args.precision,
+                    "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(main_tf / peak, 4),
+                    "traffic": None, "avg_ms": round(main_ms / main_n, 4), "launches": main_n,
+                    "flop_per_launch": stage["dct_row_main"]["work"] / main_n}
+        attach_pmc_traffic(roofline, args.precision, W, H, chunk_eff)
+        result = {
+            "metric": "Mpixels/sec embed + resize attack (12.5 %) + extract",
+            "value": round(float(total_frames) * W * H * args.steps / 1e6 / elapsed, 2),
             "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"batch={B}/GPU {W}x{H} 8-bit frames, {K}-coeff mark, embed -> into_rgb8 -> CatmullRom "
                                    f"resize to 1/8 and back -> extract + similarity; {workload_tag}",
-                       "frames_per_gpu": B, "width": W, "height": H, "k": K,
-                       "parallelism": f"frame-sharded x{world}, no collectives"},
-            "roofline": {"bound": "mfma", "kernel": "pair_gemm_%s_kernel<rows, odd half>" % args.precision,
-                         "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(main_tf / peak, 4),
-                         "traffic": None, "avg_ms": round(main_ms / main_n, 4), "launches": main_n},
+                       "frames_per_gpu": B, "total_frames": total_frames, "width": W, "height": H, "k": K,
+                       "chunk_frames": chunk_eff, "parallelism": f"frame-sharded x{world}, no collectives"},
+            "roofline": roofline,
             "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in stage.items()},
             "hbm_kernels": hbm_report(stage, ["rgb_to_yiq", "dct_prep", "select", "yiq_to_rgb", "resize"]),
             "pruned_derived_transform": prune,
             "ranks": ranks,
             "sim_mean": round(float(sims_host.mean()), 4), "sim_min": round(float(sims_host.min()), 4),
             "sim_sigma_threshold_6_passed": bool((sims_host > 6.0).all()),
-        }))
+        }
+    if rank == 0 and not args.no_cpu_baseline:
+        # tests/attack_resize.rs:17-66 on frame 0 with the oracle: timed in the reference's own arithmetic class
+        # (f32 FFT DCT + full stable sort), then untimed with the exact (f64) backend as the parity checker
+        from oracle import oracle as O
+        frame8 = frames8[0].cpu().numpy()
+        mark0 = marks_host[0].numpy()
+        f32_frame = O.u8_to_f32(frame8)
+        t0 = time.perf_counter()
+        c_marked8 = O.f32_to_u8(O.embed_frame(f32_frame, mark0, backend=O.BACKEND_F32, full_sort=True))
+        c_back = O.resize_rgb8(O.resize_rgb8(c_marked8, W // 8, H // 8), W, H)
+        _, c_sim = O.extract_frame(f32_frame, O.u8_to_f32(c_back), mark0, backend=O.BACKEND_F32, full_sort=True)
+        cpu_s = time.perf_counter() - t0
+        result["cpu_baseline"] = {
+            "value": round(W * H / 1e6 / cpu_s, 4), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": f"1 frame {W}x{H} (frame 0 of the batch): embed -> into_rgb8 -> CatmullRom 1/8 down + up -> extract + "
+                      f"similarity, oracle C restatement (f32 FFT DCT + full stable sort like the reference), single "
+                      f"thread, {cpu_s:.1f} s"}
+        g_marked8 = marked8[0].cpu().numpy()
+        g_small, g_back = small8[0].cpu().numpy(), back8[0].cpu().numpy()
+        g_ext, g_sim = extracted[0].cpu().numpy(), float(sims_host[0])
+        o_marked8 = O.f32_to_u8(O.embed_frame(f32_frame, mark0, backend=O.BACKEND_F64))
+        o_small = O.resize_rgb8(g_marked8, W // 8, H // 8)             # the oracle's resize of the GPU's own frames
+        o_back = O.resize_rgb8(g_small, W, H)
+        o_ext, o_sim = O.extract_frame(f32_frame, O.u8_to_f32(g_back), mark0, backend=O.BACKEND_F64)
+        result["parity"] = {
+            "precision": args.precision, "frame": 0,
+            "marked_rgb8_identical_fraction_vs_cpu_exact": float(np.mean(g_marked8 == o_marked8)),
+            "resize_down_bit_exact": bool(np.array_equal(g_small, o_small)),
+            "resize_up_bit_exact": bool(np.array_equal(g_back, o_back)),
+            "extracted_max_abs_diff_vs_cpu_exact": float(np.abs(g_ext - o_ext).max()),
+            "extracted_bit_identical_fraction": float(np.mean(g_ext == o_ext)),
+            "sim_gpu": g_sim, "sim_cpu_exact": float(o_sim), "sim_delta_vs_cpu_exact": abs(g_sim - float(o_sim)),
+            "sim_cpu_f32fft_own_flow": float(c_sim),
+            "note": "extraction compared on the SAME attacked 8-bit frame (the GPU's); the marked frame against the "
+                    "oracle's own embed; both resizes against the oracle's resize of the GPU's input frames"}
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def handle_api_leg(wm, L, lib, ctx, check, rgb0_dev, W, H, K, precision, reps=5):
+    """The drop-in path a `wm::Writer::mark()` / `Reader::extract` caller takes (src/algorithm.rs:295-316, :355-379,
+    :474-480, :529-539; examples/main.rs:271-278): ONE host image at a time through the single-image handles, host
+    buffers in and out, PCIe included.  8-bit frames (what image files decode to) from pageable and from pinned host
+    memory, and f32 frames (what `into_rgb32f()` yields) for comparison.  Never the headline."""
+    prec = L.PRECISION_F64 if precision == "f64" else L.PRECISION_F32
+    wcfg, rcfg = wm.WriteConfig(precision=prec), wm.ReadConfig(precision=prec)
+    n_val = H * W * 3
+    frame8_dev = torch.empty((H, W, 3), dtype=torch.uint8, device=rgb0_dev.device)
+    torch.cuda.synchronize()
+    check(lib.ssw_convert_f32_to_rgb8(ctx.handle, rgb0_dev.data_ptr(), n_val, frame8_dev.data_ptr()), "to_rgb8")
+    ctx.synchronize()
+    img8 = frame8_dev.cpu().numpy()
+    img32 = img8.astype(np.float32) / np.float32(255)
+    mark = np.random.default_rng(12345).standard_normal(K).astype(np.float32)
+    px = W * H / 1e6
+
+    def run(img, out_buf, u8_out):
+        def embed():
+            wr = wm.Writer(img, wcfg, ctx)
+            return wr.mark_rgb8([mark], out=out_buf) if u8_out else wr.mark([mark], out=out_buf)
+
+        def extract(marked):
+            ext = wm.Reader.base(img, rcfg, ctx).extract(wm.Reader.derived(marked, ctx, prec), K)
+            return ext, wm.Tester(ext, ctx).similarity(mark).similarity
+        marked = embed()
+        extract(marked)                                  # warm-up: bases, staging ring, plane pool
+        ctx.transfer_stats(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            marked = embed()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ext, sim = extract(marked)
+        t2 = time.perf_counter()
+        st = ctx.transfer_stats()
+        return {"embed_ms": round((t1 - t0) / reps * 1e3, 3), "extract_ms": round((t2 - t1) / reps * 1e3, 3),
+                "embed_mpix_s": round(px * reps / (t1 - t0), 1), "extract_mpix_s": round(px * reps / (t2 - t1), 1),
+                "embed_extract_mpix_s": round(px * reps / (t2 - t0), 1),
+                "pcie_bytes_per_frame": int((st["h2d_bytes"] + st["d2h_bytes"]) / reps),
+                "staged_fraction": round(st["staged_bytes"] / max(st["h2d_bytes"] + st["d2h_bytes"], 1.0), 3),
+                "sim": round(float(sim), 4)}, marked.copy(), ext.copy()
+
+    out = {"frame": f"{W}x{H}", "k": K, "reps": reps, "dtype": precision,
+           "flow": "Writer::new + mark [+ into_rgb8] | Reader::base + Reader::derived + extract + Tester::similarity, "
+                   "one host image per call, host buffers in and out (PCIe included)"}
+    out["rgb8_pageable"], marked8, ext8 = run(img8, None, True)
+    pin_in, pin_out = ctx.pinned_empty(img8.shape, np.uint8), ctx.pinned_empty(img8.shape, np.uint8)
+    pin_in[...] = img8
+    out["rgb8_pinned"], marked8p, ext8p = run(pin_in, pin_out, True)
+    out["f32_pageable"], _, _ = run(img32, None, False)
+    # the handles against the batch entry points on the same bytes (n = 1): bit for bit
+    cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, prec)
+    marks_dev = torch.from_numpy(mark[None]).to(rgb0_dev.device)
+    b_marked = torch.empty_like(frame8_dev)
+    b_ext = torch.zeros((1, K), dtype=torch.float32, device=rgb0_dev.device)
+    b_sim = torch.zeros((1,), dtype=torch.float32, device=rgb0_dev.device)
+    torch.cuda.synchronize()
+    check(lib.ssw_batch_embed_rgb8(ctx.handle, C.byref(cfg), frame8_dev.data_ptr(), 1, W, H, marks_dev.data_ptr(), K,
+                                   b_marked.data_ptr()), "ssw_batch_embed_rgb8")
+    check(lib.ssw_batch_extract_rgb8(ctx.handle, C.byref(cfg), frame8_dev.data_ptr(), b_marked.data_ptr(), 1, W, H, K,
+                                     b_ext.data_ptr(), marks_dev.data_ptr(), b_sim.data_ptr()), "ssw_batch_extract_rgb8")
+    ctx.synchronize()
+    out["bit_identical_to_batch_rgb8"] = bool(np.array_equal(marked8, b_marked.cpu().numpy()) and
+                                              np.array_equal(ext8, b_ext.cpu().numpy()[0]) and
+                                              np.array_equal(marked8, marked8p) and np.array_equal(ext8, ext8p))
+    # what the link itself gives: pinned host memory <-> device, 256 MiB each way
+    nbytes = 256 << 20
+    pin = ctx.pinned_empty((nbytes,), np.uint8)
+    pin[...] = 1
+    dbuf = ctx.alloc(nbytes)
+    rates = {}
+    for name, fn in (("h2d", lambda: check(lib.ssw_copy_to_dev(ctx.handle, dbuf.ptr, pin.ctypes.data, nbytes), "h2d")),
+                     ("d2h", lambda: check(lib.ssw_copy_to_host(ctx.handle, pin.ctypes.data, dbuf.ptr, nbytes), "d2h"))):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            fn()
+        rates[name] = round(4 * nbytes / 1e9 / (time.perf_counter() - t0), 1)
+    dbuf.free()
+    out["pinned_link_gbs"] = rates
+    del pin, pin_in, pin_out
+    return out
 
 
 class Dist:
@@ -272,6 +421,14 @@ def main():
     ap.add_argument("--no-serial-leg", action="store_true", help="skip the short re-measurement with one chunk at a time on one stream")
     ap.add_argument("--no-overlap", action="store_true", help="headline with one chunk at a time on one stream")
     ap.add_argument("--no-stage-timers", action="store_true", help="no hipEvent pairs in the timed region (no roofline numbers)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch frames on EVERY GPU (default); strong: --total-batch frames split over the GPUs")
+    ap.add_argument("--total-batch", type=int, default=None,
+                    help="strong scaling: frames of the whole job, contiguous block split frame b -> rank floor(b*N/B) "
+                         "(default: the config's per-GPU batch, i.e. the N=1 workload)")
+    ap.add_argument("--no-handle-leg", action="store_true", help="skip the single-image handle API leg (PCIe-inclusive)")
+    ap.add_argument("--no-full-transform-leg", action="store_true",
+                    help="skip the re-measurement with the pruned derived transform off (the reference's 4 full transforms)")
     ap.add_argument("--dump", default=None, help="rank 0 writes the gathered per-frame sims / extracted marks here (.npz)")
     args = ap.parse_args()
 
@@ -314,13 +471,22 @@ def main():
     fold_level = 0 if args.no_fold else int(os.environ.get("SSW_FOLD_LEVEL", str(L.DCT_FOLDING_DEFAULT)))
     ctx.set_dct_folding(fold_level)
     ctx.set_overlap(not args.no_overlap)
-    W, H, K, B = args.width, args.height, args.k, args.batch
+    W, H, K = args.width, args.height, args.k
+    if args.scaling == "strong":
+        total_frames = args.total_batch or args.batch
+        first_frame, hi = shard_frames(total_frames, world, rank)       # contiguous block split
+        B = hi - first_frame
+        if total_frames < world:
+            raise SystemExit(f"--total-batch {total_frames} < {world} ranks")
+    else:
+        B = args.batch
+        total_frames = B * world
+        first_frame = rank * B                   # global frame index of this rank's shard (weak scaling)
     chunk_eff = ctx.pass_frames(B, W, H)          # frames per internal pass (automatic: ~2^30 pixels)
     workload_tag = (f"configs[{args.config or 3}] of BASELINE.json: \"{preset['quote']}\"" if (args.config is not None or
                     (B, W, H, K) == (preset["batch"], preset["width"], preset["height"], preset["k"])) else "custom shape")
 
     # ---- inputs resident in HBM ------------------------------------------------------------------
-    first_frame = rank * B                       # global frame index of this rank's shard (weak scaling)
     rgb = torch.empty((B, H, W, 3), dtype=torch.float32, device=dev)
     rgb_out = torch.empty_like(rgb)
     marks_host = marks_for_frames(args.seed, first_frame, B, K)
@@ -353,8 +519,9 @@ def main():
 
     if args.attack_resize:
         run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb_out, marks, marks_host,
-                          extracted, sims, B, W, H, K, workload_tag, rank_report, dump)
+                          extracted, sims, B, total_frames, W, H, K, workload_tag, rank_report, dump)
         if dist is not None:
+            dist.barrier()                   # rank 0 runs the CPU baseline / parity legs before it gets here
             dist.close()
         ctx.close()
         return
@@ -392,7 +559,8 @@ def main():
         return own, elapsed, stage, prune, sims_host, ext_host
 
     steps = args.steps
-    px_total = float(B) * W * H * steps
+    px_total = float(B) * W * H * steps                      # this rank's pixels
+    job_px_total = float(total_frames) * W * H * steps       # the whole job's (weak: world x the rank's)
     transforms_per_step = 2 if embed_only else 4     # DCT2, DCT3 (embed) [, DCT2, DCT2 (extract)]
     dense_flop_per_step = transforms_per_step * 2.0 * B * W * H * (W + H)      # F2D = 2 W H (W + H)
 
@@ -427,23 +595,7 @@ def main():
                     "note": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency "
                              "half of the even/odd-folded basis GEMM, counted by the library per launch) / its average "
                              "duration from a hipEvent pair on the stream it runs on, inside the timed region")}
-        # HBM-side traffic of the dominant kernel: PMC counters collected offline exactly as
-        # MI355X_MICROARCH.md prescribes (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) and
-        # committed under profiles/ with the commit they were collected at; quoted only for that workload.
-        for name in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-                wl = pmc["workload"]
-                if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, chunk_eff) and roofline["kernel"] in pmc["kernels"]:
-                    roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
-                    roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
-                    roofline["traffic_source"] = f"profiles/{name} (collected at commit {pmc.get('commit', 'r1 final')})"
-                    esz = 8 if prec_name == "f64" else 4     # operand plane in, odd half basis in, f32 odd outputs
-                    lines = chunk_eff * H
-                    roofline["algorithmic_bytes_per_launch"] = int(lines * (W // 2) * esz + (W // 2) ** 2 * esz + lines * (W // 2) * 4)
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
+        attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff)
         return kernels, roofline, {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
 
     own, elapsed, stage, prune, sims_host, ext_host = measure(args.precision)
@@ -458,7 +610,7 @@ def main():
         args.steps = max(1, min(args.steps, 5))
         s_own, s_elapsed, s_stage, _, s_sims, s_ext = measure(args.precision, overlap=False)
         s_kernels, s_roofline, s_stage_ms = kernel_report(args.precision, s_stage, args.steps)
-        serial = {"value": round(world * float(B) * W * H * args.steps / 1e6 / s_elapsed, 2), "unit": "Mpix/s",
+        serial = {"value": round(float(total_frames) * W * H * args.steps / 1e6 / s_elapsed, 2), "unit": "Mpix/s",
                   "ms_per_step": round(s_elapsed / args.steps * 1e3, 3), "steps": args.steps,
                   "roofline": s_roofline, "kernels": s_kernels, "stage_ms_per_step": s_stage_ms,
                   "bit_identical_to_overlapped": bool(np.array_equal(s_sims, sims_host) and np.array_equal(s_ext, ext_host))}
@@ -469,17 +621,39 @@ def main():
         keep = (args.steps, args.no_stage_timers)
         args.steps, args.no_stage_timers = max(1, min(args.steps, 5)), True
         _, o_elapsed, _, _, _, _ = measure(args.precision)
-        timers_off = {"value": round(world * float(B) * W * H * args.steps / 1e6 / o_elapsed, 2), "unit": "Mpix/s",
+        timers_off = {"value": round(float(total_frames) * W * H * args.steps / 1e6 / o_elapsed, 2), "unit": "Mpix/s",
                       "ms_per_step": round(o_elapsed / args.steps * 1e3, 3), "steps": args.steps,
                       "note": "same workload with the stage timers disabled: what the event pairs in the timed region cost"}
         args.steps, args.no_stage_timers = keep
+
+    # the reference's literal unit of work: Reader::derived transforms the whole frame, 4 full
+    # 2-D transforms per embed + extract -- the same step with the pruned derived transform switched off
+    full = None
+    if not args.no_full_transform_leg and not embed_only:
+        keep = args.steps
+        args.steps = max(1, min(args.steps, 5))
+        ctx.set_prune(False)
+        _, f_elapsed, f_stage, f_prune, f_sims, f_ext = measure(args.precision)
+        ctx.set_prune(True)
+        f_kernels, _, f_stage_ms = kernel_report(args.precision, f_stage, args.steps)
+        full = {"value": round(float(total_frames) * W * H * args.steps / 1e6 / f_elapsed, 2), "unit": "Mpix/s",
+                "ms_per_step": round(f_elapsed / args.steps * 1e3, 3), "steps": args.steps,
+                "transforms_per_frame": 4,
+                "executed_fraction_of_dense": f_kernels["dct_all"]["executed_fraction_of_dense"],
+                "effective_dense_tflops": f_kernels["dct_all"]["effective_dense_tflops"],
+                "dct_rows_frac_mfma": f_kernels["dct_rows"]["frac_mfma"], "dct_cols_frac_mfma": f_kernels["dct_cols"]["frac_mfma"],
+                "stage_ms_per_step": f_stage_ms, "pruned_derived_transform": f_prune,
+                "bit_identical_to_headline": bool(np.array_equal(f_sims, sims_host) and np.array_equal(f_ext, ext_host)),
+                "note": "ssw_ctx_set_prune(0): every derived frame fully transformed like Reader::derived "
+                        "(src/algorithm.rs:469-480); the headline computes only the frequency columns extract reads"}
+        args.steps = keep
 
     alt = None
     if not args.no_alt:
         alt_name = "f32" if args.precision == "f64" else "f64"
         _, alt_elapsed, alt_stage, _, alt_sims, _ = measure(alt_name)
         alt_kernels, alt_roofline, _ = kernel_report(alt_name, alt_stage, steps)
-        alt = {"dtype": alt_name, "value": round(world * px_total / 1e6 / alt_elapsed, 2), "unit": "Mpix/s",
+        alt = {"dtype": alt_name, "value": round(job_px_total / 1e6 / alt_elapsed, 2), "unit": "Mpix/s",
                "ms_per_step": round(alt_elapsed / steps * 1e3, 3), "roofline": alt_roofline,
                "kernels": {k: alt_kernels[k] for k in ("dct_rows", "dct_cols")},
                "sim_mean": round(float(alt_sims.mean()), 4),
@@ -487,7 +661,7 @@ def main():
 
     result = None
     if rank == 0:
-        mpix = world * px_total / 1e6
+        mpix = job_px_total / 1e6
         flow = "embed (Writer::new + mark: DCT2 -> embed -> DCT3 round trip)" if embed_only else "embed+extract+similarity"
         result = {
             "metric": ("Mpixels/sec embed + IDCT round trip" if embed_only else
@@ -499,12 +673,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": f"batch={B}/GPU {W}x{H} f32 frames, {K}-coeff mark, {flow}; {workload_tag}",
-                       "frames_per_gpu": B, "width": W, "height": H, "k": K, "alpha": 0.1,
+            "config": {"workload": (f"batch={B}/GPU" if args.scaling == "weak" else f"batch={total_frames} over {world} GPU(s)") +
+                                   f" {W}x{H} f32 frames, {K}-coeff mark, {flow}; {workload_tag}",
+                       "frames_per_gpu": B, "total_frames": total_frames, "width": W, "height": H, "k": K, "alpha": 0.1,
                        "method": "Option2", "ordering": "Energy", "chunk_frames": chunk_eff,
                        "dct_folding_level": fold_level,
                        "overlap": "one chunk at a time on one stream" if args.no_overlap else "two chunks in flight on two streams",
@@ -520,13 +695,20 @@ def main():
             result["serialized"] = serial
         if timers_off is not None:
             result["timers_off"] = timers_off
+        if full is not None:
+            result["full_transform"] = full
         if alt is not None:
             result["alt_precision"] = alt
 
-    # ---- CPU baseline: the oracle (faithful mode) on a bounded sample, rank 0 at N=1 only ----------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    # ---- the drop-in handle API, one host image per call (PCIe-inclusive; rank 0) -------------------
+    if rank == 0 and not args.no_handle_leg:
+        result["handle_api"] = handle_api_leg(wm, L, lib, ctx, check, rgb[0], W, H, K, args.precision)
+
+    # ---- CPU baseline: the oracle (faithful mode) on a bounded sample, on rank 0 (at N > 1 after the timed
+    # region and its closing barrier: the other ranks wait in the final barrier below) -----------------
+    if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as O
-        if alt is not None or serial is not None or timers_off is not None:   # the headline precision's outputs again
+        if alt is not None or serial is not None or timers_off is not None or full is not None:   # the headline precision's outputs again
             measure_cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1,
                                    L.PRECISION_F64 if args.precision == "f64" else L.PRECISION_F32)
             check(lib.ssw_batch_embed(ctx.handle, C.byref(measure_cfg), rgb.data_ptr(), B, W, H, marks.data_ptr(), K,
@@ -579,18 +761,21 @@ def main():
         counts = {min(16, n_cores, cap), min(max(n_cores // 4, 1), cap)}
         if args.cpu_all_cores:
             counts.add(min(n_cores, cap))
+        if world > 1:                                  # the other ranks are waiting: the single-thread figure only
+            counts = set()
         for n_thr in sorted(counts):
             t0 = time.perf_counter()
             with cf.ThreadPoolExecutor(n_thr) as ex:
                 list(ex.map(one, range(n_thr)))
             par_s = time.perf_counter() - t0
             sweep.append({"threads": n_thr, "value": round(n_thr * W * H / 1e6 / par_s, 4), "seconds": round(par_s, 1)})
-        best = max(sweep, key=lambda e: e["value"])
-        result["cpu_baseline_parallel"] = {
-            "value": best["value"], "unit": "Mpix/s", "cores": best["threads"], "kind": "port",
-            "sample": f"{best['threads']} frames {W}x{H}, one per thread, same faithful pipeline, {best['seconds']} s; "
-                      f"host has {n_cores} logical cores", "sweep": sweep,
-        }
+        if sweep:
+            best = max(sweep, key=lambda e: e["value"])
+            result["cpu_baseline_parallel"] = {
+                "value": best["value"], "unit": "Mpix/s", "cores": best["threads"], "kind": "port",
+                "sample": f"{best['threads']} frames {W}x{H}, one per thread, same faithful pipeline, {best['seconds']} s; "
+                          f"host has {n_cores} logical cores", "sweep": sweep,
+            }
         # untimed: the oracle's correctly rounded (f64-backend) pipeline = what the canonical precision must equal,
         # on the first and the last frame of the batch (the last one sits in the last chunk of the pipeline)
         gpu_ext = extracted.cpu().numpy()
@@ -613,6 +798,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
+        dist.barrier()                       # rank 0 arrives after its host-side legs
         dist.close()
     ctx.close()
 

@@ -111,8 +111,14 @@ int ssw_ctx_synchronize(ssw_ctx* ctx);
          (ssw_ctx_set_stream);
      (2) treat outputs as valid only after ssw_ctx_synchronize(), or after an event recorded with
          ssw_ctx_record_event() has completed, or in later work on the stream given to ssw_ctx_set_stream.
-   Entry points that take HOST buffers (the Writer / Reader / Tester handles, ssw_copy_*) synchronise
-   before they return.  Calls change the calling thread's current HIP device only for their duration. */
+   Entry points that take HOST buffers (the Writer / Reader / Tester handles, ssw_copy_*) return when the
+   caller's buffers are theirs again: inputs have been read (staged or DMA'd), outputs are complete.  The
+   device work a handle constructor started may still be running -- it is ordered before every later call
+   on the same context, and a failure of it is reported by the next call that waits for the device.
+   Calls change the calling thread's current HIP device only for their duration.
+   One exception to "only enqueues": ssw_batch_extract* with pruning on (the default) waits once for the
+   device at its end (see ssw_ctx_set_prune); while the context's stream is being captured into a graph it
+   takes the full transform instead and does not wait. */
 /* hipStream_t the context currently enqueues on, as an opaque pointer. */
 void* ssw_ctx_stream(ssw_ctx* ctx);
 /* Enqueue on the caller's hipStream_t from now on (NULL: back to the private stream).  Synchronises the
@@ -205,6 +211,28 @@ int ssw_dev_free(ssw_ctx* ctx, void* dev_ptr);
 int ssw_copy_to_dev(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
 int ssw_copy_to_host(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
 
+/* Host <-> device transfers of the host-buffer entry points.  A pinned host buffer (ssw_host_alloc,
+   hipHostMalloc, hipHostRegister) is the DMA source / target itself; any other buffer goes through a ring
+   of pinned staging buffers in the context, filled / drained by a few host threads while the DMA of the
+   previous slice runs (csrc/transfer.hip).  The reference has no counterpart: its images never leave the
+   CPU (`DynamicImage` in, `DynamicImage` out, src/algorithm.rs:295, :355). */
+int ssw_host_alloc(ssw_ctx* ctx, size_t bytes, void** host_ptr);      /* pinned (page-locked) host memory */
+int ssw_host_free(ssw_ctx* ctx, void* host_ptr);
+/* Host threads (the caller's included) that copy between pageable buffers and the staging ring:
+   0 = automatic (4, or half the cores if fewer; environment: SSW_COPY_THREADS), 1 = the caller's only. */
+int ssw_ctx_set_copy_threads(ssw_ctx* ctx, int threads);
+typedef enum ssw_transfer_stat {
+    SSW_TRANSFER_H2D_BYTES = 0,       /* bytes uploaded by host-buffer entry points                  */
+    SSW_TRANSFER_D2H_BYTES = 1,
+    SSW_TRANSFER_H2D_SECONDS = 2,     /* host wall time inside uploads (staging copy + DMA issue)    */
+    SSW_TRANSFER_D2H_SECONDS = 3,     /* host wall time inside downloads (incl. waiting for results) */
+    SSW_TRANSFER_STAGED_BYTES = 4,    /* of the above, bytes that went through the staging ring      */
+    SSW_TRANSFER_DIRECT_BYTES = 5,    /* ... and bytes DMA'd straight from / to pinned caller memory */
+    SSW_TRANSFER_STAT_COUNT = 6
+} ssw_transfer_stat;
+/* Copies the counters (array of SSW_TRANSFER_STAT_COUNT doubles; may be NULL) and optionally zeroes them. */
+int ssw_ctx_get_transfer_stats(ssw_ctx* ctx, double* stats, int reset);
+
 /* ---- transforms (device-resident, batched) --------------------------------- */
 
 /* From<&Rgb32FImage> for YIQ32FImage, src/yiq.rs:177-186.  rgb: [n][h][w][3] f32.
@@ -295,6 +323,11 @@ int ssw_batch_extract_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* d
    consumed, :396). */
 int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
                       const ssw_config* cfg, ssw_writer** out);
+/* Writer::new on an 8-bit image: `image.into_rgb32f()` (src/algorithm.rs:308; v / 255) happens on the
+   device, fused into the colour conversion, and 3 instead of 12 bytes per pixel cross PCIe.  rgb_hwc:
+   host [h][w][3] u8.  Bit-identical to ssw_writer_create on the host-converted frame. */
+int ssw_writer_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_t h,
+                           const ssw_config* cfg, ssw_writer** out);
 /* Writer::coefficient_image(), src/algorithm.rs:319-321 -> host [h][w]. */
 int ssw_writer_coefficients(ssw_writer* wr, float* out_plane);
 /* Writer::embed(&mut self, marks), src/algorithm.rs:348-352.  marks[m] has lens[m] floats (host).
@@ -306,12 +339,21 @@ int ssw_writer_result(ssw_writer* wr, float* out_rgb_hwc);
 /* Writer::mark(self, marks), src/algorithm.rs:355-358 = embed + result. */
 int ssw_writer_mark(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks,
                     float* out_rgb_hwc);
+/* Writer::result(self).into_rgb8() / Writer::mark(self, marks).into_rgb8() (src/algorithm.rs:355-379 followed
+   by the caller's `into_rgb8()`, examples/main.rs:271-278, tests/single_simple.rs:28): round(clamp(v,0,1)*255)
+   in the epilogue of the last inverse pass -> host [h][w][3] u8.  Works on writers created from f32 or u8. */
+int ssw_writer_result_rgb8(ssw_writer* wr, uint8_t* out_rgb_hwc);
+int ssw_writer_mark_rgb8(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks,
+                         uint8_t* out_rgb_hwc);
 int ssw_writer_destroy(ssw_writer* wr);
 
 /* Reader::base(image, config) when is_base != 0 (src/algorithm.rs:462-464), else
    Reader::derived / ReaderDerived::new (:453-455, :469-471); cfg may be NULL for a derived reader. */
 int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, int is_base,
                       const ssw_config* cfg, ssw_reader** out);
+/* The same on an 8-bit image (`into_rgb32f()`, src/algorithm.rs:476, on the device); host [h][w][3] u8. */
+int ssw_reader_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_t h, int is_base,
+                           const ssw_config* cfg, ssw_reader** out);
 /* Reader::coefficients(), src/algorithm.rs:502-504 -> host [h*w]. */
 int ssw_reader_coefficients(ssw_reader* rd, float* out_plane);
 /* Reader::indices(), src/algorithm.rs:506-508: first k entries (k <= w*h-1) as u64 (`usize`). */

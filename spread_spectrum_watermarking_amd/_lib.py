@@ -27,6 +27,7 @@ PRECISION_F32, PRECISION_F64 = 0, 1
 STAGES = ["rgb_to_yiq", "dct_row", "dct_col", "select", "embed", "extract", "similarity", "yiq_to_rgb",
           "resize", "convert", "dct_prep", "dct_row_main", "dct_col_main"]
 DCT_FOLDING_DEFAULT = 5
+TRANSFER_STATS = ["h2d_bytes", "d2h_bytes", "h2d_seconds", "d2h_seconds", "staged_bytes", "direct_bytes"]
 
 
 class Config(C.Structure):
@@ -64,6 +65,10 @@ SIGNATURES = {
     "ssw_dev_free": (C.c_int, [_vp, _vp]),
     "ssw_copy_to_dev": (C.c_int, [_vp, _vp, _vp, _sz]),
     "ssw_copy_to_host": (C.c_int, [_vp, _vp, _vp, _sz]),
+    "ssw_host_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
+    "ssw_host_free": (C.c_int, [_vp, _vp]),
+    "ssw_ctx_set_copy_threads": (C.c_int, [_vp, C.c_int]),
+    "ssw_ctx_get_transfer_stats": (C.c_int, [_vp, C.POINTER(C.c_double), C.c_int]),
     "ssw_rgb_to_yiq": (C.c_int, [_vp, _f32p, _sz, _sz, _sz, _f32p, _f32p, _f32p]),
     "ssw_yiq_to_rgb": (C.c_int, [_vp, _f32p, _f32p, _f32p, _sz, _sz, _sz, _f32p]),
     "ssw_dct2d": (C.c_int, [_vp, C.c_int, C.c_int, _sz, _sz, _sz, _f32p]),
@@ -80,12 +85,16 @@ SIGNATURES = {
     "ssw_batch_embed_rgb8": (C.c_int, [_vp, _cfgp, _vp, _sz, _sz, _sz, _f32p, _sz, _vp]),
     "ssw_batch_extract_rgb8": (C.c_int, [_vp, _cfgp, _vp, _vp, _sz, _sz, _sz, _sz, _f32p, _f32p, _f32p]),
     "ssw_writer_create": (C.c_int, [_vp, _vp, _sz, _sz, _cfgp, C.POINTER(_vp)]),
+    "ssw_writer_create_rgb8": (C.c_int, [_vp, _vp, _sz, _sz, _cfgp, C.POINTER(_vp)]),
     "ssw_writer_coefficients": (C.c_int, [_vp, _vp]),
     "ssw_writer_embed": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz]),
     "ssw_writer_result": (C.c_int, [_vp, _vp]),
     "ssw_writer_mark": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp]),
+    "ssw_writer_result_rgb8": (C.c_int, [_vp, _vp]),
+    "ssw_writer_mark_rgb8": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz, _vp]),
     "ssw_writer_destroy": (C.c_int, [_vp]),
     "ssw_reader_create": (C.c_int, [_vp, _vp, _sz, _sz, C.c_int, _cfgp, C.POINTER(_vp)]),
+    "ssw_reader_create_rgb8": (C.c_int, [_vp, _vp, _sz, _sz, C.c_int, _cfgp, C.POINTER(_vp)]),
     "ssw_reader_coefficients": (C.c_int, [_vp, _vp]),
     "ssw_reader_indices": (C.c_int, [_vp, _sz, _vp]),
     "ssw_reader_extract": (C.c_int, [_vp, _vp, _vp, _sz]),

@@ -10,7 +10,8 @@ Same names, argument meaning and error behaviour as the Rust reference
   Tester / Similarity                      src/algorithm.rs:668-715
 
 Images are numpy arrays [H, W, 3]: float32 in [0, 1] (what `into_rgb32f()` yields,
-algorithm.rs:308) or uint8 (converted with v / 255 like the image crate does).
+algorithm.rs:308) or uint8 (handed to the library as they are: `into_rgb32f()`, v / 255 like the
+image crate does, runs on the device and 3 instead of 12 bytes per pixel cross PCIe).
 Where the reference panics, an SswError is raised.  All arithmetic runs on the
 GPU through libssw_hip.so; there is no CPU path in this package.
 """
@@ -106,6 +107,25 @@ class Context:
         check(self._lib.ssw_ctx_get_prune_stats(self.handle, st), "ssw_ctx_get_prune_stats")
         return {"pruned_chunks": int(st[0]), "redone_chunks": int(st[1]), "columns_needed": int(st[2])}
 
+    def set_copy_threads(self, n: int = 0):
+        """Host threads that move pageable buffers through the pinned staging ring (0 = automatic)."""
+        check(self._lib.ssw_ctx_set_copy_threads(self.handle, int(n)), "ssw_ctx_set_copy_threads")
+
+    def transfer_stats(self, reset: bool = False) -> dict:
+        """Bytes / host seconds of the host-buffer entry points' uploads and downloads (include/ssw.h)."""
+        st = (C.c_double * len(L.TRANSFER_STATS))()
+        check(self._lib.ssw_ctx_get_transfer_stats(self.handle, st, int(reset)), "ssw_ctx_get_transfer_stats")
+        return {n: float(st[i]) for i, n in enumerate(L.TRANSFER_STATS)}
+
+    def pinned_empty(self, shape, dtype) -> np.ndarray:
+        """numpy array in pinned (page-locked) host memory: the handles DMA straight from / into it.
+        The memory belongs to the context and is released when the array (and its views) are gone."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        check(self._lib.ssw_host_alloc(self.handle, n, C.byref(p)), "ssw_host_alloc")
+        return np.asarray(_PinnedBlock(self, p, n))[:n].view(dt).reshape(shape)
+
     def mem_info(self):
         free, total = C.c_size_t(), C.c_size_t()
         check(self._lib.ssw_dev_mem_info(self.handle, C.byref(free), C.byref(total)), "ssw_dev_mem_info")
@@ -120,6 +140,23 @@ class Context:
         buf = DeviceBuffer(self, a.nbytes)
         check(self._lib.ssw_copy_to_dev(self.handle, buf.ptr, a.ctypes.data, a.nbytes), "ssw_copy_to_dev")
         return buf
+
+
+class _PinnedBlock:
+    """Owner of one ssw_host_alloc block, exposed to numpy through __array_interface__: arrays made from it
+    (and their views) keep it alive, the block is released with the last of them."""
+
+    def __init__(self, ctx: Context, ptr, nbytes: int):
+        self.ctx, self.ptr, self.nbytes = ctx, ptr, nbytes
+        self.__array_interface__ = {"data": (int(ptr.value), False), "shape": (max(nbytes, 1),), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                self.ctx._lib.ssw_host_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+        except Exception:
+            pass
 
 
 class DeviceBuffer:
@@ -227,15 +264,16 @@ class ReadConfig:
         return L.Config(self.ordering.tag, self.extraction.tag, self.extraction.alpha, self.precision)
 
 
-def _as_rgb32f(image) -> np.ndarray:
-    """`DynamicImage::into_rgb32f()` (algorithm.rs:308, :476): u8 -> v/255, f32 -> as is."""
+def _as_rgb(image) -> np.ndarray:
+    """What crosses the C ABI for a `DynamicImage`: 8-bit images as they are (`into_rgb32f()`, algorithm.rs:308,
+    :476, then runs on the device: v / 255), everything else as f32 (u16 -> v / 65535 on the host)."""
     a = np.asarray(image)
     if a.ndim != 3 or a.shape[2] not in (3, 4):
         raise ValueError("image must be [H, W, 3] (or RGBA [H, W, 4])")
     a = a[:, :, :3]
     if a.dtype == np.uint8:
-        a = a.astype(np.float32) / np.float32(255)
-    elif a.dtype == np.uint16:
+        return np.ascontiguousarray(a)
+    if a.dtype == np.uint16:
         a = a.astype(np.float32) / np.float32(65535)
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -289,12 +327,12 @@ class Writer:
         self._ctx = ctx or default_context()
         self._lib = self._ctx._lib
         config = config or WriteConfig.default()
-        rgb = _as_rgb32f(image)
+        rgb = _as_rgb(image)
         self.height, self.width = rgb.shape[:2]
         h = C.c_void_p()
         cfg = config._c()
-        check(self._lib.ssw_writer_create(self._ctx.handle, rgb.ctypes.data, self.width, self.height,
-                                          C.byref(cfg), C.byref(h)), "Writer::new")
+        create = self._lib.ssw_writer_create_rgb8 if rgb.dtype == np.uint8 else self._lib.ssw_writer_create
+        check(create(self._ctx.handle, rgb.ctypes.data, self.width, self.height, C.byref(cfg), C.byref(h)), "Writer::new")
         self._h = h
 
     new = classmethod(lambda cls, image, config=None, ctx=None: cls(image, config, ctx))
@@ -308,15 +346,37 @@ class Writer:
         arrs, ptrs, lens = _marks_c(marks)
         check(self._lib.ssw_writer_embed(self._h, ptrs, lens, len(arrs)), "Writer::embed")
 
-    def result(self) -> np.ndarray:
-        out = np.empty((self.height, self.width, 3), np.float32)
+    def _out(self, out, dtype):
+        if out is None:
+            return np.empty((self.height, self.width, 3), dtype)
+        if out.dtype != dtype or out.shape != (self.height, self.width, 3) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a contiguous {np.dtype(dtype).name} array [H, W, 3]")
+        return out
+
+    def result(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Writer::result (algorithm.rs:361-379) -> f32 [H, W, 3]."""
+        out = self._out(out, np.float32)
         check(self._lib.ssw_writer_result(self._h, out.ctypes.data), "Writer::result")
         return out
 
-    def mark(self, marks) -> np.ndarray:
+    def result_rgb8(self, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """`writer.result().into_rgb8()`: quantised on the device, u8 [H, W, 3]."""
+        out = self._out(out, np.uint8)
+        check(self._lib.ssw_writer_result_rgb8(self._h, out.ctypes.data), "Writer::result")
+        return out
+
+    def mark(self, marks, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Writer::mark (algorithm.rs:355-358) -> f32 [H, W, 3]."""
         arrs, ptrs, lens = _marks_c(marks)
-        out = np.empty((self.height, self.width, 3), np.float32)
+        out = self._out(out, np.float32)
         check(self._lib.ssw_writer_mark(self._h, ptrs, lens, len(arrs), out.ctypes.data), "Writer::mark")
+        return out
+
+    def mark_rgb8(self, marks, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """`writer.mark(marks).into_rgb8()` (examples/main.rs:271-278): u8 [H, W, 3]."""
+        arrs, ptrs, lens = _marks_c(marks)
+        out = self._out(out, np.uint8)
+        check(self._lib.ssw_writer_mark_rgb8(self._h, ptrs, lens, len(arrs), out.ctypes.data), "Writer::mark")
         return out
 
     def __del__(self):
@@ -333,13 +393,14 @@ class Reader:
     def __init__(self, image, is_base: bool, config: Optional[ReadConfig], ctx: Optional[Context] = None):
         self._ctx = ctx or default_context()
         self._lib = self._ctx._lib
-        rgb = _as_rgb32f(image)
+        rgb = _as_rgb(image)
         self.height, self.width = rgb.shape[:2]
         self.is_base = is_base
         h = C.c_void_p()
         cfg = config._c() if config is not None else None
-        check(self._lib.ssw_reader_create(self._ctx.handle, rgb.ctypes.data, self.width, self.height, int(is_base),
-                                          C.byref(cfg) if cfg is not None else None, C.byref(h)), "Reader::new_impl")
+        create = self._lib.ssw_reader_create_rgb8 if rgb.dtype == np.uint8 else self._lib.ssw_reader_create
+        check(create(self._ctx.handle, rgb.ctypes.data, self.width, self.height, int(is_base),
+                     C.byref(cfg) if cfg is not None else None, C.byref(h)), "Reader::new_impl")
         self._h = h
 
     @staticmethod

@@ -11,6 +11,7 @@
 // "unpinned" (only the similarity thresholds of the reference's tests pin it).
 //
 // All kernels are HBM-bound streaming kernels; u8 frames cut the boundary traffic from 12 to 3 B/px.
+#include <atomic>
 #include <cmath>
 #include <vector>
 
@@ -521,14 +522,14 @@ int launch_resize_rgb8(hipStream_t st, const uint8_t* in, size_t n_frames, size_
     if (resize_can_fuse(in, n_frames, w, h, nw, nh, vt, ht, out, &tl, &lds)) {
         const dim3 grid(tl.tiles_x * tl.tiles_y, (unsigned)n_frames);
         {   // tiles above 64 KB of dynamic LDS need the per-device function attribute: set it once per device
-            static bool attr_set[64] = {false};
+            static std::atomic<bool> attr_set[64];           // two host threads, two contexts: no plain bools
             int dev = 0;
             SSW_HIP_CHECK(hipGetDevice(&dev));
-            if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
                 SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_fused_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
                 SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_fused_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
                 SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_fused_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-                if (dev >= 0 && dev < 64) attr_set[dev] = true;
+                if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
             }
         }
 #define SSW_RESIZE_FUSED(MODE) resize_fused_kernel<MODE><<<grid, 256, lds, st>>>(in, out, (unsigned)w, (unsigned)h, (unsigned)nw, (unsigned)nh, \

@@ -34,6 +34,14 @@ void release(ssw_ctx::Buf& b);
 int grow_select(hipStream_t st, SelectWorkspace& s, size_t frames, size_t k);
 void release_select(SelectWorkspace& s);
 
+// transfer.hip: host buffers <-> device on `st`.  upload() returns once the caller's buffer may be reused
+// (the data reaches the device in stream order), download() once the caller's buffer is complete.
+int upload(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes, hipStream_t st);
+int download(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hipStream_t st);
+void transfer_destroy(ssw_ctx* ctx);
+int transfer_set_threads(ssw_ctx* ctx, int threads);
+int transfer_stats(ssw_ctx* ctx, double* out, bool reset);
+
 // Stage timer: an event pair around a region on `st`, plus the work the region does (executed flop of the
 // GEMM stages, algorithmic bytes of the HBM-bound ones) -- both only while timing is enabled.
 struct StageTimer {

@@ -197,6 +197,8 @@ int launch_widen_indices(hipStream_t st, const uint32_t* in, size_t n, uint64_t*
 
 }  // namespace ssw
 
+namespace ssw { namespace host { struct Transfer; } }
+
 // ---- context ----------------------------------------------------------------
 struct ssw_ctx {
     int device = 0;
@@ -240,6 +242,22 @@ struct ssw_ctx {
     Buf overflow;                         // [chunks] u32 flags of the pruned path (+ class counts)
     uint64_t pruned_chunks = 0, redone_chunks = 0;
     uint64_t pruned_columns = 0;          // sum over pruned chunks of the compact plane width (cap_total)
+    // single-image handles (ssw_lib.hip): frames cross PCIe on `copy_stream` into / out of two alternating
+    // device staging buffers, so the upload of the next frame runs beside the kernels of the previous one
+    hipStream_t copy_stream = nullptr;
+    struct FrameStage {
+        Buf buf;
+        hipEvent_t uploaded = nullptr;    // copy_stream: the frame is in the buffer
+        hipEvent_t consumed = nullptr;    // stream: the last kernel that reads (or writes) the buffer is enqueued before
+        bool in_use = false;              // `consumed` has been recorded at least once
+    };
+    FrameStage frame_stage[2];
+    unsigned frame_stage_next = 0;
+    // device planes of destroyed handles, kept for the next handle of the same size (hipMalloc + hipFree of
+    // three 4K planes cost more than the transform); all reuse is ordered on the context's stream
+    std::multimap<size_t, void*> plane_pool;
+    size_t plane_pool_bytes = 0;
+    ssw::host::Transfer* xfer = nullptr;  // pinned staging ring + copy threads (transfer.hip)
     Buf small;                    // misc (mark offsets, sims, ...)
     Buf sort_scratch;             // full-order sort (lazy, Reader::indices beyond the top-k limit)
     Buf resize_tmp;               // f32 intermediate of the resize's vertical pass

@@ -30,6 +30,10 @@ struct ssw_writer {
     uint32_t* idx = nullptr;
     size_t idx_k = 0;
     bool consumed = false;
+    // host staging of embed(): lives as long as the handle, so the copies need no host synchronisation
+    std::vector<float> packed;
+    std::vector<uint32_t> offs, lns;
+    bool staging_in_flight = false;
 };
 struct ssw_reader {
     ssw_ctx* ctx;
@@ -45,6 +49,80 @@ namespace {
 // handles and single-call entry points: lane 0's workspace, the context's stream
 int topk0(ssw_ctx* ctx, const float* coef, size_t n, size_t w, size_t h, int ordering, size_t k, uint32_t* idx) {
     return topk(ctx, ctx->stream, ctx->lane[0].sel, coef, n, w, h, ordering, k, idx);
+}
+
+// ---- device planes of the handles: a size-keyed pool in the context ---------------------------
+size_t plane_pool_cap() {
+    static const size_t cap = [] {
+        const char* e = std::getenv("SSW_PLANE_POOL_MB");
+        return (e ? (size_t)std::atoll(e) : (size_t)4096) << 20;
+    }();
+    return cap;
+}
+int pool_get(ssw_ctx* ctx, size_t bytes, void** p) {
+    bytes = (std::max<size_t>(bytes, 16) + 255) / 256 * 256;
+    auto it = ctx->plane_pool.find(bytes);
+    if (it != ctx->plane_pool.end()) {
+        *p = it->second;
+        ctx->plane_pool.erase(it);
+        ctx->plane_pool_bytes -= bytes;
+        return SSW_OK;
+    }
+    int rc = dev_malloc(p, bytes);
+    if (rc == SSW_OK || ctx->plane_pool.empty()) return rc;
+    for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);        // out of memory: give the pool back first
+    ctx->plane_pool.clear();
+    ctx->plane_pool_bytes = 0;
+    return dev_malloc(p, bytes);
+}
+// Every use of a handle's plane was enqueued on the context's stream, and so is every later use by the next
+// owner: no synchronisation.  (ssw_ctx_set_stream synchronises the stream it leaves.)
+void pool_put(ssw_ctx* ctx, void* p, size_t bytes) {
+    if (!p) return;
+    bytes = (std::max<size_t>(bytes, 16) + 255) / 256 * 256;
+    if (ctx->plane_pool_bytes + bytes > plane_pool_cap()) { (void)hipFree(p); return; }
+    ctx->plane_pool.emplace(bytes, p);
+    ctx->plane_pool_bytes += bytes;
+}
+
+// ---- frames in and out of the device ------------------------------------------------------------
+int frame_stage_events(ssw_ctx::FrameStage& fs) {
+    if (!fs.uploaded) SSW_HIP_CHECK(hipEventCreateWithFlags(&fs.uploaded, hipEventDisableTiming));
+    if (!fs.consumed) SSW_HIP_CHECK(hipEventCreateWithFlags(&fs.consumed, hipEventDisableTiming));
+    return SSW_OK;
+}
+// Host frame -> the next device staging buffer, on the copy stream (beside whatever the context's stream is
+// still computing for an earlier handle); the context's stream waits for it.
+int stage_frame_in(ssw_ctx* ctx, const void* host, size_t bytes, ssw_ctx::FrameStage** out) {
+    ssw_ctx::FrameStage& fs = ctx->frame_stage[ctx->frame_stage_next++ & 1];
+    SSW_TRY(frame_stage_events(fs));
+    SSW_TRY(grow(fs.buf, bytes));
+    if (fs.in_use) SSW_HIP_CHECK(hipStreamWaitEvent(ctx->copy_stream, fs.consumed, 0));
+    SSW_TRY(upload(ctx, fs.buf.p, host, bytes, ctx->copy_stream));
+    SSW_HIP_CHECK(hipEventRecord(fs.uploaded, ctx->copy_stream));
+    SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, fs.uploaded, 0));
+    *out = &fs;
+    return SSW_OK;
+}
+int stage_consumed(ssw_ctx* ctx, ssw_ctx::FrameStage& fs) {
+    SSW_HIP_CHECK(hipEventRecord(fs.consumed, ctx->stream));
+    fs.in_use = true;
+    return SSW_OK;
+}
+
+// Writer::new / Reader::new_impl up to the coefficients (:308-313, :476-480): host frame (f32 or 8-bit) -> Y
+// (+ I, Q) -> forward transform, through the same fused chain as the batch entry points (n = 1).  Enqueues only.
+int forward_from_host(ssw_ctx* ctx, const void* host_rgb, bool u8, size_t w, size_t h, int precision, float* y, float* i,
+                      float* q) {
+    const size_t plane = w * h;
+    SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
+    ssw_ctx::FrameStage* fs = nullptr;
+    SSW_TRY(stage_frame_in(ctx, host_rgb, plane * 3 * (u8 ? 1 : sizeof(float)), &fs));
+    Chain ch;
+    SSW_TRY(build_forward_from_rgb(ctx, ctx->lane[0], precision, fs->buf.p, u8, 1, w, h, y, i, q,
+                                   (float*)ctx->lane[0].plane[3].p, ch));
+    SSW_TRY(run_serial(ch, ctx->stream));
+    return stage_consumed(ctx, *fs);
 }
 }  // namespace
 
@@ -89,7 +167,7 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
         return SSW_ERR_NO_DEVICE;
     }
     if (device_id < 0 || device_id >= count) return SSW_ERR_BAD_ARG;
-    SSW_HIP_CHECK(hipSetDevice(device_id));
+    DeviceGuard g(device_id);                // the caller's current device is restored on return
     ssw_ctx* ctx = new (std::nothrow) ssw_ctx();
     if (!ctx) return SSW_ERR_OUT_OF_MEMORY;
     ctx->device = device_id;
@@ -103,6 +181,12 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
     // Stream priorities (either way round) change nothing either.
     e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; set_last_error(hipGetErrorString(e)); return SSW_ERR_HIP; }
+    // frames of the single-image handles cross PCIe here, beside the kernels of the previous handle
+    e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->aux_stream); (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx; set_last_error(hipGetErrorString(e)); return SSW_ERR_HIP;
+    }
     const char* ov = std::getenv("SSW_OVERLAP");
     if (ov) ctx->overlap = std::atoi(ov) != 0;
     const char* pr = std::getenv("SSW_PRUNE");
@@ -116,6 +200,14 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     DeviceGuard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    transfer_destroy(ctx);
+    for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);
+    for (auto& fs : ctx->frame_stage) {
+        release(fs.buf);
+        if (fs.uploaded) (void)hipEventDestroy(fs.uploaded);
+        if (fs.consumed) (void)hipEventDestroy(fs.consumed);
+    }
     for (auto& kv : ctx->basis) (void)hipFree(kv.second);
     for (auto& ln : ctx->lane) {
         for (auto& b : ln.plane) release(b);
@@ -135,6 +227,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     for (auto& p : ctx->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SSW_OK;
@@ -269,16 +362,42 @@ int ssw_dev_free(ssw_ctx* ctx, void* dev_ptr) {
 int ssw_copy_to_dev(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
     if (!ctx || (bytes && (!dev_dst || !host_src))) return SSW_ERR_BAD_ARG;
     DeviceGuard g(ctx->device);
-    SSW_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SSW_TRY(upload(ctx, dev_dst, host_src, bytes, ctx->stream));
     SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SSW_OK;
 }
 int ssw_copy_to_host(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
     if (!ctx || (bytes && (!host_dst || !dev_src))) return SSW_ERR_BAD_ARG;
     DeviceGuard g(ctx->device);
-    SSW_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return download(ctx, host_dst, dev_src, bytes, ctx->stream);
+}
+
+int ssw_host_alloc(ssw_ctx* ctx, size_t bytes, void** host_ptr) {
+    if (!ctx || !host_ptr) return SSW_ERR_BAD_ARG;
+    *host_ptr = nullptr;
+    DeviceGuard g(ctx->device);
+    const hipError_t e = hipHostMalloc(host_ptr, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *host_ptr = nullptr;
+        set_last_error(std::string("hipHostMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
+        return SSW_ERR_OUT_OF_MEMORY;
+    }
     return SSW_OK;
+}
+int ssw_host_free(ssw_ctx* ctx, void* host_ptr) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(ctx->device);
+    if (host_ptr) SSW_HIP_CHECK(hipHostFree(host_ptr));
+    return SSW_OK;
+}
+int ssw_ctx_set_copy_threads(ssw_ctx* ctx, int threads) {
+    if (!ctx || threads < 0) return SSW_ERR_BAD_ARG;
+    return transfer_set_threads(ctx, threads);
+}
+int ssw_ctx_get_transfer_stats(ssw_ctx* ctx, double* stats, int reset) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    return transfer_stats(ctx, stats, reset != 0);
 }
 
 // ---- transforms -----------------------------------------------------------------------------
@@ -392,12 +511,20 @@ int get_taps(ssw_ctx* ctx, size_t in_len, size_t out_len, DeviceTaps* out) {
     d.quad_uniform = out_len % 4 == 0;
     for (size_t o = 0; o < out_len && d.quad_uniform; ++o)
         d.quad_uniform = host.count[o] <= 5 && host.left[o] == host.left[o & ~(size_t)3] && host.count[o] == host.count[o & ~(size_t)3];
-    SSW_ALLOC(&d.left, out_len * sizeof(uint32_t));
-    SSW_ALLOC(&d.count, out_len * sizeof(uint32_t));
-    SSW_ALLOC(&d.weights, host.weights.size() * sizeof(float));
-    SSW_HIP_CHECK(hipMemcpy(d.left, host.left.data(), out_len * sizeof(uint32_t), hipMemcpyHostToDevice));
-    SSW_HIP_CHECK(hipMemcpy(d.count, host.count.data(), out_len * sizeof(uint32_t), hipMemcpyHostToDevice));
-    SSW_HIP_CHECK(hipMemcpy(d.weights, host.weights.data(), host.weights.size() * sizeof(float), hipMemcpyHostToDevice));
+    // uploaded on the context's stream (the one the resize kernels run on); the host vectors die with this call
+    auto put = [&](void** dev, const void* host, size_t bytes) -> int {
+        SSW_ALLOC(dev, bytes);
+        SSW_HIP_CHECK(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return SSW_OK;
+    };
+    int rc = put((void**)&d.left, host.left.data(), out_len * sizeof(uint32_t));
+    if (rc == SSW_OK) rc = put((void**)&d.count, host.count.data(), out_len * sizeof(uint32_t));
+    if (rc == SSW_OK) rc = put((void**)&d.weights, host.weights.data(), host.weights.size() * sizeof(float));
+    if (rc == SSW_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SSW_ERR_HIP;
+    if (rc != SSW_OK) {                                   // nothing of a half-built table stays behind
+        (void)hipFree(d.left); (void)hipFree(d.count); (void)hipFree(d.weights);
+        return rc;
+    }
     ctx->taps[key] = d;
     *out = d;
     return SSW_OK;
@@ -471,8 +598,8 @@ int ssw_resize_rgb8(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_frames, size_t
 }
 
 // ---- Writer ---------------------------------------------------------------------------------
-int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
-                      const ssw_config* cfg, ssw_writer** out) {
+static int writer_create_impl(ssw_ctx* ctx, const void* rgb_hwc, bool u8, size_t w, size_t h, const ssw_config* cfg,
+                              ssw_writer** out) {
     if (!ctx || !rgb_hwc || !out) return SSW_ERR_BAD_ARG;
     *out = nullptr;
     SSW_TRY(check_config(cfg));
@@ -483,24 +610,23 @@ int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
     if (!wr) return SSW_ERR_OUT_OF_MEMORY;
     wr->ctx = ctx; wr->w = w; wr->h = h; wr->cfg = *cfg;
     auto fail = [&](int rc) { ssw_writer_destroy(wr); return rc; };
-    if (dev_malloc((void**)&wr->y, plane * 4) != SSW_OK || dev_malloc((void**)&wr->i, plane * 4) != SSW_OK ||
-        dev_malloc((void**)&wr->q, plane * 4) != SSW_OK)
+    if (pool_get(ctx, plane * 4, (void**)&wr->y) != SSW_OK || pool_get(ctx, plane * 4, (void**)&wr->i) != SSW_OK ||
+        pool_get(ctx, plane * 4, (void**)&wr->q) != SSW_OK)
         return fail(SSW_ERR_OUT_OF_MEMORY);
-    int rc = grow(ctx->lane[0].plane[3], std::max(plane * 3, plane) * sizeof(float));
+    const int rc = forward_from_host(ctx, rgb_hwc, u8, w, h, cfg->precision, wr->y, wr->i, wr->q);   // :308-313
     if (rc != SSW_OK) return fail(rc);
-    float* stage = (float*)ctx->lane[0].plane[3].p;                          // rgb staging, then DCT scratch
-    if (hipMemcpyAsync(stage, rgb_hwc, plane * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        return fail(SSW_ERR_HIP);
-    {
-        StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, ctx->stream);
-        rc = launch_rgb_to_yiq(ctx->stream, stage, plane, wr->y, wr->i, wr->q);          // :308
-    }
-    if (rc != SSW_OK) return fail(rc);
-    rc = dct2d_planes(ctx, SSW_DCT2, cfg->precision, 1, w, h, wr->y, stage);             // :313
-    if (rc != SSW_OK) return fail(rc);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(SSW_ERR_HIP);
     *out = wr;
     return SSW_OK;
+}
+
+int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
+                      const ssw_config* cfg, ssw_writer** out) {
+    return writer_create_impl(ctx, rgb_hwc, false, w, h, cfg, out);
+}
+
+int ssw_writer_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_t h,
+                           const ssw_config* cfg, ssw_writer** out) {
+    return writer_create_impl(ctx, rgb_hwc, true, w, h, cfg, out);
 }
 
 int ssw_writer_coefficients(ssw_writer* wr, float* out_plane) {
@@ -516,32 +642,41 @@ static int writer_embed_impl(ssw_writer* wr, const float* const* marks, const si
     DeviceGuard g(ctx->device);
     const size_t plane = wr->w * wr->h;
     if (n_marks == 0) return SSW_OK;
+    for (size_t m = 0; m < n_marks; ++m)
+        if (lens[m] && !marks[m]) return SSW_ERR_BAD_ARG;
+    if (wr->staging_in_flight) {                                      // a second embed(): the first one's copies first
+        SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        wr->staging_in_flight = false;
+    }
     // zip(indices, mark) truncates every mark at w*h-1 entries (:396, :402)
-    std::vector<uint32_t> offs(n_marks), lns(n_marks);
+    wr->offs.assign(n_marks, 0);
+    wr->lns.assign(n_marks, 0);
     size_t total = 0, max_len = 0;
     for (size_t m = 0; m < n_marks; ++m) {
-        if (lens[m] && !marks[m]) return SSW_ERR_BAD_ARG;
         const size_t len = std::min(lens[m], plane - 1);
-        offs[m] = (uint32_t)total; lns[m] = (uint32_t)len;
+        wr->offs[m] = (uint32_t)total; wr->lns[m] = (uint32_t)len;
         total += len; max_len = std::max(max_len, len);
     }
     if (max_len == 0) return SSW_OK;
-    std::vector<float> packed(total);
+    wr->packed.resize(total);
     for (size_t m = 0; m < n_marks; ++m)
-        if (lns[m]) std::memcpy(packed.data() + offs[m], marks[m], lns[m] * sizeof(float));
+        if (wr->lns[m]) std::memcpy(wr->packed.data() + wr->offs[m], marks[m], wr->lns[m] * sizeof(float));
     const size_t bytes_marks = (total * 4 + 15) / 16 * 16, bytes_tab = (n_marks * 4 + 15) / 16 * 16;
     SSW_TRY(grow(ctx->small, bytes_marks + 2 * bytes_tab));
     char* base = (char*)ctx->small.p;
-    SSW_HIP_CHECK(hipMemcpyAsync(base, packed.data(), total * 4, hipMemcpyHostToDevice, ctx->stream));
-    SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks, offs.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
-    SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks + bytes_tab, lns.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the host vectors belong to the handle and stay until it is destroyed: no host synchronisation here
+    SSW_HIP_CHECK(hipMemcpyAsync(base, wr->packed.data(), total * 4, hipMemcpyHostToDevice, ctx->stream));
+    SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks, wr->offs.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
+    SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks + bytes_tab, wr->lns.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
+    wr->staging_in_flight = true;
     if (keep_original && !wr->y0) {
-        SSW_ALLOC(&wr->y0, plane * sizeof(float));
+        SSW_TRY(pool_get(ctx, plane * sizeof(float), (void**)&wr->y0));
         SSW_HIP_CHECK(hipMemcpyAsync(wr->y0, wr->y, plane * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (max_len > wr->idx_k) {                                        // :314, from the original coefficients
-        if (wr->idx) { SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream)); SSW_HIP_CHECK(hipFree(wr->idx)); wr->idx = nullptr; wr->idx_k = 0; }
-        SSW_ALLOC(&wr->idx, max_len * sizeof(uint32_t));
+        pool_put(ctx, wr->idx, wr->idx_k * sizeof(uint32_t));
+        wr->idx = nullptr; wr->idx_k = 0;
+        SSW_TRY(pool_get(ctx, max_len * sizeof(uint32_t), (void**)&wr->idx));
         SSW_TRY(topk0(ctx, wr->y0 ? wr->y0 : wr->y, 1, wr->w, wr->h, wr->cfg.ordering, max_len, wr->idx));
         wr->idx_k = max_len;
     }
@@ -551,7 +686,6 @@ static int writer_embed_impl(ssw_writer* wr, const float* const* marks, const si
                              (const uint32_t*)(base + bytes_marks), (const uint32_t*)(base + bytes_marks + bytes_tab),
                              n_marks, max_len, max_len, wr->cfg.method, wr->cfg.alpha));
     }
-    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // host staging vectors die here
     return SSW_OK;
 }
 
@@ -559,47 +693,73 @@ int ssw_writer_embed(ssw_writer* wr, const float* const* marks, const size_t* le
     return writer_embed_impl(wr, marks, lens, n_marks, true);
 }
 
-int ssw_writer_result(ssw_writer* wr, float* out_rgb_hwc) {
+// Writer::result (:361-379): inverse transform with the colour conversion (and into_rgb8) in the epilogue of its last
+// pass where the shape allows, straight into a device staging buffer, then one download.
+static int writer_result_impl(ssw_writer* wr, void* out_rgb_hwc, bool u8_out) {
     if (!wr || !out_rgb_hwc) return SSW_ERR_BAD_ARG;
     if (wr->consumed) return SSW_ERR_CONSUMED;
     ssw_ctx* ctx = wr->ctx;
     DeviceGuard g(ctx->device);
     const size_t plane = wr->w * wr->h;
-    SSW_TRY(grow(ctx->lane[0].plane[3], plane * 3 * sizeof(float)));
-    float* stage = (float*)ctx->lane[0].plane[3].p;
-    SSW_TRY(dct2d_planes(ctx, SSW_DCT3, wr->cfg.precision, 1, wr->w, wr->h, wr->y, stage));      // :368-374
-    {
+    const size_t out_bytes = plane * 3 * (u8_out ? 1 : sizeof(float));
+    SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
+    ssw_ctx::FrameStage& fs = ctx->frame_stage[ctx->frame_stage_next++ & 1];
+    SSW_TRY(frame_stage_events(fs));
+    SSW_TRY(grow(fs.buf, out_bytes));
+    Xform inv{SSW_DCT3, wr->cfg.precision, 1, wr->w, wr->h, wr->y, (float*)ctx->lane[0].plane[3].p};      // :368-374
+    inv.iq_i = wr->i; inv.iq_q = wr->q; inv.rgb_out = fs.buf.p; inv.rgb_out_u8 = u8_out;                 // + :377
+    bool fused_rgb = false;
+    Chain ch;
+    SSW_TRY(build_transform(ctx, ctx->lane[0], inv, ch, &fused_rgb));
+    SSW_TRY(run_serial(ch, ctx->stream));
+    if (!fused_rgb) {
         StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB, ctx->stream);
-        SSW_TRY(launch_yiq_to_rgb(ctx->stream, wr->y, wr->i, wr->q, plane, stage));              // :377
+        if (u8_out) SSW_TRY(launch_yiq_to_rgb8(ctx->stream, wr->y, wr->i, wr->q, plane, (uint8_t*)fs.buf.p));
+        else        SSW_TRY(launch_yiq_to_rgb(ctx->stream, wr->y, wr->i, wr->q, plane, (float*)fs.buf.p));   // :377
     }
-    SSW_HIP_CHECK(hipMemcpyAsync(out_rgb_hwc, stage, plane * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int rc = download(ctx, out_rgb_hwc, fs.buf.p, out_bytes, ctx->stream);
+    SSW_TRY(stage_consumed(ctx, fs));
+    SSW_TRY(rc);
+    wr->staging_in_flight = false;                                    // download() waited for the stream
     wr->consumed = true;                                              // `result(self)` consumes
     return SSW_OK;
 }
 
+int ssw_writer_result(ssw_writer* wr, float* out_rgb_hwc) { return writer_result_impl(wr, out_rgb_hwc, false); }
+int ssw_writer_result_rgb8(ssw_writer* wr, uint8_t* out_rgb_hwc) { return writer_result_impl(wr, out_rgb_hwc, true); }
+
 int ssw_writer_mark(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks,
                     float* out_rgb_hwc) {
+    if (!out_rgb_hwc) return SSW_ERR_BAD_ARG;
     SSW_TRY(writer_embed_impl(wr, marks, lens, n_marks, false));      // :356 (consumed next: no snapshot needed)
-    return ssw_writer_result(wr, out_rgb_hwc);                        // :357
+    return writer_result_impl(wr, out_rgb_hwc, false);                // :357
+}
+
+int ssw_writer_mark_rgb8(ssw_writer* wr, const float* const* marks, const size_t* lens, size_t n_marks,
+                         uint8_t* out_rgb_hwc) {
+    if (!out_rgb_hwc) return SSW_ERR_BAD_ARG;
+    SSW_TRY(writer_embed_impl(wr, marks, lens, n_marks, false));
+    return writer_result_impl(wr, out_rgb_hwc, true);
 }
 
 int ssw_writer_destroy(ssw_writer* wr) {
     if (!wr) return SSW_OK;
-    DeviceGuard g(wr->ctx->device);
-    (void)hipStreamSynchronize(wr->ctx->stream);
-    if (wr->y) (void)hipFree(wr->y);
-    if (wr->i) (void)hipFree(wr->i);
-    if (wr->q) (void)hipFree(wr->q);
-    if (wr->y0) (void)hipFree(wr->y0);
-    if (wr->idx) (void)hipFree(wr->idx);
+    ssw_ctx* ctx = wr->ctx;
+    DeviceGuard g(ctx->device);
+    if (wr->staging_in_flight) (void)hipStreamSynchronize(ctx->stream);     // host vectors of embed() die with the handle
+    const size_t plane = wr->w * wr->h;
+    pool_put(ctx, wr->y, plane * 4);
+    pool_put(ctx, wr->i, plane * 4);
+    pool_put(ctx, wr->q, plane * 4);
+    pool_put(ctx, wr->y0, plane * 4);
+    pool_put(ctx, wr->idx, wr->idx_k * sizeof(uint32_t));
     delete wr;
     return SSW_OK;
 }
 
 // ---- Reader ---------------------------------------------------------------------------------
-int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, int is_base,
-                      const ssw_config* cfg, ssw_reader** out) {
+static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, bool u8, size_t w, size_t h, int is_base,
+                              const ssw_config* cfg, ssw_reader** out) {
     if (!ctx || !rgb_hwc || !out) return SSW_ERR_BAD_ARG;
     *out = nullptr;
     ssw_config c;
@@ -614,22 +774,21 @@ int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, in
     if (!rd) return SSW_ERR_OUT_OF_MEMORY;
     rd->ctx = ctx; rd->w = w; rd->h = h; rd->is_base = is_base != 0; rd->cfg = c;
     auto fail = [&](int rc) { ssw_reader_destroy(rd); return rc; };
-    if (dev_malloc((void**)&rd->y, plane * 4) != SSW_OK) return fail(SSW_ERR_OUT_OF_MEMORY);
-    int rc = grow(ctx->lane[0].plane[3], plane * 3 * sizeof(float));
+    if (pool_get(ctx, plane * 4, (void**)&rd->y) != SSW_OK) return fail(SSW_ERR_OUT_OF_MEMORY);
+    const int rc = forward_from_host(ctx, rgb_hwc, u8, w, h, c.precision, rd->y, nullptr, nullptr);   // :476-480
     if (rc != SSW_OK) return fail(rc);
-    float* stage = (float*)ctx->lane[0].plane[3].p;
-    if (hipMemcpyAsync(stage, rgb_hwc, plane * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        return fail(SSW_ERR_HIP);
-    {
-        StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, ctx->stream);
-        rc = launch_rgb_to_yiq(ctx->stream, stage, plane, rd->y, nullptr, nullptr);      // :476
-    }
-    if (rc != SSW_OK) return fail(rc);
-    rc = dct2d_planes(ctx, SSW_DCT2, c.precision, 1, w, h, rd->y, stage);                // :480
-    if (rc != SSW_OK) return fail(rc);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(SSW_ERR_HIP);
     *out = rd;
     return SSW_OK;
+}
+
+int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, int is_base,
+                      const ssw_config* cfg, ssw_reader** out) {
+    return reader_create_impl(ctx, rgb_hwc, false, w, h, is_base, cfg, out);
+}
+
+int ssw_reader_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_t h, int is_base,
+                           const ssw_config* cfg, ssw_reader** out) {
+    return reader_create_impl(ctx, rgb_hwc, true, w, h, is_base, cfg, out);
 }
 
 int ssw_reader_coefficients(ssw_reader* rd, float* out_plane) {
@@ -642,8 +801,9 @@ static int reader_ensure_indices(ssw_reader* rd, size_t k) {
     if (k > rd->w * rd->h - 1) return SSW_ERR_K_TOO_LARGE;
     if (k <= rd->idx_k) return SSW_OK;
     ssw_ctx* ctx = rd->ctx;
-    if (rd->idx) { SSW_HIP_CHECK(hipFree(rd->idx)); rd->idx = nullptr; rd->idx_k = 0; }
-    SSW_ALLOC(&rd->idx, k * sizeof(uint32_t));
+    pool_put(ctx, rd->idx, rd->idx_k * sizeof(uint32_t));
+    rd->idx = nullptr; rd->idx_k = 0;
+    SSW_TRY(pool_get(ctx, k * sizeof(uint32_t), (void**)&rd->idx));
     SSW_TRY(topk0(ctx, rd->y, 1, rd->w, rd->h, rd->cfg.ordering, k, rd->idx));           // :493
     rd->idx_k = k;
     return SSW_OK;
@@ -683,10 +843,10 @@ int ssw_reader_extract(ssw_reader* base, ssw_reader* derived, float* out, size_t
 
 int ssw_reader_destroy(ssw_reader* rd) {
     if (!rd) return SSW_OK;
-    DeviceGuard g(rd->ctx->device);
-    (void)hipStreamSynchronize(rd->ctx->stream);
-    if (rd->y) (void)hipFree(rd->y);
-    if (rd->idx) (void)hipFree(rd->idx);
+    ssw_ctx* ctx = rd->ctx;
+    DeviceGuard g(ctx->device);
+    pool_put(ctx, rd->y, rd->w * rd->h * 4);
+    pool_put(ctx, rd->idx, rd->idx_k * sizeof(uint32_t));
     delete rd;
     return SSW_OK;
 }

@@ -133,13 +133,40 @@ int check_config(const ssw_config* cfg) {
 // frames, 514 full-HD ones, 32 8K ones -- capped where the f64 operand planes of a pass would pass 4 GB (the
 // operand-ready GEMMs walk them with 32-bit offsets).  The GEMM grids then run ~64 rounds of blocks: against
 // 2^28 pixels (16 rounds, the r1 default) the tails and first-tile latencies weigh 2.8 % less at 4K, 1.8 % at
-// full HD, 1.4 % at 8K.  Workspace: 36 B/px of a pass per lane (38.7 GB), sized for 288 GB of HBM.
+// full HD, 1.4 % at 8K.  Workspace: 36 B/px of a pass per lane (38.7 GB), sized for 288 GB of HBM -- and
+// clamped to half of what the device can give right now (free memory + what the lanes already hold), so that
+// a smaller device or a co-tenant (torch's caching allocator) gets smaller passes instead of an
+// SSW_ERR_OUT_OF_MEMORY.
+namespace {
+size_t lane_bytes_held(const ssw_ctx* ctx) {
+    size_t held = 0;
+    for (const auto& ln : ctx->lane) {
+        for (const auto& b : ln.plane) held += b.bytes;
+        for (const auto& b : ln.operand) held += b.bytes;
+        for (const auto& b : ln.compact) held += b.bytes;
+        held += ln.idx.bytes + ln.gathered.bytes + ln.prune_u32.bytes;
+    }
+    return held;
+}
+}  // namespace
+
 size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames) {
     size_t c = ctx->chunk_frames;
     if (c == 0) {
-        c = std::max<size_t>(1, ((size_t)1 << 30) / std::max<size_t>(w * h, 1));
+        const size_t px = std::max<size_t>(w * h, 1);
+        c = std::max<size_t>(1, ((size_t)1 << 30) / px);
         const size_t per_frame = dct_pair_operand_elems(true, 1, w, h) * sizeof(double);
         if (per_frame) c = std::max<size_t>(1, std::min(c, (size_t)0xFFFFFFFFull / per_frame));
+        c = std::min(c, std::max<size_t>(n_frames, 1));
+        size_t free_b = 0, total_b = 0;
+        DeviceGuard g(ctx->device);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t lanes = (ctx->overlap && n_frames > 2 * c) ? 2 : 1;
+            const size_t budget = (free_b + lane_bytes_held(ctx)) / 2;
+            c = std::max<size_t>(1, std::min(c, budget / (lanes * 36 * px)));
+        } else {
+            (void)hipGetLastError();
+        }
     }
     return std::min(c, std::max<size_t>(n_frames, 1));
 }
@@ -440,13 +467,14 @@ int hop(ssw_ctx* ctx, ssw_ctx::Lane& ln, hipStream_t to) {
     return SSW_OK;
 }
 
+bool pipeline_uses_two_lanes(const ssw_ctx* ctx, size_t n_chunks) {
+    return ctx->overlap && n_chunks > 2 && ctx->aux_stream != nullptr;
+}
+
 // Runs build(chunk, lane, chain) for every chunk and enqueues the chains: one lane on one stream when
 // overlap is off, else two lanes round-robin with GEMM stages on ctx->stream and HBM-bound stages on
 // ctx->aux_stream.  On return the context's stream is ordered after everything that was enqueued.
-int run_pipeline(ssw_ctx* ctx, size_t n_chunks, const std::function<int(size_t, ssw_ctx::Lane&, Chain&)>& build) {
-    if (n_chunks == 0) return SSW_OK;
-    // two lanes pay from three chunks on (with two, each lane would run a single chunk: measured equal to one lane)
-    const bool two = ctx->overlap && n_chunks > 2 && ctx->aux_stream != nullptr;
+int run_pipeline_impl(ssw_ctx* ctx, size_t n_chunks, bool two, const std::function<int(size_t, ssw_ctx::Lane&, Chain&)>& build) {
     hipStream_t G = ctx->stream, H = two ? ctx->aux_stream : ctx->stream;
     const int n_lanes = two ? 2 : 1;
     if (two) {                                     // the caller's earlier work on the context's stream comes first
@@ -486,6 +514,20 @@ int run_pipeline(ssw_ctx* ctx, size_t n_chunks, const std::function<int(size_t, 
     }
     for (int l = 0; l < n_lanes; ++l) SSW_TRY(hop(ctx, ctx->lane[l], G));
     return SSW_OK;
+}
+
+int run_pipeline(ssw_ctx* ctx, size_t n_chunks, const std::function<int(size_t, ssw_ctx::Lane&, Chain&)>& build) {
+    if (n_chunks == 0) return SSW_OK;
+    // two lanes pay from three chunks on (with two, each lane would run a single chunk: measured equal to one lane)
+    const bool two = pipeline_uses_two_lanes(ctx, n_chunks);
+    const int rc = run_pipeline_impl(ctx, n_chunks, two, build);
+    if (rc != SSW_OK && two) {
+        // a failing stage (out of memory inside grow(), most likely) must not leave the second stream running
+        // behind the caller's back: the lanes' buffers are reused by the next call on the context's stream
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    return rc;
 }
 
 // ---- pruned transform of the derived frames (prune.hip) ---------------------------------------------------
@@ -680,9 +722,15 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
     const bool f64 = c.precision == SSW_PRECISION_F64;
     const size_t px_bytes = u8 ? 3 : 3 * sizeof(float);
     // planes of lane 0 decide the (alignment-dependent) strategy for all lanes: hipMalloc'd, always 256-byte aligned
-    for (int l = 0; l < ssw_ctx::MAX_LANES; ++l)
+    // (lane 1 only when the call will run two lanes: three chunks or more)
+    for (int l = 0; l < (pipeline_uses_two_lanes(ctx, n_chunks) ? 2 : 1); ++l)
         for (int p : {0, 2}) SSW_TRY(grow(ctx->lane[l].plane[p], chunk * plane * sizeof(float)));
-    const PruneSetup ps = make_prune_setup(ctx, f64, std::min(chunk, n_frames), w, h, k, (const float*)ctx->lane[0].plane[0].p,
+    // The pruned path ends with one look at the overflow flags on the host; a stream that is being captured into
+    // a graph cannot be waited for, so such a call takes the full transform (enqueue-only, no host round trip).
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &capture) != hipSuccess) { (void)hipGetLastError(); capture = hipStreamCaptureStatusNone; }
+    const bool allow_prune = capture == hipStreamCaptureStatusNone;
+    const PruneSetup ps = !allow_prune ? PruneSetup() : make_prune_setup(ctx, f64, std::min(chunk, n_frames), w, h, k, (const float*)ctx->lane[0].plane[0].p,
                                            (const float*)ctx->lane[0].plane[2].p, dev_derived_rgb, u8);
     if (ps.on) SSW_TRY(grow(ctx->overflow, n_chunks * 8 * sizeof(uint32_t)));
     uint32_t* overflow = (uint32_t*)ctx->overflow.p;
