@@ -206,11 +206,15 @@ def test_second_embed_and_multi_mark_still_follow_the_reference():
 
 
 def test_context_creation_keeps_the_callers_device():
-    import torch
-    before = torch.cuda.current_device()
+    """ssw_ctx_create restores the calling thread's current HIP device; a bad ordinal is an argument error."""
+    hip = C.CDLL("libamdhip64.so")
+    dev = C.c_int(-1)
+    assert hip.hipGetDevice(C.byref(dev)) == 0
+    before = dev.value
     c = wm.Context(0)
     c.close()
-    assert torch.cuda.current_device() == before
-    lib = L.load()
+    assert hip.hipGetDevice(C.byref(dev)) == 0 and dev.value == before
+    n = C.c_int(0)
+    assert hip.hipGetDeviceCount(C.byref(n)) == 0 and n.value >= 1
     bad = C.c_void_p()
-    assert lib.ssw_ctx_create(torch.cuda.device_count(), C.byref(bad)) == L.SSW_ERR_BAD_ARG
+    assert L.load().ssw_ctx_create(n.value, C.byref(bad)) == L.SSW_ERR_BAD_ARG
