@@ -113,5 +113,11 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
                        size_t n_frames, size_t w, size_t h, size_t k, float* dev_extracted, const float* dev_marks,
                        float* dev_sims);
 
+// Reader::extract with a derived frame that is still RGB on the device (single-image handles): pruned transform +
+// extraction enqueued on the context's stream; see ssw_pipeline.hip
+int extract_single_pruned(ssw_ctx* ctx, int precision, const void* derived_rgb, bool u8, size_t w, size_t h, const float* base_y,
+                          const uint32_t* idx, size_t k, int method, float alpha, float* dev_out, uint32_t** dev_info,
+                          bool* applicable);
+
 }  // namespace host
 }  // namespace ssw

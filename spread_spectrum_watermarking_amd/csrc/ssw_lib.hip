@@ -40,9 +40,16 @@ struct ssw_reader {
     size_t w, h;
     bool is_base;
     ssw_config cfg;
-    float* y = nullptr;                               // coefficients
+    float* y = nullptr;                               // coefficients (a derived reader: once something asked for them)
     uint32_t* idx = nullptr;                          // cached first idx_k indices
     size_t idx_k = 0;
+    // A derived reader (Reader::derived, :469-471) keeps its frame on the device and transforms it when it is
+    // used: in extract(), where the base reader's index list says which coefficients are read (:556-561), only the
+    // frequency columns those need (the pruned transform of the batch path, bit-identical values); fully when
+    // coefficients() is called or the pruned path does not apply.
+    void* rgb = nullptr;
+    bool rgb_u8 = false;
+    hipEvent_t rgb_uploaded = nullptr;
 };
 
 namespace {
@@ -774,10 +781,42 @@ static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, bool u8, size_t
     if (!rd) return SSW_ERR_OUT_OF_MEMORY;
     rd->ctx = ctx; rd->w = w; rd->h = h; rd->is_base = is_base != 0; rd->cfg = c;
     auto fail = [&](int rc) { ssw_reader_destroy(rd); return rc; };
+    if (!is_base && ctx->prune) {
+        // upload only; transformed on first use (see ssw_reader)
+        const size_t bytes = plane * 3 * (u8 ? 1 : sizeof(float));
+        rd->rgb_u8 = u8;
+        if (pool_get(ctx, bytes, &rd->rgb) != SSW_OK) return fail(SSW_ERR_OUT_OF_MEMORY);
+        if (hipEventCreateWithFlags(&rd->rgb_uploaded, hipEventDisableTiming) != hipSuccess) return fail(SSW_ERR_HIP);
+        // the buffer may have been handed back by a handle whose last kernels are still queued on the context's stream
+        if (hipEventRecord(rd->rgb_uploaded, ctx->stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->copy_stream, rd->rgb_uploaded, 0) != hipSuccess) return fail(SSW_ERR_HIP);
+        int rc = upload(ctx, rd->rgb, rgb_hwc, bytes, ctx->copy_stream);
+        if (rc != SSW_OK) return fail(rc);
+        if (hipEventRecord(rd->rgb_uploaded, ctx->copy_stream) != hipSuccess ||
+            hipStreamWaitEvent(ctx->stream, rd->rgb_uploaded, 0) != hipSuccess) return fail(SSW_ERR_HIP);
+        *out = rd;
+        return SSW_OK;
+    }
     if (pool_get(ctx, plane * 4, (void**)&rd->y) != SSW_OK) return fail(SSW_ERR_OUT_OF_MEMORY);
     const int rc = forward_from_host(ctx, rgb_hwc, u8, w, h, c.precision, rd->y, nullptr, nullptr);   // :476-480
     if (rc != SSW_OK) return fail(rc);
     *out = rd;
+    return SSW_OK;
+}
+
+// a derived reader's full transform, on demand (Reader::derived :475-480)
+static int reader_ensure_coefficients(ssw_reader* rd) {
+    if (rd->y) return SSW_OK;
+    ssw_ctx* ctx = rd->ctx;
+    const size_t plane = rd->w * rd->h;
+    SSW_TRY(pool_get(ctx, plane * 4, (void**)&rd->y));
+    SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
+    Chain ch;
+    SSW_TRY(build_forward_from_rgb(ctx, ctx->lane[0], rd->cfg.precision, rd->rgb, rd->rgb_u8, 1, rd->w, rd->h, rd->y,
+                                   nullptr, nullptr, (float*)ctx->lane[0].plane[3].p, ch));
+    SSW_TRY(run_serial(ch, ctx->stream));
+    pool_put(ctx, rd->rgb, plane * 3 * (rd->rgb_u8 ? 1 : sizeof(float)));      // reuse is ordered on the stream
+    rd->rgb = nullptr;
     return SSW_OK;
 }
 
@@ -793,6 +832,8 @@ int ssw_reader_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_
 
 int ssw_reader_coefficients(ssw_reader* rd, float* out_plane) {
     if (!rd || !out_plane) return SSW_ERR_BAD_ARG;
+    DeviceGuard g(rd->ctx->device);
+    SSW_TRY(reader_ensure_coefficients(rd));
     return ssw_copy_to_host(rd->ctx, out_plane, rd->y, rd->w * rd->h * sizeof(float));
 }
 
@@ -832,6 +873,20 @@ int ssw_reader_extract(ssw_reader* base, ssw_reader* derived, float* out, size_t
     DeviceGuard g(ctx->device);
     SSW_TRY(reader_ensure_indices(base, k));
     SSW_TRY(grow(ctx->small, k * sizeof(float)));
+    if (!derived->y && derived->w == base->w && derived->h == base->h) {
+        // the derived frame is still RGB: transform it only where the first k indices of the base reader read it
+        bool pruned = false;
+        uint32_t* info = nullptr;
+        SSW_TRY(extract_single_pruned(ctx, derived->cfg.precision, derived->rgb, derived->rgb_u8, base->w, base->h, base->y,
+                                      base->idx, k, base->cfg.method, base->cfg.alpha, (float*)ctx->small.p, &info, &pruned));
+        if (pruned) {
+            uint32_t overflow = 1;
+            SSW_HIP_CHECK(hipMemcpyAsync(&overflow, info, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            SSW_TRY(ssw_copy_to_host(ctx, out, ctx->small.p, k * sizeof(float)));      // waits for the stream
+            if (overflow == 0) return SSW_OK;
+        }
+    }
+    SSW_TRY(reader_ensure_coefficients(derived));
     {
         StageTimer t(ctx, SSW_STAGE_EXTRACT, ctx->stream);
         // cached list may be longer than k: its first k entries are the first k of the order
@@ -847,6 +902,8 @@ int ssw_reader_destroy(ssw_reader* rd) {
     DeviceGuard g(ctx->device);
     pool_put(ctx, rd->y, rd->w * rd->h * 4);
     pool_put(ctx, rd->idx, rd->idx_k * sizeof(uint32_t));
+    pool_put(ctx, rd->rgb, rd->w * rd->h * 3 * (rd->rgb_u8 ? 1 : sizeof(float)));
+    if (rd->rgb_uploaded) (void)hipEventDestroy(rd->rgb_uploaded);
     delete rd;
     return SSW_OK;
 }

@@ -811,5 +811,37 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
     return SSW_OK;
 }
 
+// ---- Reader::extract against ONE derived frame that has not been transformed yet (single-image handles) ------
+// Reader::derived of the reference transforms the whole frame because it cannot know which coefficients will be
+// read (:469-480); a derived handle therefore only uploads its frame, and the transform happens here, when the base
+// reader's index list is known: the pruned transform of the batch path with n = 1 (same kernels, bit-identical
+// values).  Enqueues on the context's stream: the k extracted values into dev_out, the overflow flag into
+// dev_info[0] (non-zero: the columns did not fit, the caller must transform fully).  *applicable = false (nothing
+// enqueued) when the shape or the settings do not take the pruned path.
+int extract_single_pruned(ssw_ctx* ctx, int precision, const void* derived_rgb, bool u8, size_t w, size_t h, const float* base_y,
+                          const uint32_t* idx, size_t k, int method, float alpha, float* dev_out, uint32_t** dev_info,
+                          bool* applicable) {
+    *applicable = false;
+    const size_t plane = w * h;
+    ssw_ctx::Lane& ws = ctx->lane[0];
+    for (int p : {0, 2}) SSW_TRY(grow(ws.plane[p], plane * sizeof(float)));
+    const PruneSetup ps = make_prune_setup(ctx, precision == SSW_PRECISION_F64, 1, w, h, k, (const float*)ws.plane[0].p,
+                                           (const float*)ws.plane[2].p, derived_rgb, u8);
+    if (!ps.on) return SSW_OK;
+    SSW_TRY(grow(ctx->overflow, 8 * sizeof(uint32_t)));
+    uint32_t* info = (uint32_t*)ctx->overflow.p;
+    Chain ch;
+    SSW_TRY(build_pruned_derived(ctx, ws, precision, derived_rgb, u8, 1, w, h, k, idx, ps, info, ch));
+    SSW_TRY(run_serial(ch, ctx->stream));
+    {
+        StageTimer t(ctx, SSW_STAGE_EXTRACT, ctx->stream);
+        SSW_TRY(launch_extract_pruned(ctx->stream, base_y, (const float*)ws.compact[1].p, 1, w, h, ps.plan.cap_total,
+                                      (const uint32_t*)ws.prune_u32.p + w, idx, k, method, alpha, dev_out));
+    }
+    *dev_info = info;
+    *applicable = true;
+    return SSW_OK;
+}
+
 }  // namespace host
 }  // namespace ssw

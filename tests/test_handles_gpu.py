@@ -189,6 +189,57 @@ def test_handles_in_flight_do_not_disturb_each_other():
         assert wm.Tester(e, ctx).similarity(mark).similarity > 0.5 * np.linalg.norm(mark)
 
 
+@pytest.mark.parametrize("precision", [F32, F64])
+def test_derived_reader_is_transformed_on_use_and_only_where_it_is_read(precision):
+    """Reader::derived (src/algorithm.rs:469-480) only uploads; Reader::extract (:529-562) then transforms the
+    frequency columns the base reader's first k indices use (the batch path's pruned transform, n = 1).  Same values
+    as the full transform (forced here through coefficients()), far fewer flop; a frame whose columns do not fit
+    (white noise) falls back to the full transform; a second, longer extract and a second base reader still work."""
+    ctx = G.ctx()
+    w, h, k = 1040, 144, 120
+    cfg = wm.ReadConfig(precision=precision)
+    img = O.synth_frame(8, 2, w, h)
+    mark = np.random.default_rng(3).standard_normal(k).astype(np.float32)
+    marked = wm.Writer(img, wm.WriteConfig(precision=precision), ctx).mark([mark])
+    base = wm.Reader.base(img, cfg, ctx)
+    base.indices(k)                                        # ordering done: the timers below see the derived side only
+    full = wm.Reader.derived(marked, ctx, precision)
+    full.coefficients()                                    # forces Reader::derived's full transform
+    ctx.enable_timing(True)
+    try:
+        ctx.reset_timing()
+        want = base.extract(full, k)
+        assert ctx.timing()["dct_row"]["launches"] == 0    # already transformed
+        lazy = wm.Reader.derived(marked, ctx, precision)
+        ctx.reset_timing()
+        got = base.extract(lazy, k)
+        pruned_flop = ctx.timing()["dct_row"]["work"]
+        ctx.reset_timing()
+        coef = lazy.coefficients()                         # the same handle can still produce all coefficients
+        full_flop = ctx.timing()["dct_row"]["work"]
+    finally:
+        ctx.enable_timing(False)
+    assert np.array_equal(got, want)
+    assert 0 < pruned_flop < 0.5 * full_flop
+    assert np.array_equal(coef, full.coefficients())
+    assert np.array_equal(base.extract(lazy, k + 50), base.extract(full, k + 50))
+    other = wm.Reader.base(O.synth_frame(8, 3, w, h), cfg, ctx)
+    assert np.array_equal(other.extract(wm.Reader.derived(marked, ctx, precision), k), other.extract(full, k))
+    # white noise: the index list touches nearly every column -> overflow -> full transform, same values
+    noise = np.random.default_rng(9).random((h, w, 3), dtype=np.float32)
+    nb = wm.Reader.base(noise, cfg, ctx)
+    nd_full = wm.Reader.derived(noise[::-1].copy(), ctx, precision)
+    nd_full.coefficients()
+    assert np.array_equal(nb.extract(wm.Reader.derived(noise[::-1].copy(), ctx, precision), 1000), nb.extract(nd_full, 1000))
+    # error behaviour is unchanged: a derived reader is not a base, shapes must match
+    with pytest.raises(wm.SswError) as e:
+        lazy._reader.indices(3)
+    assert e.value.status == L.SSW_ERR_NOT_BASE
+    with pytest.raises(wm.SswError) as e:
+        base.extract(wm.Reader.derived(O.synth_frame(1, 1, w, h + 8), ctx, precision), k)
+    assert e.value.status == L.SSW_ERR_LENGTH_MISMATCH
+
+
 def test_second_embed_and_multi_mark_still_follow_the_reference():
     """Writer::embed twice (the staging vectors of the handle are reused) and several marks of different
     lengths, on an 8-bit writer: equal to the f32 writer fed with the host-converted frame."""
