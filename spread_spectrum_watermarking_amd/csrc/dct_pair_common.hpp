@@ -46,6 +46,9 @@ struct PairOutT {
     const float* iq_q = nullptr;
     void* rgb = nullptr;
     unsigned rgb_u8 = 0;
+    // column passes: results leave through an LDS transpose as 16-byte pieces of whole output rows (W % 4 == 0 and
+    // 16-byte aligned planes; 4-byte aligned 8-bit RGB), decided by the launcher
+    unsigned wide = 0;
 };
 
 // yiq.rs:139-147 (f32::clamp) and :163-165, :173-175: the arithmetic of color.hip / attack.hip, per pixel
@@ -82,6 +85,38 @@ __device__ inline void pair_store_rgb_batch(const PairOutT<T>& po, size_t base, 
             float* o = static_cast<float*>(po.rgb) + 3 * (base + px[t]);
             o[0] = r; o[1] = g; o[2] = b;
         }
+    }
+}
+
+// One quad of horizontally adjacent pixels: (Y, I, Q) -> RGB like pair_store_rgb_batch, I / Q read and RGB written as
+// 16-byte pieces (f32) or 12 bytes (8-bit).  `px`: pixel index of the quad's first pixel in the frame batch.
+template <typename T>
+__device__ inline void pair_store_rgb_quad(const PairOutT<T>& po, size_t px, const float (&y)[4]) {
+    const f32x4 iv = *reinterpret_cast<const f32x4*>(po.iq_i + px);
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(po.iq_q + px);
+    float c[12];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        c[3 * t + 0] = pair_clamp01(1.0f * y[t] + 0.948262f * iv[t] + 0.624013f * qv[t]);
+        c[3 * t + 1] = pair_clamp01(1.0f * y[t] + -0.276066f * iv[t] + -0.639810f * qv[t]);
+        c[3 * t + 2] = pair_clamp01(1.0f * y[t] + -1.105450f * iv[t] + 1.729860f * qv[t]);
+    }
+    if (po.rgb_u8) {
+        unsigned w[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            unsigned v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= (unsigned)(uint8_t)roundf(pair_clamp01(c[4 * d + b]) * 255.0f) << (8 * b);
+            w[d] = v;
+        }
+        unsigned* o = reinterpret_cast<unsigned*>(static_cast<uint8_t*>(po.rgb) + 3 * px);
+        o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+    } else {
+        f32x4* o = reinterpret_cast<f32x4*>(static_cast<float*>(po.rgb) + 3 * px);
+        o[0] = (f32x4){c[0], c[1], c[2], c[3]};
+        o[1] = (f32x4){c[4], c[5], c[6], c[7]};
+        o[2] = (f32x4){c[8], c[9], c[10], c[11]};
     }
 }
 

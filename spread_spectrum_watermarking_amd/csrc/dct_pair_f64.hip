@@ -28,6 +28,7 @@
 // supplies k = 4 s + lq (the same assignment on both operands).
 #include "dct_pair_common.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace ssw {
@@ -51,8 +52,12 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     unsigned Kp, unsigned yrows /*lines of the basis planes*/, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
     constexpr int NX = SAMEX ? 1 : 2;
     constexpr int BN = 64, XQ = BM / 64;                                   // XQ: X lines per staging thread
-    __shared__ __attribute__((aligned(16))) double sX[2][NX][BM * PBK];    // [buffer][product]
-    __shared__ __attribute__((aligned(16))) double sY[2][2][BN * PBK];
+    // operand tiles [buffer][product][rows * 8]; a column pass reuses the region to transpose its results (epilogue)
+    constexpr int SXD = 2 * NX * BM * PBK, SYD = 2 * 2 * BN * PBK;
+    constexpr int TRD = COLS ? 4 * 32 * (BM / 2 + 16) / 2 : 0;              // 4 waves x 32 result rows x pitch floats
+    __shared__ __attribute__((aligned(16))) double lds[SXD + SYD > TRD ? SXD + SYD : TRD];
+    double (*sX)[NX][BM * PBK] = reinterpret_cast<double (*)[NX][BM * PBK]>(lds);
+    double (*sY)[2][BN * PBK] = reinterpret_cast<double (*)[2][BN * PBK]>(lds + SXD);
 
     unsigned tm, tn;
     tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
@@ -269,7 +274,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             lp[(n - 1 - n2) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
         }
     };
-    if (!COLS) {
+    if constexpr (!COLS) {
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn) {
             const unsigned pair = p0 + wn + 16 * jn + li;
@@ -283,7 +288,114 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                     emit(po.out + (size_t)row * W, po.tmp + (size_t)row * (n / 2), 1, pair, acc1[i][jn][r], acc2[i][jn][r]);
                 }
         }
-    } else {
+    } else if constexpr (EPI != EPI_INV_E) {
+      if (po.wide) {
+        // Column pass, wide stores.  A D tile has the image columns along the lanes, 16 at a time: stored as it is, a
+        // wave writes 64-byte pieces (half cache lines, measured: the write traffic of such an epilogue costs the
+        // co-resident block's main loop 4 % of a column pass).  Instead each wave transposes its results through LDS
+        // -- 32 result rows x CW columns per round -- and every lane stores 16 bytes of a row: whole lines, a
+        // quarter of the store instructions and of the address arithmetic.  Same values, same rounding points.
+        constexpr int CW = 16 * NI;                                        // image columns of this wave's sub-tile
+        constexpr int TPF = (CW % 32 == 0) ? CW + 16 : CW + 32;           // row pitch in floats: odd multiple of 16 banks
+        constexpr int QPR = CW / 4, RPI = 64 / QPR, NRI = 32 / RPI;        // quads per row, rows per read, reads per round
+        static_assert(4 * 32 * TPF * 4 <= (int)sizeof(lds), "transpose area");
+        __syncthreads();                      // every wave has read its last fragments: the operand tiles are free
+        float* tw = reinterpret_cast<float*>(lds) + wave * (32 * TPF);
+        const unsigned wr0 = lq * TPF + li;                                // + (16 jn + 4 r) * TPF + 16 i
+        const unsigned q = lane % QPR, rrow = lane / QPR;
+        const unsigned line = m0 + wm + 4 * q;                             // = frame * W + column, a multiple of 4
+        const bool line_ok = line < L;
+        const unsigned z = line_ok ? line / W : 0, col = line_ok ? line - z * W : 0;
+        const size_t fbase = (size_t)z * H * W + col;                      // (frame z, row 0, col) in elements
+        const float* trd = tw + rrow * TPF + 4 * q;
+        // LDS instructions of one wave execute in order, so a read sees the writes issued before it; the fences keep
+        // the compiler from moving one across the other (it cannot see that other lanes wrote what a lane reads)
+        auto lds_order = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        const bool plain = ep.first == 1.0f && ep.base == 1.0f;            // x * 1.0f is exact: skipping it changes nothing
+        auto put_quad = [&](unsigned idx, f32x4 v) {                       // 4 columns of output row idx
+            const float f = idx == 0 ? ep.first : ep.base;
+            float y[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) y[t] = plain ? v[t] : v[t] * f;
+            const size_t px = fbase + (size_t)idx * W;
+            if (EPI == EPI_INV_O_RGB) pair_store_rgb_quad<double>(po, px, y);
+            else *reinterpret_cast<f32x4*>(po.out + px) = (f32x4){y[0], y[1], y[2], y[3]};
+        };
+        if (EPI == EPI_FWD || EPI == EPI_INV) {
+#pragma unroll
+            for (int set = 0; set < 2; ++set) {
+                lds_order();
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double a1 = acc1[i][jn][r], a2 = acc2[i][jn][r];
+                            const float v = EPI == EPI_FWD ? (float)(set ? a2 : a1) : (float)(set ? a1 - a2 : a1 + a2);
+                            tw[wr0 + (16 * jn + 4 * r) * TPF + 16 * i] = v;
+                        }
+                lds_order();
+#pragma unroll
+                for (int t = 0; t < NRI; ++t) {
+                    const unsigned pair = p0 + wn + t * RPI + rrow;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
+                    if (!line_ok || pair >= NP) continue;
+                    const unsigned idx = EPI == EPI_FWD ? (set ? po.c2 : po.c1) + po.cs * pair : (set ? n - 1 - pair : pair);
+                    put_quad(idx, v);
+                }
+            }
+        } else {
+            // EPI_INV_O / EPI_INV_O_RGB: x[n1] = E[n1] + a1, x[n-1-n1] = E[n1] - a1, x[n2] = E[n2] + a2, x[n-1-n2] = E[n2] - a2
+            // (n1 = pair, n2 = pair + n/4); a round = 16 pairs: the "+" rows in staging rows 0..15, the "-" rows in 16..31
+            const double* tpl = po.tmp + (size_t)z * (n / 2) * W + (m0 + wm - z * W);      // + row * W + 16 i + li, own frame only
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    double e[NI][4];
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const unsigned ln = m0 + wm + 16 * i + li;
+                        const unsigned lz = ln < L ? ln / W : 0, lc = ln < L ? ln - lz * W : 0;
+                        const double* tp = po.tmp + (size_t)lz * (n / 2) * W + lc;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
+                            const unsigned pc = pair < NP ? pair : 0;
+                            e[i][r] = tp[(size_t)(pc + (half ? n / 4 : 0)) * W];
+                        }
+                    }
+                    (void)tpl;
+                    lds_order();
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double a = half ? acc2[i][jn][r] : acc1[i][jn][r];
+                            tw[wr0 + (4 * r) * TPF + 16 * i] = (float)(e[i][r] + a);
+                            tw[wr0 + (16 + 4 * r) * TPF + 16 * i] = (float)(e[i][r] - a);
+                        }
+                    lds_order();
+#pragma unroll
+                    for (int t = 0; t < NRI; ++t) {
+                        const unsigned srow = t * RPI + rrow;                        // staging row: [0, 16) plus, [16, 32) minus
+                        const unsigned pair = p0 + wn + 16 * jn + (srow & 15);
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
+                        if (!line_ok || pair >= NP) continue;
+                        const unsigned nn = pair + (half ? n / 4 : 0);
+                        put_quad(srow < 16 ? nn : n - 1 - nn, v);
+                    }
+                }
+        }
+        return;
+      }
+    }
+    if constexpr (COLS) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const unsigned line = m0 + wm + 16 * i + li;       // = frame * W + column
@@ -375,6 +487,9 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     if (kind == 1) { po.c1 = 0; po.c2 = 2 * fs; po.cs = 4 * fs; }
     if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
+    auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
+    po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0) ? 1u : 0u;
+    if (sink && sink->rgb && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;
     if ((unsigned long long)Kp * L * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
 #define SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, SUBV, BMV) \
         pair_gemm_f64_kernel<COLS, EPI, SAMEX, SUBV, BMV><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep)

@@ -16,8 +16,15 @@ W, H, REPS = (int(a) for a in (sys.argv[1:4] + ["3840", "2160", "10"][len(sys.ar
 K = 1000
 ctx = wm.Context(0)
 rng = np.random.default_rng(1)
-rgb32 = rng.random((H, W, 3), dtype=np.float32)
-rgb8 = (rgb32 * 255).astype(np.uint8)
+# the bench's synthetic frames (multi-octave value noise: a natural-like spectrum), made on the device
+import ctypes as C
+from spread_spectrum_watermarking_amd.api import check
+_d = ctx.alloc(H * W * 12)
+check(ctx._lib.ssw_synth_frames(ctx.handle, 1, 0, 1, W, H, _d.ptr), "ssw_synth_frames")
+ctx.synchronize()
+rgb8 = np.floor(np.clip(_d.to_host(np.float32, (H, W, 3)), 0, 1) * np.float32(255) + np.float32(0.5)).astype(np.uint8)
+rgb32 = rgb8.astype(np.float32) / np.float32(255)
+_d.free()
 mark = rng.standard_normal(K).astype(np.float32)
 px = W * H / 1e6
 
