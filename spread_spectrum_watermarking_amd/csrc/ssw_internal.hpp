@@ -177,9 +177,10 @@ size_t resize_tmp_bytes(const uint8_t* in, size_t n_frames, size_t w, size_t h, 
 int launch_resize_rgb8(hipStream_t st, const uint8_t* in, size_t n_frames, size_t w, size_t h, size_t nw, size_t nh,
                        const DeviceTaps& vt, const DeviceTaps& ht, float* tmp, uint8_t* out);
 
-// sort_full.hip: all W*H-1 indices of one plane in the reference's order (rocPRIM radix sort; not hot)
-int full_sort_scratch_bytes(size_t plane_len, size_t* bytes);
-int launch_full_sort(hipStream_t st, const float* coef, size_t w, size_t h, int ordering, void* scratch,
+// sort_full.hip: the first k of all W*H-1 indices of n_frames planes in the reference's order (batched LSD radix
+// sort; not hot: only Reader::indices() with a large k and marks longer than the top-k limit reach it)
+int full_sort_scratch_bytes(size_t plane_len, size_t n_frames, size_t* bytes);
+int launch_full_sort(hipStream_t st, const float* coef, size_t n_frames, size_t w, size_t h, int ordering, void* scratch,
                      size_t scratch_bytes, uint32_t* indices_out, size_t k);
 int launch_embed(hipStream_t st, float* coef, size_t n_frames, size_t plane_len,
                  const uint32_t* indices, size_t idx_stride, const float* marks,

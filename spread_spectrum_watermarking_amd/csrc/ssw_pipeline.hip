@@ -417,16 +417,14 @@ int topk(ssw_ctx* ctx, hipStream_t st, SelectWorkspace& sel, const float* coef, 
          size_t k, uint32_t* idx) {
     const double bytes = 4.0 * (double)n * (double)w * (double)h;
     if (k > select_max_k()) {
-        // Beyond the in-LDS top-k limit (16384 entries; BASELINE marks are 1000 and 10000 long): a full device
-        // sort of each plane with rocPRIM's radix sort, first k entries kept.  A library call, one frame at
-        // a time, off the hot path: only Reader::indices() with a large k and marks that long reach it.
+        // Beyond the in-LDS top-k limit (16384 entries; BASELINE marks are 1000 and 10000 long): the full order of
+        // every plane (sort_full.hip: a batched radix sort over all frames of the call), first k entries kept.  Off
+        // the hot path: only Reader::indices() with a large k and marks that long reach it.
         size_t sb = 0;
-        SSW_TRY(full_sort_scratch_bytes(w * h, &sb));
+        SSW_TRY(full_sort_scratch_bytes(w * h, n, &sb));
         SSW_TRY(grow(ctx->sort_scratch, sb));
         StageTimer t(ctx, SSW_STAGE_SELECT, st, bytes);
-        for (size_t f = 0; f < n; ++f)
-            SSW_TRY(launch_full_sort(st, coef + f * w * h, w, h, ordering, ctx->sort_scratch.p, ctx->sort_scratch.bytes, idx + f * k, k));
-        return SSW_OK;
+        return launch_full_sort(st, coef, n, w, h, ordering, ctx->sort_scratch.p, ctx->sort_scratch.bytes, idx, k);
     }
     SSW_TRY(grow_select(st, sel, n, k));
     StageTimer t(ctx, SSW_STAGE_SELECT, st, bytes);

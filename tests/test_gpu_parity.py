@@ -293,6 +293,25 @@ def test_long_index_lists_at_full_hd():
     assert np.all(sims > 0.97 * np.linalg.norm(marks, axis=1)) and np.abs(ext - marks).max() < 0.1
 
 
+def test_full_index_list_at_4k_and_batched_equals_the_stable_sort():
+    """Reader::indices() with no limit on a 3840x2160 frame (8.3 M entries, src/algorithm.rs:200-210, :506-508): the
+    library's own batched radix sort (sort_full.hip) against the oracle's stable sort, and three frames of different
+    content sorted in one call (ssw_topk_indices with k beyond the top-k limit) against one-at-a-time results."""
+    rgb = G.synth(9, 4, 1, 3840, 2160)[0]
+    reader = wm.Reader.base(rgb)
+    coef = reader.coefficients().reshape(2160, 3840)
+    full = reader.indices()
+    assert full.shape == (3840 * 2160 - 1,)
+    assert np.array_equal(full, O.indices(coef))
+    planes = np.stack([O.dct2d(O.rgb_to_yiq(O.synth_frame(5, f, 320, 200))[0]) for f in range(3)])
+    planes[1, 7, 9] = planes[1, 100, 50] = -planes[1, 3, 3]            # exact energy ties
+    k = 320 * 200 - 1
+    got = G.topk(planes, k)
+    for f in range(3):
+        assert np.array_equal(got[f], O.indices(planes[f]))
+        assert np.array_equal(got[f], G.topk(planes[f], k))
+
+
 def test_topk_degenerate_planes():
     z = np.zeros((2, 9, 13), np.float32)                               # every key ties: index order
     assert np.array_equal(G.topk(z, 50)[0], np.arange(1, 51))
