@@ -299,11 +299,8 @@ __global__ __launch_bounds__(256) void pair_prep4_rows_rgb_kernel(const void* __
                                                                  unsigned rows, unsigned W, unsigned Kq, unsigned Kp,
                                                                  unsigned tiles_q) {
     const unsigned Nh = W / 2, Nq = W / 4;
-    // block = 8 rows x 128 q: the four waves take adjacent 32-q ranges of the same rows (contiguous 1536-byte reads
-    // of the 48-byte pixel quads per row and piece; see pair_prep8_rows_kernel)
-    const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const unsigned q = (blockIdx.x % tiles_q) * 128 + wv * 32 + (ln & 7) * 4;
-    const unsigned row = (blockIdx.x / tiles_q) * 8 + (ln >> 3);
+    const unsigned q = (blockIdx.x % tiles_q) * 32 + (threadIdx.x & 7) * 4;
+    const unsigned row = (blockIdx.x / tiles_q) * 32 + (threadIdx.x >> 3);
     if (row >= rows || q >= Kq) return;
     vec4_t<T> a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
     if (q < Nq) {                                                 // Nq % 4 == 0
@@ -354,15 +351,8 @@ __global__ __launch_bounds__(256) void pair_prep8_rows_kernel(const void* __rest
                                                              unsigned rows, unsigned W, unsigned K8, unsigned Kq, unsigned Kp,
                                                              unsigned tiles_e) {
     const unsigned Nh = W / 2, Nq = W / 4, Ne = W / 8;
-    // plane source: block = 32 rows x 32 e (a wave = 8 rows x 8 quads: 128-byte read runs, 512-byte write runs).
-    // RGB source: a quad is 48 (12) bytes and a 32-e run of a row 384 bytes at any 48-byte offset -- up to a third
-    // more cache lines than bytes asked for (measured 1.23x the algorithmic traffic); there the four waves of a block
-    // take adjacent 32-e ranges of the SAME 8 rows, so a block reads 1536 contiguous bytes per row and piece and the
-    // lines its waves share are fetched once; the write runs of a wave stay 8 rows x 64 bytes per k-block.
-    constexpr bool WIDE = SRC != 0;
-    const unsigned wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
-    const unsigned e0 = WIDE ? (blockIdx.x % tiles_e) * 128 + wv * 32 + (ln & 7) * 4 : (blockIdx.x % tiles_e) * 32 + (threadIdx.x & 7) * 4;
-    const unsigned row = WIDE ? (blockIdx.x / tiles_e) * 8 + (ln >> 3) : (blockIdx.x / tiles_e) * 32 + (threadIdx.x >> 3);
+    const unsigned e0 = (blockIdx.x % tiles_e) * 32 + (threadIdx.x & 7) * 4;
+    const unsigned row = (blockIdx.x / tiles_e) * 32 + (threadIdx.x >> 3);
     if (row >= rows || e0 >= K8) return;
     vec4_t<T> r1 = {0, 0, 0, 0}, r2 = {0, 0, 0, 0};
     if (e0 < Ne) {                                                // Ne % 4 == 0
@@ -593,9 +583,9 @@ static int prep4_rgb_impl(hipStream_t st, bool u8, const void* rgb, size_t n_fra
                           T* q1, T* q2, T* p, float* ip, float* qp) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const unsigned Kp = (unsigned)pair_kpad<T>(w), Kq = (unsigned)pair_kpad<T>(w / 2), tiles_q = (Kq + 127) / 128;
+    const unsigned Kp = (unsigned)pair_kpad<T>(w), Kq = (unsigned)pair_kpad<T>(w / 2), tiles_q = (Kq + 31) / 32;
     const size_t rows = n_frames * h;
-    const unsigned long long nblk = (unsigned long long)((rows + 7) / 8) * tiles_q;
+    const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_q;
     if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     const bool iq = ip && qp;
 #define SSW_PREP_RGB(U8V, IQV) pair_prep4_rows_rgb_kernel<T, U8V, IQV><<<(unsigned)nblk, 256, 0, st>>>( \
@@ -624,10 +614,9 @@ static int prep8_impl(hipStream_t st, int src_kind, const void* src, size_t n_fr
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned Kp = (unsigned)pair_kpad<T>(w), Kq = (unsigned)pair_kpad<T>(w / 2), K8 = (unsigned)pair_kpad<T>(w / 4);
-    const bool wide = src_kind != 0;                          // RGB sources: 8 rows x 128 e per block (see the kernel)
-    const unsigned tiles_e = wide ? (K8 + 127) / 128 : (K8 + 31) / 32;
+    const unsigned tiles_e = (K8 + 31) / 32;
     const size_t rows = n_frames * h;
-    const unsigned long long nblk = (unsigned long long)(wide ? (rows + 7) / 8 : (rows + 31) / 32) * tiles_e;
+    const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_e;
     if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     const bool iq = ip && qp;
 #define SSW_PREP8(SRCV, IQV) pair_prep8_rows_kernel<T, SRCV, IQV><<<(unsigned)nblk, 256, 0, st>>>( \

@@ -1,12 +1,12 @@
 mkdir -p gpurun_out
-python tools/dct_microbench.py 3840 2160 64 2 f64 0
-python tools/dct_microbench.py 3840 2160 64 2 f64 2
-python tools/dct_microbench.py 1920 1080 128 2 f64 0
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-alt --no-handle-leg --no-full-transform-leg --no-timers-off-leg --no-serial-leg > gpurun_out/b6.json 2>gpurun_out/b6.err
-python - <<PY
+for i in 1 2; do
+for o in 0 1; do
+  if [ $o = 1 ]; then export SSW_PREP_OLD=1; else unset SSW_PREP_OLD; fi
+  python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-handle-leg --no-full-transform-leg --no-timers-off-leg --no-serial-leg > gpurun_out/p.json 2>/dev/null
+  python - <<PY
 import json
-r=json.load(open("gpurun_out/b6.json"))
-k=r["kernels"]
-print("value", r["value"], "rows", k["dct_rows"]["frac_mfma"], "cols", k["dct_cols"]["frac_mfma"], r["roofline"]["frac"], r["stage_ms_per_step"])
+r=json.load(open("gpurun_out/p.json")); k=r["kernels"]
+print("old=$o value", r["value"], "rgb", k["rgb_to_yiq"], "prep", k["dct_prep"]["gbs"])
 PY
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -3
+done
+done
