@@ -512,8 +512,15 @@ def main():
     def dump(sims_host, ext_host):
         if not args.dump:
             return
-        all_s = dist.gather(sims_host) if dist is not None else [sims_host]
-        all_e = dist.gather(ext_host) if dist is not None else [ext_host]
+        if dist is None:
+            all_s, all_e = [sims_host], [ext_host]
+        else:                                        # strong scaling: shards may differ by one frame -> pad, gather, trim
+            counts = [int(c[0]) for c in dist.gather(np.array([B], dtype=np.int64))]
+            top = max(counts)
+            pad_s = np.full((top,), np.nan, np.float32); pad_s[:B] = sims_host
+            pad_e = np.full((top, K), np.nan, np.float32); pad_e[:B] = ext_host
+            all_s = [a[:c] for a, c in zip(dist.gather(pad_s), counts)]
+            all_e = [a[:c] for a, c in zip(dist.gather(pad_e), counts)]
         if rank == 0:
             np.savez(args.dump, sims=np.concatenate(all_s), extracted=np.concatenate(all_e))
 

@@ -90,6 +90,15 @@ __device__ inline void pair_store_rgb_batch(const PairOutT<T>& po, size_t base, 
 
 // One quad of horizontally adjacent pixels: (Y, I, Q) -> RGB like pair_store_rgb_batch, I / Q read and RGB written as
 // 16-byte pieces (f32) or 12 bytes (8-bit).  `px`: pixel index of the quad's first pixel in the frame batch.
+// f32::clamp(x, 0, 1) of a finite x in one instruction (v_med3_f32); a result of -0.0 where the comparison form
+// gives +0.0 compares equal and quantises to the same byte
+__device__ inline float pair_clamp01_med3(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+// into_rgb8 of a clamped channel: round(c * 255), halves away from zero, as an integer-valued float.  For x >= 0:
+// floor(x + 0.5) is exact except below 0.5, where x + 0.5 can round up to 1.0 (x = 0.5 - 2^-25): those are 0.
+__device__ inline float pair_round255(float c) {
+    const float x = c * 255.0f;
+    return x < 0.5f ? 0.0f : floorf(x + 0.5f);
+}
 template <typename T>
 __device__ inline void pair_store_rgb_quad(const PairOutT<T>& po, size_t px, const float (&y)[4]) {
     const f32x4 iv = *reinterpret_cast<const f32x4*>(po.iq_i + px);
@@ -97,9 +106,9 @@ __device__ inline void pair_store_rgb_quad(const PairOutT<T>& po, size_t px, con
     float c[12];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        c[3 * t + 0] = pair_clamp01(1.0f * y[t] + 0.948262f * iv[t] + 0.624013f * qv[t]);
-        c[3 * t + 1] = pair_clamp01(1.0f * y[t] + -0.276066f * iv[t] + -0.639810f * qv[t]);
-        c[3 * t + 2] = pair_clamp01(1.0f * y[t] + -1.105450f * iv[t] + 1.729860f * qv[t]);
+        c[3 * t + 0] = pair_clamp01_med3(1.0f * y[t] + 0.948262f * iv[t] + 0.624013f * qv[t]);
+        c[3 * t + 1] = pair_clamp01_med3(1.0f * y[t] + -0.276066f * iv[t] + -0.639810f * qv[t]);
+        c[3 * t + 2] = pair_clamp01_med3(1.0f * y[t] + -1.105450f * iv[t] + 1.729860f * qv[t]);
     }
     if (po.rgb_u8) {
         unsigned w[3];
@@ -107,7 +116,7 @@ __device__ inline void pair_store_rgb_quad(const PairOutT<T>& po, size_t px, con
         for (int d = 0; d < 3; ++d) {
             unsigned v = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) v |= (unsigned)(uint8_t)roundf(pair_clamp01(c[4 * d + b]) * 255.0f) << (8 * b);
+            for (int b = 0; b < 4; ++b) v = __builtin_amdgcn_cvt_pk_u8_f32(pair_round255(c[4 * d + b]), b, v);   // exact: integer-valued
             w[d] = v;
         }
         unsigned* o = reinterpret_cast<unsigned*>(static_cast<uint8_t*>(po.rgb) + 3 * px);

@@ -325,6 +325,50 @@ def test_bench_two_ranks_equal_one_process(tmp_path):
     assert j2["value"] > 0 and j2["scaling"] == "weak"
 
 
+def test_bench_strong_scaling_splits_a_fixed_batch(tmp_path):
+    """`--scaling strong --total-batch 7 --gpus 2`: the contiguous block split of SURVEY 8(e) (frame b -> rank
+    floor(b * N / B): 3 + 4 frames), whole-job pixels in `value`, per-frame results equal to one process on 7 frames."""
+    two, one = str(tmp_path / "two.npz"), str(tmp_path / "one.npz")
+    j2 = _bench(["--gpus", "2", "--scaling", "strong", "--total-batch", "7", "--dump", two, "--no-handle-leg",
+                 "--no-full-transform-leg"] + SMALL, {"SSW_BENCH_SHARE_DEVICE": "1", "SSW_BENCH_DIST_BACKEND": "gloo"})
+    j1 = _bench(["--gpus", "1", "--batch", "7", "--dump", one, "--no-handle-leg", "--no-full-transform-leg"] + SMALL)
+    assert j2["scaling"] == "strong" and j2["config"]["total_frames"] == 7 and j2["config"]["frames_per_gpu"] == 3
+    assert j1["config"]["total_frames"] == 7
+    a, b = np.load(two), np.load(one)
+    assert a["sims"].shape == (7,) and np.array_equal(a["sims"], b["sims"]) and np.array_equal(a["extracted"], b["extracted"])
+
+
+def test_bench_line_carries_every_leg():
+    """The default line's extra legs on a small shape: handle API (PCIe-inclusive, bit-identical to the batch entry
+    points), the reference's four full transforms (prune off, bit-identical to the headline), CPU baseline and parity."""
+    j = _bench(["--gpus", "1", "--batch", "4", "--steps", "1", "--warmup", "1", "--width", "512", "--height", "288", "--k", "100",
+                "--no-alt", "--no-serial-leg", "--no-timers-off-leg"])
+    h = j["handle_api"]
+    assert h["bit_identical_to_batch_rgb8"] is True
+    for leg in ("rgb8_pageable", "rgb8_pinned", "f32_pageable"):
+        assert h[leg]["embed_extract_mpix_s"] > 0 and h[leg]["pcie_bytes_per_frame"] > 0
+    assert h["rgb8_pinned"]["staged_fraction"] == 0.0 and h["rgb8_pageable"]["pcie_bytes_per_frame"] * 3 < h["f32_pageable"]["pcie_bytes_per_frame"]
+    f = j["full_transform"]
+    assert f["bit_identical_to_headline"] is True and f["pruned_derived_transform"]["pruned_chunks"] == 0
+    assert f["executed_fraction_of_dense"] > j["kernels"]["dct_all"]["executed_fraction_of_dense"]
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["value"] > 0
+    assert j["parity"]["frames"][0]["sim_delta_vs_cpu_exact"] < 1e-4
+    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] <= 1.0
+
+
+def test_bench_attack_line_checks_itself_against_the_oracle():
+    """`--config 4` flow (embed -> into_rgb8 -> CatmullRom 1/8 down + up -> extract, tests/attack_resize.rs:17-66) on a
+    small shape: the line carries a CPU baseline of the same flow and a parity block against the oracle."""
+    j = _bench(["--config", "4", "--gpus", "1", "--batch", "3", "--steps", "1", "--warmup", "1", "--width", "1024", "--height", "576",
+                "--k", "400"])
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+    p = j["parity"]
+    assert p["resize_down_bit_exact"] is True and p["resize_up_bit_exact"] is True
+    assert p["marked_rgb8_identical_fraction_vs_cpu_exact"] >= 0.9999
+    assert p["extracted_max_abs_diff_vs_cpu_exact"] <= 1e-5 * 10 and p["sim_delta_vs_cpu_exact"] < 1e-4 * max(1.0, abs(p["sim_cpu_exact"]))
+    assert j["roofline"]["flop_per_launch"] > 0 and j["config"]["chunk_frames"] == 3
+
+
 def test_bench_under_torchrun_two_ranks(tmp_path):
     """The driver's multi-GPU command line: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
     127.0.0.1 --master-port P bench.py --gpus N ...` -- bench.py is then one rank (RANK / LOCAL_RANK / WORLD_SIZE come
