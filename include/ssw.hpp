@@ -108,6 +108,15 @@ struct ImageRgb32F {
     ImageRgb32F(size_t w, size_t h) : width(w), height(h), data(w * h * 3) {}
 };
 
+// An 8-bit RGB image [h][w][3] (what image files decode to).  Handed to the library as it is: `into_rgb32f()`
+// (algorithm.rs:308, :476) runs on the device and a quarter of the bytes cross PCIe.
+struct ImageRgb8 {
+    size_t width = 0, height = 0;
+    std::vector<uint8_t> data;
+    ImageRgb8() = default;
+    ImageRgb8(size_t w, size_t h) : width(w), height(h), data(w * h * 3) {}
+};
+
 class MarkBuf {                                        // algorithm.rs:607-645
 public:
     MarkBuf() = default;
@@ -137,6 +146,12 @@ public:
         ssw_config c = config.c();
         check(ssw_writer_create(ctx.get(), image.data.data(), w_, h_, &c, &wr_), "Writer::new");
     }
+    Writer(Context& ctx, const ImageRgb8& image, const WriteConfig& config = WriteConfig())
+        : w_(image.width), h_(image.height) {
+        if (image.data.size() != w_ * h_ * 3) throw Error(SSW_ERR_BAD_DIMS, "Writer::new");
+        ssw_config c = config.c();
+        check(ssw_writer_create_rgb8(ctx.get(), image.data.data(), w_, h_, &c, &wr_), "Writer::new");
+    }
     ~Writer() { ssw_writer_destroy(wr_); }
     Writer(const Writer&) = delete;
     Writer& operator=(const Writer&) = delete;
@@ -160,6 +175,13 @@ public:
         embed(marks);
         return result();
     }
+    // `writer.mark(marks).into_rgb8()` (examples/main.rs:271-278): quantised on the device, 3 bytes per pixel back
+    ImageRgb8 mark_rgb8(const std::vector<const MarkBuf*>& marks) {
+        embed(marks);
+        ImageRgb8 out(w_, h_);
+        check(ssw_writer_result_rgb8(wr_, out.data.data()), "Writer::mark");
+        return out;
+    }
 
 private:
     size_t w_, h_;
@@ -171,6 +193,9 @@ class ReaderDerived;
 class Reader {                                         // algorithm.rs:441-594
 public:
     static Reader base(Context& ctx, const ImageRgb32F& image, const ReadConfig& config = ReadConfig()) {   // :462-464
+        return Reader(ctx, image, true, config);
+    }
+    static Reader base(Context& ctx, const ImageRgb8& image, const ReadConfig& config = ReadConfig()) {
         return Reader(ctx, image, true, config);
     }
     ~Reader() { ssw_reader_destroy(rd_); }
@@ -198,6 +223,12 @@ private:
         ssw_config c = config.c();
         check(ssw_reader_create(ctx.get(), image.data.data(), w_, h_, is_base ? 1 : 0, &c, &rd_), "Reader::new_impl");
     }
+    Reader(Context& ctx, const ImageRgb8& image, bool is_base, const ReadConfig& config)
+        : w_(image.width), h_(image.height) {
+        if (image.data.size() != w_ * h_ * 3) throw Error(SSW_ERR_BAD_DIMS, "Reader::new_impl");
+        ssw_config c = config.c();
+        check(ssw_reader_create_rgb8(ctx.get(), image.data.data(), w_, h_, is_base ? 1 : 0, &c, &rd_), "Reader::new_impl");
+    }
     size_t w_, h_;
     ssw_reader* rd_ = nullptr;
 };
@@ -205,6 +236,8 @@ private:
 class ReaderDerived {                                  // algorithm.rs:448-456
 public:
     ReaderDerived(Context& ctx, const ImageRgb32F& image, ssw_precision precision = SSW_PRECISION_F64)
+        : r_(ctx, image, false, [&] { ReadConfig c; c.precision = precision; return c; }()) {}
+    ReaderDerived(Context& ctx, const ImageRgb8& image, ssw_precision precision = SSW_PRECISION_F64)
         : r_(ctx, image, false, [&] { ReadConfig c; c.precision = precision; return c; }()) {}
     std::vector<float> coefficients() const { return r_.coefficients(); }
 

@@ -36,7 +36,7 @@ def test_cpp_doc_test_flow_matches_oracle(tmp_path):
     mark = np.random.default_rng(5).standard_normal(k).astype(np.float32)
     p = lambda n: os.path.join(str(tmp_path), n)
     rgb.tofile(p("rgb.f32")); mark.tofile(p("mark.f32"))
-    out = subprocess.run([exe, p("rgb.f32"), str(w), str(h), p("mark.f32"), str(k), p("marked.f32"), p("ext.f32")],
+    out = subprocess.run([exe, p("rgb.f32"), str(w), str(h), p("mark.f32"), str(k), p("marked.f32"), p("ext.f32"), p("marked8.u8")],
                          check=True, capture_output=True, text=True).stdout.split()
     vals = dict(zip(out[::2], out[1::2]))
     marked = np.fromfile(p("marked.f32"), np.float32).reshape(h, w, 3)
@@ -50,3 +50,10 @@ def test_cpp_doc_test_flow_matches_oracle(tmp_path):
     assert abs(float(vals["random"])) < 5.0
     coef = O.dct2d(O.rgb_to_yiq(rgb)[0])
     assert int(vals["first_index"]) == int(O.indices(coef, k=1)[0])
+    # the 8-bit leg (ImageRgb8 in, mark_rgb8 out): same bytes through the oracle
+    img8 = O.f32_to_u8(rgb)
+    marked8 = np.fromfile(p("marked8.u8"), np.uint8).reshape(h, w, 3)
+    o_marked8 = O.f32_to_u8(O.embed_frame(O.u8_to_f32(img8), mark))
+    assert np.mean(marked8 == o_marked8) >= 0.9999
+    _, o_sim8 = O.extract_frame(O.u8_to_f32(img8), O.u8_to_f32(marked8), mark)
+    assert abs(float(vals["similarity8"]) - o_sim8) < 1e-4 * max(1.0, abs(o_sim8))

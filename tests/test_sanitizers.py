@@ -53,7 +53,8 @@ def test_cpp_host_wrappers_under_asan_ubsan(tmp_path):
     rng.standard_normal(k).astype(np.float32).tofile(tmp_path / "mark.f32")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([exe, str(tmp_path / "rgb.f32"), str(w), str(h), str(tmp_path / "mark.f32"), str(k),
-                        str(tmp_path / "marked.f32"), str(tmp_path / "ext.f32")], capture_output=True, text=True, env=env)
+                        str(tmp_path / "marked.f32"), str(tmp_path / "ext.f32"), str(tmp_path / "marked8.u8")],
+                       capture_output=True, text=True, env=env)
     report = r.stdout[-2000:] + r.stderr[-2000:]
     assert "runtime error:" not in report and "AddressSanitizer" not in report, report
     import torch

@@ -1,2 +1,2 @@
-python tools/dct_microbench.py 3840 2160 64 2 f64 0
-SSW_ONEBLOCK=1 python tools/dct_microbench.py 3840 2160 64 2 f64 0
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/t8.log 2>&1; tail -15 gpurun_out/t8.log
