@@ -28,6 +28,8 @@
 //   the whole plane instead of the candidate list -- slow but exact, and never taken by images.
 #include "ssw_internal.hpp"
 
+#include <type_traits>
+
 namespace ssw {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,7 +37,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DIGIT_BITS = 11;
 constexpr int NBINS = 1 << DIGIT_BITS;          // 2048
 constexpr size_t MAX_K = 16384;                 // 128 KiB of LDS for the in-block sort
-constexpr unsigned SAMPLE_STRIDE = 64;
+// sampling rate of the threshold estimate: one element in 64, or one in 256 for long marks (k >= 4096), whose
+// tail still holds >= 48 samples -- the sample pass pulls a cache line per 16-byte quad it reads, i.e. 1/8 of the
+// plane at rate 1/64 (98 us of a 1.07 ms selection on 32 8K frames with k = 10000)
+constexpr unsigned SAMPLE_STRIDE = 64, SAMPLE_STRIDE_LONG = 256;
+static inline unsigned sample_stride_for(size_t k) { return k >= 4096 ? SAMPLE_STRIDE_LONG : SAMPLE_STRIDE; }
 constexpr unsigned FINISH_THREADS = 1024;
 
 size_t select_max_k() { return MAX_K; }
@@ -137,13 +143,13 @@ __device__ inline void find_threshold_digit(const uint32_t* h, uint32_t m, uint3
 }
 
 __global__ __launch_bounds__(256) void select_sample_kernel(const float* __restrict__ coef, size_t plane_len,
-                                                            KeyParams kp, uint32_t* __restrict__ hist) {
+                                                            KeyParams kp, uint32_t* __restrict__ hist, unsigned sample_stride) {
     __shared__ uint32_t lh[NBINS];
     const size_t f = blockIdx.y;
     for (int i = threadIdx.x; i < NBINS; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     const float* __restrict__ c = coef + f * plane_len;
-    constexpr unsigned GROUP = SAMPLE_STRIDE * 4;                        // 256 elements = 64 quads
+    const unsigned GROUP = sample_stride * 4;                            // one quad out of GROUP / 4 (a power of two)
     const size_t groups = (plane_len + GROUP - 1) / GROUP;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const bool vec = (plane_len % 4 == 0) && ((reinterpret_cast<uintptr_t>(c) & 15) == 0);
@@ -168,22 +174,22 @@ __global__ __launch_bounds__(256) void select_sample_kernel(const float* __restr
     }
 }
 
-// 2. threshold digit of every frame (one block per frame)
-__global__ __launch_bounds__(256) void select_sample_find_kernel(uint32_t* __restrict__ ctrl,
-                                                                 const uint32_t* __restrict__ hist, uint32_t m) {
-    __shared__ uint32_t part[256];
-    find_threshold_digit(hist + (size_t)blockIdx.x * NBINS, m, part, &ctrl[(size_t)blockIdx.x * 4 + 0]);
-}
-
 // 3. the one full pass over the plane: append every coefficient whose top digit >= threshold.
 // ENERGY ordering (the default; keys c*c >= 0, so digit order = float order): the test is one multiply and
 // one float compare against the threshold digit's lower edge, two 16-byte loads in flight per thread.
 template <bool ENERGY>
 __global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ coef, size_t plane_len,
                                                              KeyParams kp, uint32_t* __restrict__ ctrl,
+                                                             const uint32_t* __restrict__ hist, uint32_t m,
                                                              uint64_t* __restrict__ cand, size_t cap) {
     const size_t f = blockIdx.y;
-    const uint32_t thr = ctrl[f * 4 + 0];
+    // 2. the threshold digit, from the frame's sample histogram: every block works it out for itself (8 KB of
+    // L2-resident counts, one wave scan) instead of waiting for a separate one-block-per-frame launch
+    __shared__ uint32_t part[256];
+    __shared__ uint32_t thr_s;
+    find_threshold_digit(hist + f * NBINS, m, part, &thr_s);
+    __syncthreads();
+    const uint32_t thr = thr_s;
     uint32_t* count = &ctrl[f * 4 + 1];
     const float* __restrict__ c = coef + f * plane_len;
     uint64_t* __restrict__ out = cand + f * cap;
@@ -343,6 +349,9 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
         if (tid < k) indices[tid] = ~(uint32_t)(v & 0xFFFFFFFFull);
         return;
     }
+    // more keys than threads: compare-exchanges through LDS.  (A variant with 1024 * R keys in registers -- own keys
+    // in registers, wave partners by shuffle, LDS only from stride 64 R up -- measured SLOWER: 220 vs 176 us for the
+    // k = 10000 finish of an 8K frame; one CU sorting 16384 64-bit keys is bound by its VALU / LDS-crossbar issue.)
     for (unsigned size = 2; size <= n_pow2; size <<= 1) {
         for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
             for (unsigned i = tid; i < n_pow2 / 2; i += blockDim.x) {
@@ -407,24 +416,24 @@ int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, si
                 kp.s[fr][fc] = sc;
             }
     }
-    const size_t groups = (plane_len + SAMPLE_STRIDE * 4 - 1) / (SAMPLE_STRIDE * 4);
+    const unsigned stride_s = sample_stride_for(k);
+    const size_t groups = (plane_len + stride_s * 4 - 1) / (stride_s * 4);
     size_t sb = (groups + 256 * 2 - 1) / (256 * 2);
     if (sb < 1) sb = 1;
     if (sb > 256) sb = 256;
 
     // expected survivors ~ 3k (sampling noise at this depth is ~15 %: falling short of k = 1000 is a
     // -4.6 sigma event, and then the exact whole-plane select still answers); at least 32 samples deep
-    uint32_t m = (uint32_t)((3 * k + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE);
+    uint32_t m = (uint32_t)((3 * k + stride_s - 1) / stride_s);
     if (m < 32) m = 32;
-    select_sample_kernel<<<dim3((unsigned)sb, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.hist);
-    select_sample_find_kernel<<<(unsigned)n_frames, 256, 0, st>>>(ws.ctrl, ws.hist, m);
+    select_sample_kernel<<<dim3((unsigned)sb, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.hist, stride_s);
     size_t bpf = (plane_len + 256 * 32 - 1) / (256 * 32);             // >= 32 elements per thread
     if (bpf < 1) bpf = 1;
     if (bpf > 2048) bpf = 2048;
     if (ordering == SSW_ORDER_ENERGY)
-        select_compact_kernel<true><<<dim3((unsigned)bpf, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.ctrl, ws.cand, ws.cap);
+        select_compact_kernel<true><<<dim3((unsigned)bpf, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.ctrl, ws.hist, m, ws.cand, ws.cap);
     else
-        select_compact_kernel<false><<<dim3((unsigned)bpf, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.ctrl, ws.cand, ws.cap);
+        select_compact_kernel<false><<<dim3((unsigned)bpf, (unsigned)n_frames), 256, 0, st>>>(coef, plane_len, kp, ws.ctrl, ws.hist, m, ws.cand, ws.cap);
     unsigned n_pow2 = 2;
     while (n_pow2 < k) n_pow2 <<= 1;
     const size_t smem = (size_t)(n_pow2 > FINISH_THREADS ? n_pow2 : FINISH_THREADS) * sizeof(uint64_t) + 8 * sizeof(uint64_t) +
