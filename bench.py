@@ -305,11 +305,12 @@ def handle_api_leg(wm, L, lib, ctx, check, rgb0_dev, W, H, K, precision, reps=5)
     out = {"frame": f"{W}x{H}", "k": K, "reps": reps, "dtype": precision,
            "flow": "Writer::new + mark [+ into_rgb8] | Reader::base + Reader::derived + extract + Tester::similarity, "
                    "one host image per call, host buffers in and out (PCIe included)"}
-    out["rgb8_pageable"], marked8, ext8 = run(img8, None, True)
+    # pageable legs: ordinary numpy arrays, the output array allocated once and reused like a caller's frame buffer
+    out["rgb8_pageable"], marked8, ext8 = run(img8, np.empty_like(img8), True)
     pin_in, pin_out = ctx.pinned_empty(img8.shape, np.uint8), ctx.pinned_empty(img8.shape, np.uint8)
     pin_in[...] = img8
     out["rgb8_pinned"], marked8p, ext8p = run(pin_in, pin_out, True)
-    out["f32_pageable"], _, _ = run(img32, None, False)
+    out["f32_pageable"], _, _ = run(img32, np.empty_like(img32), False)
     # the handles against the batch entry points on the same bytes (n = 1): bit for bit
     cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, prec)
     marks_dev = torch.from_numpy(mark[None]).to(rgb0_dev.device)

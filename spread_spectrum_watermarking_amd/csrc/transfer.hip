@@ -22,8 +22,13 @@ namespace host {
 
 namespace {
 constexpr size_t SUB = (size_t)1 << 20;          // piece one host thread copies at a time
-constexpr size_t SUBS_PER_SLICE = 4;             // one DMA per 4 MiB slice
-constexpr size_t SLICE = SUB * SUBS_PER_SLICE;
+// one DMA per slice of SUBS_PER_SLICE pieces (4 MiB by default; SSW_COPY_SLICE_MB: 1 .. 64)
+static const size_t SUBS_PER_SLICE = [] {
+    const char* e = std::getenv("SSW_COPY_SLICE_MB");
+    size_t v = e ? (size_t)std::atoi(e) : 4;
+    return v < 1 ? (size_t)1 : (v > 64 ? (size_t)64 : v);
+}();
+#define SLICE (SUB * SUBS_PER_SLICE)
 constexpr size_t PIECE = (size_t)64 << 20;       // size of one pinned staging buffer
 constexpr int RING = 3;
 constexpr size_t SMALL = (size_t)256 << 10;      // below this a plain pageable copy is as fast
@@ -48,7 +53,7 @@ struct Transfer {
         size_t bytes = 0, n_sub = 0;
         std::atomic<size_t> next_sub{0};
         std::atomic<size_t> ready_sub{0};              // pieces whose source is valid (download: DMA landed)
-        std::atomic<uint32_t> done[PIECE / SLICE];     // pieces finished, per slice
+        std::atomic<uint32_t> done[PIECE / SUB];       // pieces finished, per slice
         std::atomic<int> users{0};
     };
     std::vector<std::thread> workers;
@@ -263,7 +268,7 @@ int download(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hi
         if (bytes >= SMALL) t->stats[SSW_TRANSFER_DIRECT_BYTES] += (double)bytes;
         return SSW_OK;
     }
-    constexpr size_t SLICES = PIECE / SLICE;
+    const size_t SLICES = PIECE / SUB;                 // event slots per staging buffer (>= slices of a piece)
     while (t->slice_ev.size() < SLICES * RING) {
         hipEvent_t e = nullptr;
         SSW_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
