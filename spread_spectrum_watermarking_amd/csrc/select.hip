@@ -28,6 +28,8 @@
 //   the whole plane instead of the candidate list -- slow but exact, and never taken by images.
 #include "ssw_internal.hpp"
 
+#include <atomic>
+
 #include <type_traits>
 
 namespace ssw {
@@ -440,13 +442,13 @@ int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, si
                         (NBINS + 256) * sizeof(uint32_t);
     constexpr size_t LDS_LIMIT = 160 * 1024;
     {   // the dynamic-LDS ceiling is a per-device function attribute: set it once on every device used
-        static bool attr_set[64] = {false};
+        static std::atomic<bool> attr_set[64];           // contexts on several host threads: no plain bools
         int dev = 0;
         SSW_HIP_CHECK(hipGetDevice(&dev));
-        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
             SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(select_finish_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+            if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
     }
     select_finish_kernel<<<(unsigned)n_frames, FINISH_THREADS, smem, st>>>(coef, plane_len, kp, ws.ctrl, ws.hist,

@@ -40,7 +40,7 @@ run_bench config2_n1 --config 2 --steps 10 --warmup 3
 run_bench config1_n1 --config 1 --steps 20 --warmup 5
 run_bench config4_n1 --config 4 --steps 3 --warmup 1
 # 2. kernel stats of the same commands (one chunk-pair worth of steps)
-SHORT="--no-cpu-baseline --no-alt --no-serial-leg --no-timers-off-leg"
+SHORT="--no-cpu-baseline --no-alt --no-serial-leg --no-timers-off-leg --no-handle-leg --no-full-transform-leg"
 stats config3 --steps 3 --warmup 1 $SHORT
 stats config3_serial --steps 3 --warmup 1 --no-overlap $SHORT
 stats config2 --config 2 --steps 3 --warmup 1 $SHORT
