@@ -119,8 +119,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     // The wave grid is 2 x 2 (each wave BM/2 lines x 32 pairs: NI = BM/32 line tiles) unless the tile holds at
     // most 32 valid pairs -- the last tile column of e.g. 540 pairs -- where it is 4 x 1 (each wave
     // BM/4 lines x 32 pairs: NI = BM/64) and the tile takes half the MFMAs instead of computing padding.
-    auto run = [&](auto nic) {
+    auto run = [&](auto nic, auto njc) {
     constexpr int NI = decltype(nic)::value;
+    constexpr int NJ = decltype(njc)::value;                 // pair tiles of 16 per wave: 2, or 1 when the tile holds <= 16 valid pairs
     constexpr bool FULL = NI == BM / 32;
     const unsigned wm = FULL ? (wave >> 1) * (BM / 2) : wave * (BM / 4), wn = FULL ? (wave & 1) * 32 : 0;
     f64x4 acc1[NI][2], acc2[NI][2];
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         constexpr int cur = decltype(bufc)::value;
         constexpr int sh = decltype(shc)::value;
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
+        for (int jn = 0; jn < NJ; ++jn) {
             f.y1[jn] = sY[cur][0][rdy[sh] + 16 * jn * PBK];
             f.y2[jn] = sY[cur][1][rdy[sh] + 16 * jn * PBK];
         }
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn) {
+            for (int jn = 0; jn < NJ; ++jn) {
                 const double xb = SAMEX ? f.x1[i] : f.x2[i];
                 if (!COLS) {      // D[row = line][col = pair]
                     acc1[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.x1[i], f.y1[jn], acc1[i][jn], 0, 0, 0);
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     // wave at the LDS queue with its MFMAs behind it), then the staging writes two per MFMA
     auto interleave = [&](auto storec) {
         constexpr bool STORE = decltype(storec)::value != 0;
-        constexpr int NMF = 4 * NI;                             // MFMAs per half-step
-        constexpr int NRD = (4 + NI * NX) / 2;                  // ds_read2_b64 per half-step (fragments pair up)
+        constexpr int NMF = 2 * NJ * NI;                        // MFMAs per half-step
+        constexpr int NRD = (2 * NJ + NI * NX + 1) / 2;         // ds_read2_b64 per half-step (fragments pair up)
 #pragma unroll
         for (int i = 0; i < NRD; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     };
     if constexpr (!COLS) {
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
+        for (int jn = 0; jn < NJ; ++jn) {
             const unsigned pair = p0 + wn + 16 * jn + li;
             if (pair >= NP) continue;
 #pragma unroll
@@ -288,7 +289,51 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                     emit(po.out + (size_t)row * W, po.tmp + (size_t)row * (n / 2), 1, pair, acc1[i][jn][r], acc2[i][jn][r]);
                 }
         }
-    } else if constexpr (EPI != EPI_INV_E) {
+    } else if constexpr (EPI == EPI_INV_E) {
+      if (po.wide) {
+        // The even half E of a two-level inverse column pass leaves unrounded, as doubles: T[pair] = a1 + a2,
+        // T[n/2-1-pair] = a1 - a2.  Same idea as below with 8-byte elements: per round 16 result rows x CW columns of
+        // one sign go through LDS (pitch CW doubles: a 16-lane ds_write_b64 group covers one 128-byte bank window)
+        // and every lane stores two doubles: 512-byte row segments instead of 128-byte ones, half the stores.
+        constexpr int CW = 16 * NI, DPR = CW / 2, RPI = 64 / DPR, NRI = 16 / RPI;   // double pairs per row, rows per read
+        static_assert(4 * 16 * CW * 8 <= (int)sizeof(lds), "transpose area");
+        __syncthreads();
+        double* tw = lds + wave * (16 * CW);
+        const unsigned wr0 = lq * CW + li;                                 // + (4 r) * CW + 16 i
+        const unsigned dq = lane % DPR, rrow = lane / DPR;
+        const unsigned line = m0 + wm + 2 * dq;                            // = frame * W + column, even
+        const bool line_ok = line < L;
+        const unsigned z = line_ok ? line / W : 0, col = line_ok ? line - z * W : 0;
+        double* tbase = po.tmp + (size_t)z * (n / 2) * W + col;
+        const double* trd = tw + rrow * CW + 2 * dq;
+        auto lds_order = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+            for (int sign = 0; sign < 2; ++sign) {
+                lds_order();
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        tw[wr0 + (4 * r) * CW + 16 * i] = sign ? acc1[i][jn][r] - acc2[i][jn][r] : acc1[i][jn][r] + acc2[i][jn][r];
+                lds_order();
+#pragma unroll
+                for (int t = 0; t < NRI; ++t) {
+                    const unsigned pair = p0 + wn + 16 * jn + t * RPI + rrow;
+                    const f64x2 v = *reinterpret_cast<const f64x2*>(trd + t * RPI * CW);
+                    if (!line_ok || pair >= NP) continue;
+                    const unsigned idx = sign ? n / 2 - 1 - pair : pair;
+                    *reinterpret_cast<f64x2*>(tbase + (size_t)idx * W) = v;
+                }
+            }
+        return;
+      }
+    } else {
       if (po.wide) {
         // Column pass, wide stores.  A D tile has the image columns along the lanes, 16 at a time: stored as it is, a
         // wave writes 64-byte pieces (half cache lines, measured: the write traffic of such an epilogue costs the
@@ -332,7 +377,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int jn = 0; jn < 2; ++jn)
+                    for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const double a1 = acc1[i][jn][r], a2 = acc2[i][jn][r];
@@ -356,7 +401,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #pragma unroll
             for (int half = 0; half < 2; ++half)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
+                for (int jn = 0; jn < NJ; ++jn) {
                     double e[NI][4];
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
@@ -409,7 +454,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 // offsets from the frame's pixel (row 0, col) address I, Q and RGB alike
                 const size_t base = (size_t)z * H * W + col;
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn)
+                for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
                         double e1[2], e2[2];
@@ -439,7 +484,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 continue;
             }
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
+            for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
@@ -449,8 +494,13 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         }
     }
     };
-    if (NP - p0 <= 32) run(std::integral_constant<int, BM / 64>{});
-    else               run(std::integral_constant<int, BM / 32>{});
+    // (a tail of at most 16 pairs -- 270 = 4 x 64 + 14 at full HD, the 16-pair classes of the pruned transform -- runs
+    // one 16-pair MFMA tile per wave instead of two)
+    using J1 = std::integral_constant<int, 1>;
+    using J2 = std::integral_constant<int, 2>;
+    if (NP - p0 <= 16)      run(std::integral_constant<int, BM / 64>{}, J1{});
+    else if (NP - p0 <= 32) run(std::integral_constant<int, BM / 64>{}, J2{});
+    else                    run(std::integral_constant<int, BM / 32>{}, J2{});
 }
 
 
@@ -488,7 +538,7 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0) ? 1u : 0u;
+    po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16))) ? 1u : 0u;
     if (sink && sink->rgb && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;
     if ((unsigned long long)Kp * L * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
 #define SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, SUBV, BMV) \

@@ -258,7 +258,11 @@ def test_second_embed_and_multi_mark_still_follow_the_reference():
 
 def test_context_creation_keeps_the_callers_device():
     """ssw_ctx_create restores the calling thread's current HIP device; a bad ordinal is an argument error."""
-    hip = C.CDLL("libamdhip64.so")
+    L.load()
+    # the HIP runtime instance libssw_hip.so is linked against (dlopen of an already loaded path returns that instance;
+    # a bare "libamdhip64.so" could resolve to a second copy, e.g. torch's, with its own idea of the current device)
+    paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64.so" in l})
+    hip = C.CDLL(paths[0] if paths else "libamdhip64.so")
     dev = C.c_int(-1)
     assert hip.hipGetDevice(C.byref(dev)) == 0
     before = dev.value
