@@ -5,7 +5,7 @@
 // this host.  This file replaces it with
 //   * a direct DMA when the caller's buffer is pinned (ssw_host_alloc, hipHostMalloc, hipHostRegister),
 //   * otherwise a ring of pinned staging buffers filled by a few host threads in 1 MiB pieces, the DMA of
-//     a 4 MiB slice starting as soon as its pieces are in (upload), or the pieces of a slice being copied
+//     an 8 MiB slice starting as soon as its pieces are in (upload), or the pieces of a slice being copied
 //     out as soon as its DMA has landed (download) -- host copy and PCIe run concurrently.
 // An upload returns when the caller's buffer may be reused, NOT when the device has the data: that is
 // ordered on the stream it was given (the staging buffer is guarded by an event).
@@ -22,10 +22,11 @@ namespace host {
 
 namespace {
 constexpr size_t SUB = (size_t)1 << 20;          // piece one host thread copies at a time
-// one DMA per slice of SUBS_PER_SLICE pieces (4 MiB by default; SSW_COPY_SLICE_MB: 1 .. 64)
+// one DMA per slice of SUBS_PER_SLICE pieces (8 MiB by default -- 4 .. 8 MiB measured best for 25 MB frames, smaller
+// slices pay per-call overhead, larger ones start the DMA late; SSW_COPY_SLICE_MB: 1 .. 64)
 static const size_t SUBS_PER_SLICE = [] {
     const char* e = std::getenv("SSW_COPY_SLICE_MB");
-    size_t v = e ? (size_t)std::atoi(e) : 4;
+    size_t v = e ? (size_t)std::atoi(e) : 8;
     return v < 1 ? (size_t)1 : (v > 64 ? (size_t)64 : v);
 }();
 #define SLICE (SUB * SUBS_PER_SLICE)

@@ -1,17 +1,9 @@
-mkdir -p gpurun_out
-run() {
-  python bench.py $EXTRA --steps 3 --warmup 1 --no-cpu-baseline --no-alt --no-handle-leg --no-full-transform-leg --no-timers-off-leg --no-serial-leg > gpurun_out/p.json 2>/dev/null
-  python - <<PY
-import json
-r=json.load(open("gpurun_out/p.json")); k=r["kernels"]; s=r["stage_ms_per_step"]
-print("$1 value", r["value"], "ms", r["ms_per_step"], "row", s["dct_row"], "col", s["dct_col"], "rgb", s["rgb_to_yiq"], "prep", s["dct_prep"], "sel", s["select"])
+python - <<PY
+import ctypes as C, time
+hip=C.CDLL("/opt/rocm/lib/libamdhip64.so")
+ev=C.c_void_p(); hip.hipEventCreate(C.byref(ev))
+t0=time.perf_counter()
+for _ in range(2000): hip.hipEventRecord(ev, None); hip.hipEventQuery(ev)
+print("hipEventRecord+Query: %.1f us" % ((time.perf_counter()-t0)/2000*1e6))
 PY
-}
-EXTRA=""; run "chunk128 serial     "
-EXTRA="--chunk 64"; run "chunk64 two lanes   "
-EXTRA="--chunk 64 --no-overlap"; run "chunk64 one lane    "
-export SSW_ONEBLOCK=60
-EXTRA="--chunk 64"; run "chunk64 2 lanes 1blk "
-export SSW_ONEBLOCK=44
-EXTRA="--chunk 64"; run "chunk64 2 lanes 1blk44"
-EXTRA="--chunk 43"; run "chunk43 2 lanes 1blk44"
+for mb in 4 8 16; do echo "slice $mb MiB"; SSW_COPY_SLICE_MB=$mb python tools/handle_bench.py 2>&1 | grep -E "4 copy|u8 pinned"; done
