@@ -311,6 +311,36 @@ def handle_api_leg(wm, L, lib, ctx, check, rgb0_dev, W, H, K, precision, reps=5)
     pin_in[...] = img8
     out["rgb8_pinned"], marked8p, ext8p = run(pin_in, pin_out, True)
     out["f32_pageable"], _, _ = run(img32, np.empty_like(img32), False)
+    # two host threads with a context each (ctypes releases the GIL inside the library): one thread's transfers run
+    # beside the other's kernels -- what a caller with a queue of images gets from the same single-image API
+    import threading
+    n_thr, times = 2, []
+    gate = threading.Barrier(n_thr)
+
+    def worker():
+        c = wm.Context(ctx.device_id)
+        pi, po = c.pinned_empty(img8.shape, np.uint8), c.pinned_empty(img8.shape, np.uint8)
+        pi[...] = img8
+        def once():
+            m = wm.Writer(pi, wcfg, c).mark_rgb8([mark], out=po)
+            e = wm.Reader.base(pi, rcfg, c).extract(wm.Reader.derived(m, c, prec), K)
+            return wm.Tester(e, c).similarity(mark).similarity
+        once(); once()
+        gate.wait()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            once()
+        times.append(time.perf_counter() - t0)
+        del pi, po
+        c.close()
+    threads = [threading.Thread(target=worker) for _ in range(n_thr)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if len(times) == n_thr:
+        out["rgb8_pinned_two_threads"] = {"threads": n_thr, "embed_extract_mpix_s": round(px * reps * n_thr / max(times), 1),
+                                          "note": "one context per host thread, same GPU; aggregate over both threads"}
     # the handles against the batch entry points on the same bytes (n = 1): bit for bit
     cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, prec)
     marks_dev = torch.from_numpy(mark[None]).to(rgb0_dev.device)

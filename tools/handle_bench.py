@@ -64,6 +64,37 @@ bench("u8 pinned", p_in, True, p_out)
 p32_in, p32_out = ctx.pinned_empty(rgb32.shape, np.float32), ctx.pinned_empty(rgb32.shape, np.float32)
 p32_in[...] = rgb32
 bench("f32 pinned", p32_in, False, p32_out)
+# two host threads, one context each (contexts are independent; ctypes releases the GIL inside the library): the
+# transfers of one thread's image overlap the kernels of the other's
+import threading
+
+
+def worker(n, out):
+    c = wm.Context(0)
+    pi, po = c.pinned_empty(rgb8.shape, np.uint8), c.pinned_empty(rgb8.shape, np.uint8)
+    pi[...] = rgb8
+    for _ in range(2):                                   # warm-up: bases, staging ring, plane pool of this context
+        m = wm.Writer(pi, ctx=c).mark_rgb8([mark], out=po)
+        wm.Reader.base(pi, ctx=c).extract(wm.Reader.derived(m, c), K)
+    barrier.wait()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        m = wm.Writer(pi, ctx=c).mark_rgb8([mark], out=po)
+        e = wm.Reader.base(pi, ctx=c).extract(wm.Reader.derived(m, c), K)
+        wm.Tester(e, c).similarity(mark)
+    out.append(time.perf_counter() - t0)
+    del pi, po
+    c.close()
+
+
+for n_thr in (1, 2, 3):
+    res = []
+    barrier = threading.Barrier(n_thr)
+    th = [threading.Thread(target=worker, args=(REPS, res)) for _ in range(n_thr)]
+    for t in th: t.start()
+    for t in th: t.join()
+    dt = max(res)
+    print(f"{n_thr} host thread(s) x own context, u8 pinned: embed+extract {px * REPS * n_thr / dt:6.0f} Mpix/s")
 ctx.enable_timing(True); ctx.reset_timing()
 wr = wm.Writer(p_in, ctx=ctx); m = wr.mark_rgb8([mark], out=p_out)
 b = wm.Reader.base(p_in, ctx=ctx); e = b.extract(wm.Reader.derived(m, ctx), K)
