@@ -49,6 +49,9 @@ struct PairOutT {
     // column passes: results leave through an LDS transpose as 16-byte pieces of whole output rows (W % 4 == 0 and
     // 16-byte aligned planes; 4-byte aligned 8-bit RGB), decided by the launcher
     unsigned wide = 0;
+    // block tiles of 32 instead of 64 pairs (every tile runs the 4 x 1 wave layout): small launches whose 64-pair
+    // grid would load the CUs unevenly -- a single 4K frame's column pass is 60 x 9 = 540 blocks for 256 CUs
+    unsigned bn32 = 0;
 };
 
 // yiq.rs:139-147 (f32::clamp) and :163-165, :173-175: the arithmetic of color.hip / attack.hip, per pixel

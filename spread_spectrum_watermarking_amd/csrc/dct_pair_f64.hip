@@ -61,7 +61,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 
     unsigned tm, tn;
     tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
-    const unsigned m0 = tm * BM, p0 = tn * BN;
+    const unsigned m0 = tm * BM, p0 = tn * (po.bn32 ? 32u : (unsigned)BN);
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
     const unsigned li = lane & 15, lq = lane >> 4;
@@ -498,9 +498,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     // one 16-pair MFMA tile per wave instead of two)
     using J1 = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>;
-    if (NP - p0 <= 16)      run(std::integral_constant<int, BM / 64>{}, J1{});
-    else if (NP - p0 <= 32) run(std::integral_constant<int, BM / 64>{}, J2{});
-    else                    run(std::integral_constant<int, BM / 32>{}, J2{});
+    if (NP - p0 <= 16)                 run(std::integral_constant<int, BM / 64>{}, J1{});
+    else if (NP - p0 <= 32 || po.bn32) run(std::integral_constant<int, BM / 64>{}, J2{});
+    else                               run(std::integral_constant<int, BM / 32>{}, J2{});
 }
 
 
@@ -526,17 +526,29 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     const unsigned NP = (unsigned)(kind == 0 ? leff / 2 : leff / 4);
     const unsigned Kp = (unsigned)(kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
     const unsigned BN = 64;
-    const unsigned tiles_n = (NP + BN - 1) / BN;
+    unsigned tiles_n = (NP + BN - 1) / BN;
     // 64-line tiles when 128-line ones would not fill the 512 block slots of the chip (2 per CU)
     const bool small = (unsigned long long)((L + 127) / 128) * tiles_n < 448;
     const unsigned BM = small ? 64 : 128;
     const unsigned tiles_m = (L + BM - 1) / BM;
+    // ... and 32-pair tiles when that spreads such a launch more evenly over the 256 CUs (all its blocks are resident
+    // at once, so a launch takes as long as the fullest CU): balance = blocks / (256 * ceil(blocks / 256)); the smaller
+    // tiles reuse their basis fragments less, hence the 8 % handicap
+    bool bn32 = false;
+    if (small) {
+        static const int force = [] { const char* e = std::getenv("SSW_BN32"); return e ? std::atoi(e) : -1; }();
+        auto balance = [](unsigned long long n) { return (double)n / (256.0 * (double)((n + 255) / 256)); };
+        const unsigned tn32 = (NP + 31) / 32;
+        bn32 = force >= 0 ? force != 0 : 0.92 * balance((unsigned long long)tiles_m * tn32) > balance((unsigned long long)tiles_m * tiles_n);
+        if (bn32) tiles_n = tn32;
+    }
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)len, 0, 1, 2};
     if (kind == 1) { po.c1 = 0; po.c2 = 2 * fs; po.cs = 4 * fs; }
     if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
+    po.bn32 = bn32 ? 1u : 0u;
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16))) ? 1u : 0u;
     if (sink && sink->rgb && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;
