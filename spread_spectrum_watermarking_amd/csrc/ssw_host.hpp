@@ -98,6 +98,11 @@ bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float*
 // rgb -> Y (+ I, Q) -> forward transform of Y into `y` (Writer::new / Reader::new_impl), fused where possible
 int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t n, size_t w,
                            size_t h, float* y, float* i, float* q, float* tmp, Chain& ch);
+// the same transform as two chains: the row pass of a band of image rows, and the column pass of the whole frame
+bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8);
+int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t w, size_t rows,
+                            float* tmp, float* i, float* q, Chain& ch);
+int build_forward_cols_after_rows(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, size_t w, size_t h, float* tmp, float* y, Chain& ch);
 int run_serial(Chain& ch, hipStream_t st);
 // transform now, on the context's stream, with lane 0's workspace (handles, ssw_dct2d)
 int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size_t h, float* data, float* tmp);

@@ -248,7 +248,8 @@ struct ssw_ctx {
     hipStream_t copy_stream = nullptr;
     struct FrameStage {
         Buf buf;
-        hipEvent_t uploaded = nullptr;    // copy_stream: the frame is in the buffer
+        hipEvent_t uploaded = nullptr;    // copy_stream: the frame (or its top half) is in the buffer
+        hipEvent_t uploaded2 = nullptr;   // copy_stream: the bottom half (frames uploaded in two bands)
         hipEvent_t consumed = nullptr;    // stream: the last kernel that reads (or writes) the buffer is enqueued before
         bool in_use = false;              // `consumed` has been recorded at least once
     };

@@ -95,6 +95,7 @@ void pool_put(ssw_ctx* ctx, void* p, size_t bytes) {
 // ---- frames in and out of the device ------------------------------------------------------------
 int frame_stage_events(ssw_ctx::FrameStage& fs) {
     if (!fs.uploaded) SSW_HIP_CHECK(hipEventCreateWithFlags(&fs.uploaded, hipEventDisableTiming));
+    if (!fs.uploaded2) SSW_HIP_CHECK(hipEventCreateWithFlags(&fs.uploaded2, hipEventDisableTiming));
     if (!fs.consumed) SSW_HIP_CHECK(hipEventCreateWithFlags(&fs.consumed, hipEventDisableTiming));
     return SSW_OK;
 }
@@ -122,12 +123,41 @@ int stage_consumed(ssw_ctx* ctx, ssw_ctx::FrameStage& fs) {
 int forward_from_host(ssw_ctx* ctx, const void* host_rgb, bool u8, size_t w, size_t h, int precision, float* y, float* i,
                       float* q) {
     const size_t plane = w * h;
+    const size_t bytes = plane * 3 * (u8 ? 1 : sizeof(float));
     SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
+    float* tmp = (float*)ctx->lane[0].plane[3].p;
+    {
+        // Two bands: the row pass of the top half of the frame runs while the bottom half is still crossing PCIe
+        // (image rows are independent lines of a row pass: same values), then the column pass of the whole frame.
+        ssw_ctx::FrameStage& fs = ctx->frame_stage[ctx->frame_stage_next & 1];
+        SSW_TRY(grow(fs.buf, bytes));
+        static const bool no_split = std::getenv("SSW_NO_SPLIT") != nullptr;      // A/B switch
+        if (!no_split && bytes >= ((size_t)8 << 20) &&
+            can_split_forward_rows(ctx, precision == SSW_PRECISION_F64, w, h, y, tmp, fs.buf.p, u8)) {
+            ++ctx->frame_stage_next;
+            SSW_TRY(frame_stage_events(fs));
+            if (fs.in_use) SSW_HIP_CHECK(hipStreamWaitEvent(ctx->copy_stream, fs.consumed, 0));
+            const size_t hb = bytes / 2, hp = plane / 2;
+            for (int band = 0; band < 2; ++band) {
+                hipEvent_t ev = band ? fs.uploaded2 : fs.uploaded;
+                SSW_TRY(upload(ctx, (char*)fs.buf.p + band * hb, (const char*)host_rgb + band * hb, hb, ctx->copy_stream));
+                SSW_HIP_CHECK(hipEventRecord(ev, ctx->copy_stream));
+                SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
+                Chain ch;
+                SSW_TRY(build_forward_rows_band(ctx, ctx->lane[0], precision, (char*)fs.buf.p + band * hb, u8, w, h / 2, tmp + band * hp,
+                                                i ? i + band * hp : nullptr, q ? q + band * hp : nullptr, ch));
+                SSW_TRY(run_serial(ch, ctx->stream));
+            }
+            SSW_TRY(stage_consumed(ctx, fs));
+            Chain ch;
+            SSW_TRY(build_forward_cols_after_rows(ctx, ctx->lane[0], precision, w, h, tmp, y, ch));
+            return run_serial(ch, ctx->stream);
+        }
+    }
     ssw_ctx::FrameStage* fs = nullptr;
-    SSW_TRY(stage_frame_in(ctx, host_rgb, plane * 3 * (u8 ? 1 : sizeof(float)), &fs));
+    SSW_TRY(stage_frame_in(ctx, host_rgb, bytes, &fs));
     Chain ch;
-    SSW_TRY(build_forward_from_rgb(ctx, ctx->lane[0], precision, fs->buf.p, u8, 1, w, h, y, i, q,
-                                   (float*)ctx->lane[0].plane[3].p, ch));
+    SSW_TRY(build_forward_from_rgb(ctx, ctx->lane[0], precision, fs->buf.p, u8, 1, w, h, y, i, q, tmp, ch));
     SSW_TRY(run_serial(ch, ctx->stream));
     return stage_consumed(ctx, *fs);
 }
@@ -213,6 +243,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     for (auto& fs : ctx->frame_stage) {
         release(fs.buf);
         if (fs.uploaded) (void)hipEventDestroy(fs.uploaded);
+        if (fs.uploaded2) (void)hipEventDestroy(fs.uploaded2);
         if (fs.consumed) (void)hipEventDestroy(fs.consumed);
     }
     for (auto& kv : ctx->basis) (void)hipFree(kv.second);

@@ -401,6 +401,24 @@ int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const
     return build_transform(ctx, ws, x, ch);
 }
 
+// The two passes of a rows-first forward transform from RGB as separate chains (single-image handles: the row pass
+// of the top half of a frame runs while the bottom half is still crossing PCIe -- image rows are independent lines
+// of a row pass, so any band of rows gives the values the whole frame gives).  `rows` consecutive image rows starting
+// at `rgb` -> the same rows of the intermediate plane `tmp` (+ I, Q); then the column pass tmp -> y on the whole frame.
+bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8) {
+    return w >= h && h % 16 == 0 && can_fuse_rgb(ctx, f64, w, h, y, tmp, rgb, u8) && can_fuse_rgb(ctx, f64, w, h / 2, y, tmp, rgb, u8);
+}
+int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t w, size_t rows,
+                            float* tmp, float* i, float* q, Chain& ch) {
+    Xform x{SSW_DCT2, precision, 1, w, rows, tmp /* never read or written by this pass */, tmp};
+    x.rgb = rgb; x.rgb_u8 = u8; x.iq_i = i; x.iq_q = q;
+    return build_pass(ctx, ws, x, true, true, tmp, tmp, Epilogue{1.f, 1.f}, ch);
+}
+int build_forward_cols_after_rows(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, size_t w, size_t h, float* tmp, float* y, Chain& ch) {
+    Xform x{SSW_DCT2, precision, 1, w, h, y, tmp};
+    return build_pass(ctx, ws, x, false, false, tmp, y, Epilogue{1.f, 1.f}, ch);
+}
+
 int run_serial(Chain& ch, hipStream_t st) {
     for (auto& s : ch) SSW_TRY(s.run(st));
     return SSW_OK;
