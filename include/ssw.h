@@ -132,7 +132,9 @@ int ssw_ctx_record_event(ssw_ctx* ctx, void* hip_event);
    pixel of a pass in the default GEMM strategy, per lane -- see ssw_ctx_set_overlap).  0 = automatic, the
    default: about 2^30 pixels per pass (128 4K frames, 514 full-HD frames, 32 8K frames; 38.7 GB of
    workspace per lane): sized for the 288 GB of an MI355X, where longer GEMM launches amortise their tails
-   (2^28 pixels cost 2.8 % at 4K, 1.8 % at full HD).  Smaller devices / co-tenants: set it explicitly. */
+   (2^28 pixels cost 2.8 % at 4K, 1.8 % at full HD).  The automatic size never asks for more than half of what
+   the device can give at the time of the call (free memory + what the context already holds): a smaller device
+   or a co-tenant gets smaller passes, not SSW_ERR_OUT_OF_MEMORY. */
 int ssw_ctx_set_chunk_frames(ssw_ctx* ctx, size_t frames);
 /* Frames per pass a batch call over n_frames frames of w x h would use with the current setting. */
 size_t ssw_ctx_pass_frames(ssw_ctx* ctx, size_t n_frames, size_t w, size_t h);
