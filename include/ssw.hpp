@@ -63,9 +63,33 @@ public:
     size_t pass_frames(size_t n_frames, size_t w, size_t h) const { return ssw_ctx_pass_frames(ctx_, n_frames, w, h); }
     void set_overlap(bool on) { check(ssw_ctx_set_overlap(ctx_, on ? 1 : 0), "ssw_ctx_set_overlap"); }
     void set_prune(bool on) { check(ssw_ctx_set_prune(ctx_, on ? 1 : 0), "ssw_ctx_set_prune"); }
+    // Host-buffer entry points: copy threads of the pinned staging ring (0 = automatic) and the transfer counters.
+    void set_copy_threads(int n) { check(ssw_ctx_set_copy_threads(ctx_, n), "ssw_ctx_set_copy_threads"); }
+    std::vector<double> transfer_stats(bool reset = false) {
+        std::vector<double> st(SSW_TRANSFER_STAT_COUNT);
+        check(ssw_ctx_get_transfer_stats(ctx_, st.data(), reset ? 1 : 0), "ssw_ctx_get_transfer_stats");
+        return st;
+    }
 
 private:
     ssw_ctx* ctx_ = nullptr;
+};
+
+// Pinned (page-locked) host memory from the context: an image decoded into it is the DMA source / target of the
+// handles, no staging copy (include/ssw.h: ssw_host_alloc).
+class PinnedBuffer {
+public:
+    PinnedBuffer(Context& ctx, size_t bytes) : ctx_(ctx.get()), bytes_(bytes) { check(ssw_host_alloc(ctx_, bytes, &p_), "ssw_host_alloc"); }
+    ~PinnedBuffer() { ssw_host_free(ctx_, p_); }
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    void* data() { return p_; }
+    size_t size() const { return bytes_; }
+
+private:
+    ssw_ctx* ctx_;
+    void* p_ = nullptr;
+    size_t bytes_;
 };
 
 // Insertion / Extraction (algorithm.rs:68-77, :115-124).  Custom(closure) exists in the reference;
