@@ -78,6 +78,40 @@ def test_alloc_failure_is_out_of_memory_and_recoverable():
     buf.free()
 
 
+def test_automatic_pass_size_shrinks_when_device_memory_is_short():
+    """the automatic pass size (2^30 pixels, 36 B/px of workspace per lane) is clamped to half of what the
+    device can give -- free memory plus what the context already holds -- so a nearly full device gets smaller passes
+    instead of SSW_ERR_OUT_OF_MEMORY, with bit-identical results."""
+    w, h, n, k = 1920, 1080, 60, 200
+    ctx = wm.Context(0)
+    lib = ctx._lib
+    try:
+        rgb = G.synth(6, 0, n, w, h)
+        marks = np.random.default_rng(6).standard_normal((n, k)).astype(np.float32)
+        cfg = G.default_config()
+        d, dm = ctx.to_device(rgb), ctx.to_device(marks)
+        out = ctx.alloc(rgb.nbytes)
+
+        def run():
+            check(lib.ssw_batch_embed(ctx.handle, C.byref(cfg), d.ptr, n, w, h, dm.ptr, k, out.ptr, None, None), "embed")
+            return out.to_host(np.float32, rgb.shape)
+        assert ctx.pass_frames(n, w, h) == n                      # plenty of memory: one pass
+        want = run()
+        free, _ = ctx.mem_info()
+        hog = ctx.alloc(free - (3 << 30))                         # leave ~3 GB + the ~4.7 GB workspace the context holds
+        try:
+            short = ctx.pass_frames(n, w, h)
+            assert 1 <= short < n                                 # (3 + 4.7) / 2 GB over 36 B/px of 1080p frames: ~50
+            got = run()
+        finally:
+            hog.free()
+        assert np.array_equal(got, want)
+        for b in (d, dm, out):
+            b.free()
+    finally:
+        ctx.close()
+
+
 def test_second_embed_ranks_the_original_coefficients():
     """Writer::new fixes the ordering once (algorithm.rs:314); embed() twice must not re-rank the
     modified plane."""
