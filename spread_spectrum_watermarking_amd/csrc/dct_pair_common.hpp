@@ -52,6 +52,12 @@ struct PairOutT {
     // block tiles of 32 instead of 64 pairs (every tile runs the 4 x 1 wave layout): small launches whose 64-pair
     // grid would load the CUs unevenly -- a single 4K frame's column pass is 60 x 9 = 540 blocks for 256 CUs
     unsigned bn32 = 0;
+    // split odd half (dct_pair_f64.hip, "rotated quarter-length pair"): the two products are a cosine and a sine
+    // transform of the rotated operands and the outputs are their sum and difference: 1 = (acc1 + acc2 -> first
+    // output, acc1 - acc2 -> second), 2 = the sum only (gathered rows of the pruned transform).  Outputs whose
+    // index along the transformed axis is not below `lim` do not exist (the first / last pair of a class).
+    unsigned pm = 0;
+    unsigned lim = 0xFFFFFFFFu;
 };
 
 // yiq.rs:139-147 (f32::clamp) and :163-165, :173-175: the arithmetic of color.hip / attack.hip, per pixel

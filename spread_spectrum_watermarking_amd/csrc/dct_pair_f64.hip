@@ -246,6 +246,20 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     interleave(B0{});
     fmma(fb);
 
+    if (po.pm) {                               // split odd half: cosine part +/- sine part (block-uniform branch)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double s = acc1[i][jn][r] + acc2[i][jn][r];
+                    acc2[i][jn][r] = acc1[i][jn][r] - acc2[i][jn][r];
+                    acc1[i][jn][r] = s;
+                }
+    }
+    const bool second_out = po.pm != 2;
+
     // D map of 16x16x4 f64: col = lane & 15, row = (lane >> 4) + 4 reg
     const unsigned n = po.n, W = po.W, H = po.H;
     // one output line: element idx of the transformed axis lives at lp[idx * es] (and tp[idx * es] in T)
@@ -257,8 +271,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 const f32x2 v = {apply_epilogue(ep, (float)a1, i1), apply_epilogue(ep, (float)a2, i2)};
                 *reinterpret_cast<f32x2*>(lp + i1) = v;
             } else {
-                lp[i1 * es] = apply_epilogue(ep, (float)a1, i1);
-                lp[i2 * es] = apply_epilogue(ep, (float)a2, i2);
+                if (i1 < po.lim) lp[i1 * es] = apply_epilogue(ep, (float)a1, i1);
+                if (i2 < po.lim && second_out) lp[i2 * es] = apply_epilogue(ep, (float)a2, i2);
             }
         } else if (EPI == EPI_INV) {
             lp[pair * es] = apply_epilogue(ep, (float)(a1 + a2), pair);
@@ -267,12 +281,17 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             tp[pair * es] = a1 + a2;
             tp[(n / 2 - 1 - pair) * es] = a1 - a2;
         } else {
-            const unsigned n1 = pair, n2 = pair + n / 4;
-            const double e1 = tp[n1 * es], e2 = tp[n2 * es];
-            lp[n1 * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
-            lp[(n - 1 - n1) * es] = apply_epilogue(ep, (float)(e1 - a1), n - 1 - n1);
-            lp[n2 * es] = apply_epilogue(ep, (float)(e2 + a2), n2);
-            lp[(n - 1 - n2) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
+            const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * pair;      // positions in the odd part, < n/2
+            if (n1 < n / 2) {
+                const double e1 = tp[n1 * es];
+                lp[n1 * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
+                lp[(n - 1 - n1) * es] = apply_epilogue(ep, (float)(e1 - a1), n - 1 - n1);
+            }
+            if (n2 < n / 2) {
+                const double e2 = tp[n2 * es];
+                lp[n2 * es] = apply_epilogue(ep, (float)(e2 + a2), n2);
+                lp[(n - 1 - n2) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
+            }
         }
     };
     if constexpr (!COLS) {
@@ -391,6 +410,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                     const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
                     if (!line_ok || pair >= NP) continue;
                     const unsigned idx = EPI == EPI_FWD ? (set ? po.c2 : po.c1) + po.cs * pair : (set ? n - 1 - pair : pair);
+                    if (EPI == EPI_FWD && (idx >= po.lim || (set && !second_out))) continue;
                     put_quad(idx, v);
                 }
             }
@@ -412,7 +432,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                         for (int r = 0; r < 4; ++r) {
                             const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
                             const unsigned pc = pair < NP ? pair : 0;
-                            e[i][r] = tp[(size_t)(pc + (half ? n / 4 : 0)) * W];
+                            const unsigned nn = (half ? po.c2 : po.c1) + po.cs * pc;
+                            e[i][r] = tp[(size_t)(nn < n / 2 ? nn : 0) * W];
                         }
                     }
                     (void)tpl;
@@ -432,7 +453,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                         const unsigned pair = p0 + wn + 16 * jn + (srow & 15);
                         const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
                         if (!line_ok || pair >= NP) continue;
-                        const unsigned nn = pair + (half ? n / 4 : 0);
+                        const unsigned nn = (half ? po.c2 : po.c1) + po.cs * pair;
+                        if (nn >= n / 2) continue;
                         put_quad(srow < 16 ? nn : n - 1 - nn, v);
                     }
                 }
@@ -458,27 +480,34 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
                         double e1[2], e2[2];
-                        bool okp[2];
+                        bool ok1[2], ok2[2];
+                        unsigned m1[2], m2[2];
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const unsigned pair = p0 + wn + 16 * jn + lq + 4 * (r + q);
-                            okp[q] = pair < NP;
-                            const unsigned pc = okp[q] ? pair : 0;
-                            e1[q] = tp[(size_t)pc * W];
-                            e2[q] = tp[(size_t)(pc + n / 4) * W];
+                            const unsigned pc = pair < NP ? pair : 0;
+                            const unsigned n1 = po.c1 + po.cs * pc, n2 = po.c2 + po.cs * pc;
+                            ok1[q] = pair < NP && n1 < n / 2;
+                            ok2[q] = pair < NP && n2 < n / 2;
+                            m1[q] = ok1[q] ? n1 : 0;
+                            m2[q] = ok2[q] ? n2 : 0;
+                            e1[q] = tp[(size_t)m1[q] * W];
+                            e2[q] = tp[(size_t)m2[q] * W];
                         }
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
-                            const unsigned pair = p0 + wn + 16 * jn + lq + 4 * (r + q);
-                            const unsigned n1 = okp[q] ? pair : 0, n2 = n1 + n / 4;
                             const double a1 = acc1[i][jn][r + q], a2 = acc2[i][jn][r + q];
-                            const unsigned idx[4] = {n1, n - 1 - n1, n2, n - 1 - n2};
-                            const float v[4] = {(float)(e1[q] + a1), (float)(e1[q] - a1), (float)(e2[q] + a2), (float)(e2[q] - a2)};
-                            unsigned px[4];
-                            float yv[4];
+                            const unsigned idx1[2] = {m1[q], n - 1 - m1[q]}, idx2[2] = {m2[q], n - 1 - m2[q]};
+                            const float v1[2] = {(float)(e1[q] + a1), (float)(e1[q] - a1)}, v2[2] = {(float)(e2[q] + a2), (float)(e2[q] - a2)};
+                            unsigned px1[2], px2[2];
+                            float y1[2], y2[2];
 #pragma unroll
-                            for (int o = 0; o < 4; ++o) { px[o] = idx[o] * W; yv[o] = apply_epilogue(ep, v[o], idx[o]); }
-                            pair_store_rgb_batch<double, 4>(po, base, px, yv, okp[q]);
+                            for (int o = 0; o < 2; ++o) {
+                                px1[o] = idx1[o] * W; y1[o] = apply_epilogue(ep, v1[o], idx1[o]);
+                                px2[o] = idx2[o] * W; y2[o] = apply_epilogue(ep, v2[o], idx2[o]);
+                            }
+                            pair_store_rgb_batch<double, 2>(po, base, px1, y1, ok1[q]);
+                            pair_store_rgb_batch<double, 2>(po, base, px2, y2, ok2[q]);
                         }
                     }
                 continue;
@@ -508,6 +537,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 //   0  one folding level (forward: interleave even/odd; inverse: mirror)            pairs = len/2, K = len/2
 //   1  level 2, even half: X = (SS, SD) | (EE, EO), Y = half bases of len/2          pairs = len/4, K = len/4
 //   2  level 2, odd half:  X = D | O (shared), Y = the two halves of the odd basis   pairs = len/4, K = len/2
+//   3 / 4  the odd half split once more (see "Split odd half" in dct_pair_prep.hip): X = (AS, BD) | (AD, BS), the rotated
+//      and folded odd operand; Y = (cosine, sine) rows 2i | 2i+1 of the quarter-length bases; outputs acc1 +/- acc2
+//      pairs = len/8 + 1 | len/8, K = len/8
 // x*, y*: k-blocked planes (y2 of kind 2 = y1 + 8 * len/4: the second row block of the same plane).
 // sub (forward only): the launch belongs to the transform of length len >> sub that a deeper folding level
 // applies to the even part (its frequencies are multiples of 2^sub of the full transform's).
@@ -523,8 +555,10 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     if (sub < 0 || sub > 8 || (sub > 0 && (inverse || kind == 0))) return SSW_ERR_BAD_ARG;
     const size_t leff = len >> sub;                           // length of the (sub-)transform this launch serves
     const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
-    const unsigned NP = (unsigned)(kind == 0 ? leff / 2 : leff / 4);
-    const unsigned Kp = (unsigned)(kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
+    const bool split = kind == 3 || kind == 4;
+    if (split && (leff % 8 != 0 || (inverse && sub != 0))) return SSW_ERR_BAD_ARG;
+    const unsigned NP = (unsigned)(kind == 0 ? leff / 2 : kind == 3 ? leff / 8 + 1 : kind == 4 ? leff / 8 : leff / 4);
+    const unsigned Kp = (unsigned)(split ? pair_kpad<double>(leff / 4) : kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
     const unsigned BN = 64;
     unsigned tiles_n = (NP + BN - 1) / BN;
     // 64-line tiles when 128-line ones would not fill the 512 block slots of the chip (2 per CU)
@@ -547,6 +581,17 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)len, 0, 1, 2};
     if (kind == 1) { po.c1 = 0; po.c2 = 2 * fs; po.cs = 4 * fs; }
     if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
+    if (inverse && kind == 2) { po.c1 = 0; po.c2 = (unsigned)(len / 4); po.cs = 1; }      // positions pair, pair + n/4 of the odd part
+    if (split) {
+        // odd frequency u = 2k+1 of the (sub-)transform; class E (kind 3) pair i: k = 4i (+), 4i-1 (-); class O: k = 4i+2 (+), 4i+1 (-)
+        po.pm = 1;
+        if (!inverse) {
+            po.c1 = (kind == 3 ? 1u : 5u) * fs; po.c2 = kind == 3 ? 0u - fs : 3u * fs; po.cs = 8 * fs;
+            po.lim = (unsigned)len;
+        } else {
+            po.c1 = kind == 3 ? 0u : 2u; po.c2 = kind == 3 ? 0u - 1u : 1u; po.cs = 4;             // positions of the odd part
+        }
+    }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     po.bn32 = bn32 ? 1u : 0u;
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
@@ -562,15 +607,20 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     if (!inverse) {
         if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD_ADJ, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
         else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
-        else { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, true); else SSW_LAUNCH_PAIR(true, EPI_FWD, true); }
+        else if (kind == 2) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, true); else SSW_LAUNCH_PAIR(true, EPI_FWD, true); }
+        else {
+            if (small) { if (is_row) SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 3, 64); else SSW_LAUNCH_PAIR_BM(true, EPI_FWD, false, 3, 64); }
+            else       { if (is_row) SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 3, 128); else SSW_LAUNCH_PAIR_BM(true, EPI_FWD, false, 3, 128); }
+        }
     } else {
         if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV, false); else SSW_LAUNCH_PAIR(true, EPI_INV, false); }
         else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_E, false); else SSW_LAUNCH_PAIR(true, EPI_INV_E, false); }
         else if (sink && sink->rgb) {      // last pass of Writer::result: colour conversion in the epilogue
             if (is_row || sub != 0) return SSW_ERR_BAD_ARG;
             po.iq_i = sink->iq_i; po.iq_q = sink->iq_q; po.rgb = sink->rgb; po.rgb_u8 = sink->u8 ? 1u : 0u;
-            SSW_LAUNCH_PAIR(true, EPI_INV_O_RGB, true);
+            if (split) SSW_LAUNCH_PAIR(true, EPI_INV_O_RGB, false); else SSW_LAUNCH_PAIR(true, EPI_INV_O_RGB, true);
         }
+        else if (split) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, false); else SSW_LAUNCH_PAIR(true, EPI_INV_O, false); }
         else { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, true); else SSW_LAUNCH_PAIR(true, EPI_INV_O, true); }
     }
 #undef SSW_LAUNCH_PAIR
@@ -595,6 +645,25 @@ int launch_dct_pair_gemm_rows_subset_f64(hipStream_t st, const double* x, const 
     PairOut po{out, nullptr, out_stride, 0, 0, off, off + NP, 1};
     const Epilogue ep{1.f, 1.f};
     pair_gemm_f64_kernel<false, EPI_FWD, true, 2><<<(unsigned)nblk, PT, 0, st>>>(x, x, y, y + (size_t)NP * 8, po, L, NP, Kp, cap, tiles_m, tiles_n, ep);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// The same for a class of the split odd half: gathered cosine rows `y1` and gathered sine rows `y2` (negated where the
+// output is the difference) against the class's operand pair; pair j -> compact column off + j = acc1 + acc2.
+int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1, const double* x2, const double* y1, const double* y2,
+                                               unsigned cap, unsigned Kp, float* out, unsigned out_stride, unsigned off, size_t lines) {
+    if (lines == 0 || cap == 0) return SSW_OK;
+    if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned L = (unsigned)lines, NP = cap;
+    const unsigned tiles_m = (L + 127) / 128, tiles_n = (NP + 63) / 64;
+    const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if ((unsigned long long)Kp * L * sizeof(double) > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    PairOut po{out, nullptr, out_stride, 0, 0, off, 0, 1};
+    po.pm = 2;
+    const Epilogue ep{1.f, 1.f};
+    pair_gemm_f64_kernel<false, EPI_FWD, false, 3><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, cap, tiles_m, tiles_n, ep);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

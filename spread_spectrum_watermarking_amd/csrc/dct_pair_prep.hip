@@ -39,6 +39,153 @@ int launch_make_half_basis_blocked(hipStream_t st, bool f64, size_t n, bool inve
 }
 
 // ---------------------------------------------------------------------------------------------
+// Split odd half.  The odd frequencies of a length-N transform are a DCT-IV of the M = N/2 differences d[n]:
+//   X[k] = sum_{n<M} d[n] cos(pi (2k+1)(2n+1) / (4M)),  k < M           (frequency 2k+1; inverse: the same sum with the
+//                                                                         roles of k and n exchanged -- the matrix is symmetric)
+// Pairing n with M-1-n and splitting the angle of an even k = 2j into pi j (2n+1)/M + psi_n, psi_n = pi (2n+1)/(4M):
+//   a[n] =  d[n] cos psi_n + d[M-1-n] sin psi_n,   b[n] = -d[n] sin psi_n + d[M-1-n] cos psi_n        (n < M/2: a rotation)
+//   A[j] = sum_n a[n] cos(pi j (2n+1)/M),  B[j] = sum_n b[n] sin(pi j (2n+1)/M)                       (j = 0 .. M/2)
+//   X[2j] = A[j] + B[j],   X[2j-1] = A[j] - B[j]
+// A is a DCT-II and B a DST-II of length M/2; both fold once more (n <-> M/2-1-n, exact additions):
+//   j = 2i   :  A = sum_{n<M/4} (a[n] + a[M/2-1-n]) cos(..),   B = sum (b[n] - b[M/2-1-n]) sin(..)    operands AS, BD
+//   j = 2i+1 :  A = sum_{n<M/4} (a[n] - a[M/2-1-n]) cos(..),   B = sum (b[n] + b[M/2-1-n]) sin(..)    operands AD, BS
+// i.e. two GEMM launches with K = M/4 = N/8 and N/8 (+1) output pairs instead of one with K = N/2 and N/4 pairs:
+// a quarter of the multiply-adds.  The only inexact step before the MFMA sums is the rotation (two f64 products and
+// one sum per operand element, relative error 2^-52 of |d|): the folded operands of the other launches stay exact.
+// Bases, k-blocked like the half bases: rows i of scale * cos / sin(2 pi j (2n+1) / N), j = 2i (E, N/8 + 1 rows) or
+// 2i + 1 (O, N/8 rows), n < N/8; scale 2 forward, 1/2 inverse as in make_half_basis_blocked_kernel.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void make_split_basis_blocked_kernel(size_t n, bool inverse, int which /*0 cosE, 1 sinE, 2 cosO, 3 sinO*/, size_t kpad,
+                                                size_t rows, T* out) {
+    const size_t ktrue = n / 8, total = rows * kpad;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t o = i / kpad, s = i % kpad;
+        double v = 0.0;
+        if (s < ktrue) {
+            const unsigned long long j = (which & 2) ? 2ull * o + 1ull : 2ull * o;
+            const unsigned long long a = (j * (2ull * s + 1ull)) % (unsigned long long)n;       // angle 2 pi a / n
+            const double arg = (double)(2ull * a) / (double)n;
+            const double c = (which & 1) ? sinpi(arg) : cospi(arg);
+            v = (inverse ? 0.5 : 2.0) * c;
+        }
+        out[blk_index<T>(o, (unsigned)s, rows)] = (T)v;
+    }
+}
+// rotation table of a length-n axis: [0 .. n/4) cos psi, [n/4 .. n/2) sin psi, psi = pi (2 m + 1) / (2 n)
+__global__ void make_rot_table_kernel(size_t n, double* out) {
+    const size_t q = n / 4;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < q; i += (size_t)gridDim.x * blockDim.x) {
+        const double arg = (double)(2ull * i + 1ull) / (double)(2ull * n);
+        out[i] = cospi(arg);
+        out[q + i] = sinpi(arg);
+    }
+}
+
+bool dct_pair_can_split(size_t len, bool is_row) { (void)is_row; return len % 8 == 0 && len >= 128; }
+size_t dct_pair_split_kpad(size_t len) { return pair_kpad<double>(len / 4); }
+// doubles in the four split planes of a pass over n frames (the larger of the row and the column pass)
+size_t dct_pair_split_elems(size_t n_frames, size_t w, size_t h) {
+    const size_t a = n_frames * h * dct_pair_split_kpad(w), b = n_frames * w * dct_pair_split_kpad(h);
+    return 4 * (a > b ? a : b);
+}
+size_t dct_pair_split_basis_rows(size_t len, int which) { return (which & 2) ? len / 8 : len / 8 + 1; }
+
+int launch_make_split_basis_blocked(hipStream_t st, size_t n, bool inverse, int which, double* out) {
+    const size_t kp = dct_pair_split_kpad(n), rows = dct_pair_split_basis_rows(n, which), total = rows * kp;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    make_split_basis_blocked_kernel<double><<<blocks ? blocks : 1, 256, 0, st>>>(n, inverse, which, kp, rows, out);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+int launch_make_rot_table(hipStream_t st, size_t n, double* out) {
+    make_rot_table_kernel<<<(unsigned)((n / 4 + 255) / 256 ? (n / 4 + 255) / 256 : 1), 256, 0, st>>>(n, out);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// Rotation + fold of an odd operand plane P ([Kp / 8][L][8], positions n < M = len/2) into the four split planes
+// ([K8 / 8][L][8], K8 = kpad(len/4), zero padded): one thread = one line x 8 consecutive e (one 64-byte piece of each
+// output plane); consecutive threads take consecutive lines, so every piece access of a wave is one contiguous run.
+// ALIGNED: M/2 is a multiple of 8 and the mirrored positions are whole pieces too (16-byte loads); otherwise the
+// mirrored elements are fetched one by one.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void pair_rotate_kernel(const double* __restrict__ P, const double* __restrict__ rot,
+                                                         double* __restrict__ AS, double* __restrict__ BD,
+                                                         double* __restrict__ AD, double* __restrict__ BS,
+                                                         unsigned L, unsigned M, unsigned K8, unsigned line_blocks) {
+    const unsigned line = (blockIdx.x % line_blocks) * 256 + threadIdx.x;
+    const unsigned e0 = (blockIdx.x / line_blocks) * 8;
+    if (line >= L || e0 >= K8) return;
+    const unsigned Mh = M / 2, Mq = M / 4;
+    double as[8], bd[8], ad[8], bs[8];
+    auto ld = [&](unsigned pos) { return P[blk_index<double>(line, pos, L)]; };
+    double d0[8], d1[8], d2[8], d3[8];          // d[e], d[M/2-1-e], d[M/2+e], d[M-1-e]
+    if (ALIGNED && e0 + 8 <= Mq) {
+        const double* p0 = P + blk_index<double>(line, e0, L);
+        const double* p1 = P + blk_index<double>(line, Mh - 8 - e0, L);
+        const double* p2 = P + blk_index<double>(line, Mh + e0, L);
+        const double* p3 = P + blk_index<double>(line, M - 8 - e0, L);
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const f64x2 v0 = *reinterpret_cast<const f64x2*>(p0 + i), v1 = *reinterpret_cast<const f64x2*>(p1 + i);
+            const f64x2 v2 = *reinterpret_cast<const f64x2*>(p2 + i), v3 = *reinterpret_cast<const f64x2*>(p3 + i);
+            d0[i] = v0[0]; d0[i + 1] = v0[1];
+            d1[7 - i] = v1[0]; d1[6 - i] = v1[1];
+            d2[i] = v2[0]; d2[i + 1] = v2[1];
+            d3[7 - i] = v3[0]; d3[6 - i] = v3[1];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned e = e0 + i;
+            const bool ok = e < Mq;
+            d0[i] = ok ? ld(e) : 0.0;
+            d1[i] = ok ? ld(Mh - 1 - e) : 0.0;
+            d2[i] = ok ? ld(Mh + e) : 0.0;
+            d3[i] = ok ? ld(M - 1 - e) : 0.0;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned e = e0 + i;
+        const unsigned ec = e < Mq ? e : 0, em = Mh - 1 - ec;          // n = e and its mirror n' = M/2 - 1 - e
+        const double c = rot[ec], s = rot[Mh + ec], cm = rot[em], sm = rot[Mh + em];
+        const double a = d0[i] * c + d3[i] * s, b = d3[i] * c - d0[i] * s;                 // n: partner M-1-n
+        const double am = d1[i] * cm + d2[i] * sm, bm = d2[i] * cm - d1[i] * sm;           // n': partner M-1-n' = M/2 + e
+        const bool ok = e < Mq;
+        as[i] = ok ? a + am : 0.0;
+        ad[i] = ok ? a - am : 0.0;
+        bs[i] = ok ? b + bm : 0.0;
+        bd[i] = ok ? b - bm : 0.0;
+    }
+    const size_t at = blk_index<double>(line, e0, L);
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        *reinterpret_cast<f64x2*>(AS + at + i) = (f64x2){as[i], as[i + 1]};
+        *reinterpret_cast<f64x2*>(BD + at + i) = (f64x2){bd[i], bd[i + 1]};
+        *reinterpret_cast<f64x2*>(AD + at + i) = (f64x2){ad[i], ad[i + 1]};
+        *reinterpret_cast<f64x2*>(BS + at + i) = (f64x2){bs[i], bs[i + 1]};
+    }
+}
+
+// P: the odd operand plane of a length-`len` axis (kpad(len) wide, `lines` lines) -> sp: four consecutive planes
+// AS | BD | AD | BS of lines * K8 doubles each
+int launch_dct_pair_rotate(hipStream_t st, const double* p, const double* rot, double* sp, size_t lines, size_t len) {
+    if (lines == 0) return SSW_OK;
+    if (lines > 0xFFFFFFFFull || len % 8 != 0) return SSW_ERR_BAD_DIMS;
+    const unsigned L = (unsigned)lines, M = (unsigned)(len / 2), K8 = (unsigned)dct_pair_split_kpad(len);
+    const unsigned line_blocks = (L + 255) / 256;
+    const unsigned long long nblk = (unsigned long long)line_blocks * (K8 / 8);
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const size_t plane = (size_t)L * K8;
+    if ((M / 2) % 8 == 0) pair_rotate_kernel<true><<<(unsigned)nblk, 256, 0, st>>>(p, rot, sp, sp + plane, sp + 2 * plane, sp + 3 * plane, L, M, K8, line_blocks);
+    else                  pair_rotate_kernel<false><<<(unsigned)nblk, 256, 0, st>>>(p, rot, sp, sp + plane, sp + 2 * plane, sp + 3 * plane, L, M, K8, line_blocks);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pre-passes (HBM-bound): f32 plane -> the f64 operand planes of the pass, k-blocked.
 // One folding level:   forward  O1 = S, O2 = D;   inverse  O1 = E (even coefficients), O2 = O (odd)
 // ---------------------------------------------------------------------------------------------

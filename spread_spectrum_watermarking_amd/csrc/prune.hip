@@ -50,12 +50,12 @@ __global__ __launch_bounds__(1024) void prune_build_kernel(const uint32_t* __res
         const PruneClass pc = plan.c[c];
         if (t == 0) base_s = 0;
         __syncthreads();
-        // members of the class in ascending order: v = rem + mod * m
-        const unsigned members = (plan.W - pc.rem + pc.mod - 1) / pc.mod;
-        for (unsigned m0 = 0; m0 < members; m0 += 1024) {
-            const unsigned m = m0 + t;
-            const unsigned v = pc.rem + pc.mod * m;
-            const bool on = m < members && flag[v] != 0;
+        // members of the class in ascending order of v
+        for (unsigned v0 = 0; v0 < plan.W; v0 += 1024) {
+            const unsigned v = v0 + t;
+            const unsigned r = v % pc.mod;
+            const bool neg = pc.rem2 != PRUNE_NO_REM && r == pc.rem2;
+            const bool on = v < plan.W && (r == pc.rem || neg) && flag[v] != 0;
             const unsigned long long bal = __ballot(on);
             const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
             if (lane == 0) wave_sum[wv] = __popcll(bal);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(1024) void prune_build_kernel(const uint32_t* __res
             if (on) {
                 const unsigned j = prefix + before;
                 if (j < pc.cap) {
-                    rows[pc.off + j] = v / pc.mod;
+                    rows[pc.off + j] = ((v + pc.radd) / pc.mod) | (neg ? PRUNE_NEG : 0u);
                     pos[v] = pc.off + j;
                 }
             }
@@ -90,16 +90,20 @@ __global__ __launch_bounds__(1024) void prune_build_kernel(const uint32_t* __res
 // rows where rows[j] == PRUNE_NONE.  One thread = one 16-byte piece; k-block pieces are 64 bytes in both precisions.
 __global__ __launch_bounds__(256) void prune_gather_basis_kernel(const uint32_t* __restrict__ rows, unsigned cap,
                                                                 const char* __restrict__ src, unsigned src_rows,
-                                                                unsigned kblocks, char* __restrict__ dst) {
+                                                                unsigned kblocks, char* __restrict__ dst, bool negate) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     const size_t total = (size_t)kblocks * cap * 4;
     if (i >= total) return;
     const unsigned piece = (unsigned)(i & 3);
     const unsigned j = (unsigned)((i >> 2) % cap);
     const unsigned kb = (unsigned)((i >> 2) / cap);
-    const uint32_t r = rows[j];
+    const uint32_t rf = rows[j];
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (r != PRUNE_NONE) v = *reinterpret_cast<const u32x4*>(src + ((size_t)kb * src_rows + r) * 64 + piece * 16);
+    if (rf != PRUNE_NONE) {
+        const uint32_t r = rf & ~PRUNE_NEG;
+        v = *reinterpret_cast<const u32x4*>(src + ((size_t)kb * src_rows + r) * 64 + piece * 16);
+        if (negate && (rf & PRUNE_NEG)) { v[1] ^= 0x80000000u; v[3] ^= 0x80000000u; }      // two doubles: flip the sign bits
+    }
     *reinterpret_cast<u32x4*>(dst + ((size_t)kb * cap + j) * 64 + piece * 16) = v;
 }
 
@@ -115,11 +119,11 @@ int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, siz
 }
 
 int launch_prune_gather_basis(hipStream_t st, const uint32_t* rows, unsigned cap, const void* src, size_t src_rows,
-                              size_t kblocks, void* dst) {
+                              size_t kblocks, void* dst, bool negate_flagged_f64) {
     const size_t total = kblocks * cap * 4;
     if (total == 0) return SSW_OK;
     prune_gather_basis_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(rows, cap, (const char*)src, (unsigned)src_rows,
-                                                                                 (unsigned)kblocks, (char*)dst);
+                                                                                 (unsigned)kblocks, (char*)dst, negate_flagged_f64);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -124,20 +124,35 @@ int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind
 
 int launch_dct_pair_gemm_rows_subset_f64(hipStream_t st, const double* x, const double* y, unsigned cap, unsigned Kp, float* out,
                                          unsigned out_stride, unsigned off, size_t lines);
+int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1, const double* x2, const double* y1, const double* y2,
+                                               unsigned cap, unsigned Kp, float* out, unsigned out_stride, unsigned off, size_t lines);
+// split odd half (f64 only; dct_pair_prep.hip "Split odd half"): quarter-length cosine / sine bases (which: 0 cosE, 1 sinE,
+// 2 cosO, 3 sinO), the rotation table of an axis, and the pass that turns an odd operand plane into AS | BD | AD | BS
+bool dct_pair_can_split(size_t len, bool is_row);
+size_t dct_pair_split_kpad(size_t len);
+size_t dct_pair_split_elems(size_t n_frames, size_t w, size_t h);
+size_t dct_pair_split_basis_rows(size_t len, int which);
+int launch_make_split_basis_blocked(hipStream_t st, size_t n, bool inverse, int which, double* out);
+int launch_make_rot_table(hipStream_t st, size_t n, double* out);
+int launch_dct_pair_rotate(hipStream_t st, const double* p, const double* rot, double* sp, size_t lines, size_t len);
 int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const float* y, unsigned cap, unsigned Kp, float* out,
                                          unsigned out_stride, unsigned off, size_t lines);
 
 // prune.hip: the derived frame's transform restricted to the frequency columns a chunk's index lists use
-struct PruneClass { unsigned mod, rem, cap, off; };      // v in the class when v % mod == rem; basis row v / mod
+// v is in the class when v % mod == rem, or == rem2 (classes of the split odd half: there the output is the cosine
+// part MINUS the sine part and the gathered sine row is negated); basis row (v + radd) / mod
+constexpr unsigned PRUNE_NO_REM = 0xFFFFFFFFu;
+constexpr uint32_t PRUNE_NEG = 0x40000000u;              // rows[] flag: negate the gathered sine row
+struct PruneClass { unsigned mod, rem, cap, off, rem2 = PRUNE_NO_REM, radd = 0; };
 struct PrunePlan {
     unsigned n_classes = 0;
-    PruneClass c[4];
+    PruneClass c[5];
     unsigned W = 0, cap_total = 0;
 };
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,
                        uint32_t* flag /*[W]*/, uint32_t* rows /*[cap_total]*/, uint32_t* pos /*[W]*/, uint32_t* info /*[8]*/);
 int launch_prune_gather_basis(hipStream_t st, const uint32_t* rows, unsigned cap, const void* src, size_t src_rows,
-                              size_t kblocks, void* dst);
+                              size_t kblocks, void* dst, bool negate_flagged_f64 = false);
 int launch_extract_pruned(hipStream_t st, const float* base, const float* compact, size_t n_frames, size_t w, size_t h,
                           size_t cap, const uint32_t* pos, const uint32_t* indices, size_t k, int method, float alpha,
                           float* out);
@@ -224,7 +239,7 @@ struct ssw_ctx {
     // HBM-bound stages (operand pre-passes, selection, colour conversion) run on `aux_stream`.
     struct Lane {
         Buf plane[4];             // y / i / q / t planes of the chunk
-        Buf operand[5];           // operand planes of the operand-ready GEMMs: S|E, D|O, SS|EE, SD|EO, T
+        Buf operand[6];           // operand planes of the operand-ready GEMMs: S|E, D|O, SS|EE, SD|EO, T, split odd (AS|BD|AD|BS)
         Buf idx;                  // [chunk][k] u32
         ssw::SelectWorkspace sel;
         Buf compact[2];           // pruned derived transform: row-pass result, column-pass result [chunk][H][cap]
@@ -238,6 +253,7 @@ struct ssw_ctx {
     hipStream_t aux_stream = nullptr;     // HBM-bound stages of the batch pipelines
     bool overlap = true;                  // two lanes / two streams in the batch entry points
     bool prune = true;                    // batch extract: derived transform only where the index lists need it
+    bool split = true;                    // f64 GEMMs: odd halves as rotated quarter-length cosine + sine pairs
     std::vector<hipEvent_t> sync_events;  // cross-stream dependencies (ring)
     size_t sync_next = 0;
     Buf overflow;                         // [chunks] u32 flags of the pruned path (+ class counts)

@@ -104,9 +104,16 @@ int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const vo
     auto it = ctx->basis.find(key);
     if (it != ctx->basis.end()) { *out = it->second; return SSW_OK; }
     void* p = nullptr;
-    const size_t elems = kind == 0 ? n * dense_basis_kpad(n) : kind >= 3 ? (n / 2) * dct_pair_kpad(f64, n) : (n / 2) * half_basis_kpad(n);
+    // kinds 5..8: split odd half bases (cosE, sinE, cosO, sinO), 9: the rotation table (f64 only)
+    const size_t elems = kind == 0 ? n * dense_basis_kpad(n)
+                       : kind == 9 ? n / 2
+                       : kind >= 5 ? dct_pair_split_basis_rows(n, kind - 5) * dct_pair_split_kpad(n)
+                       : kind >= 3 ? (n / 2) * dct_pair_kpad(f64, n) : (n / 2) * half_basis_kpad(n);
+    if (kind >= 5 && !f64) return SSW_ERR_BAD_ARG;
     SSW_ALLOC(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float)));
-    int rc = kind >= 3 ? launch_make_half_basis_blocked(ctx->stream, f64, n, inverse, kind - 3, p)
+    int rc = kind == 9 ? launch_make_rot_table(ctx->stream, n, (double*)p)
+             : kind >= 5 ? launch_make_split_basis_blocked(ctx->stream, n, inverse, kind - 5, (double*)p)
+             : kind >= 3 ? launch_make_half_basis_blocked(ctx->stream, f64, n, inverse, kind - 3, p)
              : kind != 0 ? (f64 ? launch_make_half_basis_f64(ctx->stream, n, inverse, kind - 1, (double*)p)
                               : launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p))
              : f64     ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
@@ -187,6 +194,7 @@ int pair_gemm(hipStream_t st, bool f64, bool is_row, bool inverse, int kind, int
 double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t h) {
     const double lines = (double)(is_row ? n * h : n * w);
     const size_t leff = (is_row ? w : h) >> sub;
+    if (kind == 3 || kind == 4) return 4.0 * lines * (double)(leff / 8 + (kind == 3 ? 1 : 0)) * (double)(leff / 8);
     const double np = (double)(kind == 0 ? leff / 2 : leff / 4), k = (double)(kind == 1 ? leff / 4 : leff / 2);
     return 4.0 * lines * np * k;
 }
@@ -224,6 +232,29 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
         // a third level pays once the sums are long enough (4K: +1.6 %, 1080p: -3 %); level 6 forces it
         const bool three = two && !inverse && dct_pair_can_fold3(len) &&
                            (ctx->fold_level >= 6 || (ctx->fold_level == 5 && len >= 3072));
+        // the odd half as a rotated pair of quarter-length cosine / sine transforms (f64): a quarter of its multiply-adds
+        const bool split = two && f64 && ctx->split && dct_pair_can_split(len, is_row);
+        const void *sb[4] = {nullptr, nullptr, nullptr, nullptr}, *rot = nullptr;
+        double* sp = nullptr;
+        const size_t lines = is_row ? n * h : n * w;
+        const size_t sp_plane = lines * (split ? dct_pair_split_kpad(len) : 0);
+        if (split) {
+            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len, inverse, true, 5 + b, &sb[b]));
+            SSW_TRY(get_basis(ctx, len, false, true, 9, &rot));
+            SSW_TRY(grow(ws.operand[5], dct_pair_split_elems(n, w, h) * sizeof(double)));
+            sp = (double*)ws.operand[5].p;
+        }
+        // the odd half of the full-length transform from the operand plane `odd`: one launch, or rotate + two
+        auto odd_rotate = [=](hipStream_t st, const void* odd) -> int {
+            return split ? launch_dct_pair_rotate(st, (const double*)odd, (const double*)rot, sp, lines, len) : SSW_OK;
+        };
+        auto odd_gemm = [=](hipStream_t st, const void* odd, const void* basis, void* tmpE, const RgbSink* sink) -> int {
+            if (!split) return pair_gemm(st, f64, is_row, inverse, 2, 0, odd, odd, basis, (const char*)basis + (len / 4) * 64, dst, tmpE, n, w, h, ep, sink);
+            SSW_TRY(pair_gemm(st, true, is_row, inverse, 3, 0, sp, sp + sp_plane, sb[0], sb[1], dst, tmpE, n, w, h, ep, sink));
+            return pair_gemm(st, true, is_row, inverse, 4, 0, sp + 2 * sp_plane, sp + 3 * sp_plane, sb[2], sb[3], dst, tmpE, n, w, h, ep, sink);
+        };
+        const double f_odd = split ? pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h)
+                                   : pair_gemm_flop(is_row, 2, 0, n, w, h);
         if (three) {
             // forward pass, three levels: x- (odd frequencies), S- (2 mod 4), (SSS, SS-) (0 and 4 mod 8); on a column
             // pass (8K: 4320 rows) the pre-pass transposes like the two-level one
@@ -238,18 +269,19 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             SSW_TRY(get_basis(ctx, len / 4, false, f64, 4, &e1));
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
-                if (!is_row) return launch_dct_pair_prep8_cols(st, f64, src, n, w, h, r1, r2, d2, d1);
-                return launch_dct_pair_prep8_rows(st, f64, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h,
-                                                  r1, r2, d2, d1, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
+                if (!is_row) SSW_TRY(launch_dct_pair_prep8_cols(st, f64, src, n, w, h, r1, r2, d2, d1));
+                else SSW_TRY(launch_dct_pair_prep8_rows(st, f64, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h,
+                                                        r1, r2, d2, d1, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr));
+                return odd_rotate(st, d1);
             }});
-            const double f_main = pair_gemm_flop(is_row, 2, 0, n, w, h);
+            const double f_main = f_odd;
             const double f_all = f_main + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 2, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 SSW_TRY(pair_gemm(st, f64, is_row, inverse, 1, 1, r1, r2, e0, e1, dst, nullptr, n, w, h, ep));
                 SSW_TRY(pair_gemm(st, f64, is_row, inverse, 2, 1, d2, d2, h1, (const char*)h1 + (len / 8) * 64, dst, nullptr, n, w, h, ep));
                 StageTimer tm(ctx, st_main, st, f_main);
-                return pair_gemm(st, f64, is_row, inverse, 2, 0, d1, d1, b1, (const char*)b1 + (len / 4) * 64, dst, nullptr, n, w, h, ep);
+                return odd_gemm(st, d1, b1, nullptr, nullptr);
             }});
         } else if (!two) {
             for (int b = 0; b < 2; ++b) SSW_TRY(grow(ws.operand[b], bytes));
@@ -276,10 +308,11 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             SSW_TRY(get_basis(ctx, len / 2, inverse, f64, 4, &q1));
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
-                if (from_rgb) return launch_dct_pair_prep4_rows_rgb(st, f64, rgb_u8, rgb, n, w, h, xx1, xx2, x2, iq_i, iq_q);
-                return launch_dct_pair_prep4(st, f64, is_row, inverse, src, n, w, h, xx1, xx2, x2);
+                if (from_rgb) SSW_TRY(launch_dct_pair_prep4_rows_rgb(st, f64, rgb_u8, rgb, n, w, h, xx1, xx2, x2, iq_i, iq_q));
+                else SSW_TRY(launch_dct_pair_prep4(st, f64, is_row, inverse, src, n, w, h, xx1, xx2, x2));
+                return odd_rotate(st, x2);
             }});
-            const double f_main = pair_gemm_flop(is_row, 2, 0, n, w, h);
+            const double f_main = f_odd;
             const double f_all = f_main + pair_gemm_flop(is_row, 1, 0, n, w, h);
             // Writer::result: the last pass of an inverse transform (a column pass) converts to RGB in its epilogue
             RgbSink sink;
@@ -295,8 +328,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 // odd half: full half-length sum, the odd basis split into two row blocks (second block:
                 // len/4 lines further inside every k-block of the same plane = 64 bytes per line)
                 StageTimer tm(ctx, st_main, st, f_main);
-                return pair_gemm(st, f64, is_row, inverse, 2, 0, x2, x2, b1, (const char*)b1 + (len / 4) * 64, dst, tmpE, n, w, h, ep,
-                                 with_sink ? &sink : nullptr);
+                return odd_gemm(st, x2, b1, tmpE, with_sink ? &sink : nullptr);
             }});
         }
         return SSW_OK;
@@ -551,6 +583,7 @@ struct PruneSetup {
     bool on = false;
     PrunePlan plan;
     int levels = 0;                 // folding levels of the forward row pass: 2 or 3
+    bool split = false;             // odd frequencies through the split odd half (two classes instead of one)
 };
 
 // capacity of the compact plane in frequency columns: the index lists of natural spectra use ~3 sqrt(k)
@@ -577,18 +610,28 @@ PruneSetup make_prune_setup(const ssw_ctx* ctx, bool f64, size_t n, size_t w, si
     ps.plan.W = (unsigned)w;
     ps.plan.cap_total = (unsigned)cap;
     const unsigned c = (unsigned)cap;
-    if (three) {
-        ps.plan.n_classes = 4;
-        ps.plan.c[0] = {2, 1, c / 2, 0};
-        ps.plan.c[1] = {4, 2, c / 4, c / 2};
-        ps.plan.c[2] = {8, 0, c / 8, c / 2 + c / 4};
-        ps.plan.c[3] = {8, 4, c / 8, c / 2 + c / 4 + c / 8};
+    ps.split = f64 && ctx->split && dct_pair_can_split(w, true);
+    unsigned nc = 0, off = 0;
+    auto add = [&](unsigned mod, unsigned rem, unsigned cc, unsigned rem2 = PRUNE_NO_REM, unsigned radd = 0) {
+        ps.plan.c[nc] = {mod, rem, cc, off, rem2, radd};
+        off += cc;
+        ++nc;
+    };
+    if (ps.split) {                       // odd v = 8i +/- 1 -> class E row i (= (v + 1) / 8), v = 8i + 5 | 8i + 3 -> class O row i
+        add(8, 1, c / 4, 7, 1);
+        add(8, 5, c / 4, 3, 0);
     } else {
-        ps.plan.n_classes = 3;
-        ps.plan.c[0] = {2, 1, c / 2, 0};
-        ps.plan.c[1] = {4, 0, c / 4, c / 2};
-        ps.plan.c[2] = {4, 2, c / 4, c / 2 + c / 4};
+        add(2, 1, c / 2);
     }
+    if (three) {
+        add(4, 2, c / 4);
+        add(8, 0, c / 8);
+        add(8, 4, c / 8);
+    } else {
+        add(4, 0, c / 4);
+        add(4, 2, c / 4);
+    }
+    ps.plan.n_classes = nc;
     ps.on = true;
     return ps;
 }
@@ -608,30 +651,48 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     uint32_t* flag = (uint32_t*)ws.prune_u32.p;
     uint32_t* pos = flag + w;
     uint32_t* rows = pos + w;
-    // class -> image operand plane, cached half basis, padded / true sum length
-    struct ClassSrc { const void* x; const void* basis; size_t src_rows, kp, ktrue; };
-    ClassSrc cs[4];
-    const void *b1 = nullptr;
-    SSW_TRY(get_basis(ctx, w, false, f64, 4, &b1));
+    // class -> image operand plane(s), cached basis plane(s), padded / true sum length
+    struct ClassSrc { const void* x; const void* basis; size_t src_rows, kp, ktrue; const void* x2 = nullptr; const void* basis2 = nullptr; };
+    ClassSrc cs[5];
+    unsigned ci = 0;
+    const size_t lines = n * h;
+    const void* rot = nullptr;
+    double* sp = nullptr;
+    if (ps.split) {
+        const void* sb[4];
+        for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w, false, true, 5 + b, &sb[b]));
+        SSW_TRY(get_basis(ctx, w, false, true, 9, &rot));
+        const size_t kp8 = dct_pair_split_kpad(w), plane = lines * kp8;
+        SSW_TRY(grow(ws.operand[5], dct_pair_split_elems(n, w, h) * sizeof(double)));
+        sp = (double*)ws.operand[5].p;
+        cs[ci++] = {sp, sb[0], dct_pair_split_basis_rows(w, 0), kp8, w / 8, sp + plane, sb[1]};                  // AS x cosE, BD x sinE
+        cs[ci++] = {sp + 2 * plane, sb[2], dct_pair_split_basis_rows(w, 2), kp8, w / 8, sp + 3 * plane, sb[3]};  // AD x cosO, BS x sinO
+    } else {
+        const void* b1 = nullptr;
+        SSW_TRY(get_basis(ctx, w, false, f64, 4, &b1));
+        cs[ci++] = {ws.operand[1].p, b1, w / 2, dct_pair_kpad(f64, w), w / 2};       // x- | D : odd
+    }
     if (ps.levels == 3) {
         const void *h1 = nullptr, *e0 = nullptr, *e1 = nullptr;
         SSW_TRY(get_basis(ctx, w / 2, false, f64, 4, &h1));
         SSW_TRY(get_basis(ctx, w / 4, false, f64, 3, &e0));
         SSW_TRY(get_basis(ctx, w / 4, false, f64, 4, &e1));
-        cs[0] = {ws.operand[1].p, b1, w / 2, dct_pair_kpad(f64, w), w / 2};          // x-  : odd
-        cs[1] = {ws.operand[0].p, h1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // S-  : 2 mod 4
-        cs[2] = {ws.operand[2].p, e0, w / 8, dct_pair_kpad(f64, w / 4), w / 8};      // SSS : 0 mod 8
-        cs[3] = {ws.operand[3].p, e1, w / 8, dct_pair_kpad(f64, w / 4), w / 8};      // SS- : 4 mod 8
+        cs[ci++] = {ws.operand[0].p, h1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // S-  : 2 mod 4
+        cs[ci++] = {ws.operand[2].p, e0, w / 8, dct_pair_kpad(f64, w / 4), w / 8};      // SSS : 0 mod 8
+        cs[ci++] = {ws.operand[3].p, e1, w / 8, dct_pair_kpad(f64, w / 4), w / 8};      // SS- : 4 mod 8
     } else {
         const void *q0 = nullptr, *q1 = nullptr;
         SSW_TRY(get_basis(ctx, w / 2, false, f64, 3, &q0));
         SSW_TRY(get_basis(ctx, w / 2, false, f64, 4, &q1));
-        cs[0] = {ws.operand[1].p, b1, w / 2, dct_pair_kpad(f64, w), w / 2};          // D  : odd
-        cs[1] = {ws.operand[2].p, q0, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SS : 0 mod 4
-        cs[2] = {ws.operand[3].p, q1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SD : 2 mod 4
+        cs[ci++] = {ws.operand[2].p, q0, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SS : 0 mod 4
+        cs[ci++] = {ws.operand[3].p, q1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SD : 2 mod 4
     }
-    size_t goff[4], gtotal = 0;
-    for (unsigned c = 0; c < plan.n_classes; ++c) { goff[c] = gtotal; gtotal += cs[c].kp * plan.c[c].cap * esz; }
+    if (ci != plan.n_classes) return SSW_ERR_BAD_ARG;
+    size_t goff[5], goff2[5], gtotal = 0;
+    for (unsigned c = 0; c < plan.n_classes; ++c) {
+        goff[c] = gtotal; gtotal += cs[c].kp * plan.c[c].cap * esz;
+        goff2[c] = gtotal; if (cs[c].x2) gtotal += cs[c].kp * plan.c[c].cap * esz;
+    }
     SSW_TRY(grow(ws.gathered, gtotal));
     char* gathered = (char*)ws.gathered.p;
     float* t_compact = (float*)ws.compact[0].p;
@@ -643,21 +704,28 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     ch.push_back({true, [=](hipStream_t st) -> int {
         SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
         StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, prep_bytes);
-        if (levels == 3) return launch_dct_pair_prep8_rows(st, f64, u8 ? 2 : 1, rgb, n, w, h, o2, o3, o0, o1, nullptr, nullptr);
-        return launch_dct_pair_prep4_rows_rgb(st, f64, u8, rgb, n, w, h, o2, o3, o1, nullptr, nullptr);
+        if (levels == 3) SSW_TRY(launch_dct_pair_prep8_rows(st, f64, u8 ? 2 : 1, rgb, n, w, h, o2, o3, o0, o1, nullptr, nullptr));
+        else SSW_TRY(launch_dct_pair_prep4_rows_rgb(st, f64, u8, rgb, n, w, h, o2, o3, o1, nullptr, nullptr));
+        return sp ? launch_dct_pair_rotate(st, (const double*)o1, (const double*)rot, sp, lines, w) : SSW_OK;
     }});
     double flop = 0.0;
-    for (unsigned c = 0; c < plan.n_classes; ++c) flop += 2.0 * (double)(n * h) * plan.c[c].cap * (double)cs[c].ktrue;
+    for (unsigned c = 0; c < plan.n_classes; ++c) flop += (cs[c].x2 ? 4.0 : 2.0) * (double)lines * plan.c[c].cap * (double)cs[c].ktrue;
     ch.push_back({false, [=](hipStream_t st) -> int {
-        for (unsigned c = 0; c < plan.n_classes; ++c)
+        for (unsigned c = 0; c < plan.n_classes; ++c) {
             SSW_TRY(launch_prune_gather_basis(st, rows + plan.c[c].off, plan.c[c].cap, cs[c].basis, cs[c].src_rows,
                                               cs[c].kp / (64 / esz), gathered + goff[c]));
+            if (cs[c].x2) SSW_TRY(launch_prune_gather_basis(st, rows + plan.c[c].off, plan.c[c].cap, cs[c].basis2, cs[c].src_rows,
+                                                            cs[c].kp / (64 / esz), gathered + goff2[c], true));
+        }
         StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
         for (unsigned c = 0; c < plan.n_classes; ++c) {
-            if (f64) SSW_TRY(launch_dct_pair_gemm_rows_subset_f64(st, (const double*)cs[c].x, (const double*)(gathered + goff[c]), plan.c[c].cap,
-                                                                  (unsigned)cs[c].kp, t_compact, (unsigned)cap, plan.c[c].off, n * h));
+            if (cs[c].x2) SSW_TRY(launch_dct_pair_gemm_rows_subset_split_f64(st, (const double*)cs[c].x, (const double*)cs[c].x2, (const double*)(gathered + goff[c]),
+                                                                             (const double*)(gathered + goff2[c]), plan.c[c].cap, (unsigned)cs[c].kp, t_compact,
+                                                                             (unsigned)cap, plan.c[c].off, lines));
+            else if (f64) SSW_TRY(launch_dct_pair_gemm_rows_subset_f64(st, (const double*)cs[c].x, (const double*)(gathered + goff[c]), plan.c[c].cap,
+                                                                       (unsigned)cs[c].kp, t_compact, (unsigned)cap, plan.c[c].off, lines));
             else     SSW_TRY(launch_dct_pair_gemm_rows_subset_f32(st, (const float*)cs[c].x, (const float*)(gathered + goff[c]), plan.c[c].cap,
-                                                                  (unsigned)cs[c].kp, t_compact, (unsigned)cap, plan.c[c].off, n * h));
+                                                                  (unsigned)cs[c].kp, t_compact, (unsigned)cap, plan.c[c].off, lines));
         }
         return SSW_OK;
     }});
