@@ -35,6 +35,28 @@ namespace ssw {
 
 constexpr int PT = 256;
 constexpr int PBK = 8;
+
+#ifdef SSW_TILE_TRACE
+// diagnostic build only: per block (thread 0) the 100 MHz wall clock at entry, after the first tile is staged, after
+// the main loop and after the epilogue, plus the hardware id (XCC / SE / CU) -- tools/tile_trace.py
+__device__ unsigned long long* g_tile_trace = nullptr;
+__device__ unsigned int g_tile_trace_cap = 0;
+__device__ unsigned int g_tile_trace_n = 0;
+extern "C" int ssw_debug_set_tile_trace(void* dev_ptr, unsigned cap) {
+    unsigned long long* p = static_cast<unsigned long long*>(dev_ptr);
+    unsigned zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace), &p, sizeof(p)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace_cap), &cap, sizeof(cap)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_tile_trace_n), &zero, sizeof(zero)) != hipSuccess) return -1;
+    return 0;
+}
+extern "C" int ssw_debug_get_tile_trace_count(unsigned* n) {
+    return hipMemcpyFromSymbol(n, HIP_SYMBOL(g_tile_trace_n), sizeof(*n)) == hipSuccess ? 0 : -1;
+}
+#define SSW_TT(i) do { if (threadIdx.x == 0) tt[i] = wall_clock64(); } while (0)
+#else
+#define SSW_TT(i) do { } while (0)
+#endif
 typedef PairOutT<double> PairOut;
 
 
@@ -59,6 +81,10 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     double (*sX)[NX][BM * PBK] = reinterpret_cast<double (*)[NX][BM * PBK]>(lds);
     double (*sY)[2][BN * PBK] = reinterpret_cast<double (*)[2][BN * PBK]>(lds + SXD);
 
+#ifdef SSW_TILE_TRACE
+    unsigned long long tt[5] = {0, 0, 0, 0, 0};
+#endif
+    SSW_TT(0);
     unsigned tm, tn;
     tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
     const unsigned m0 = tm * BM, p0 = tn * (po.bn32 ? 32u : (unsigned)BN);
@@ -186,6 +212,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     gload(0);
     lstore(B0{});
     __syncthreads();
+    SSW_TT(1);
 #pragma unroll
     for (int q = 0; q < XQ; ++q) { rx1[q] = nx1[q]; if (!SAMEX) rx2[q] = nx2[q]; }
     ry1 = ny1; ry2 = ny2;
@@ -245,7 +272,33 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     fmma(fa);
     interleave(B0{});
     fmma(fb);
+    SSW_TT(2);
 
+#ifdef SSW_TILE_TRACE
+    auto trace_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x == 0) tt[4] = wall_clock64();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0 && g_tile_trace) {
+        tt[3] = wall_clock64();
+        const unsigned slot = atomicAdd(&g_tile_trace_n, 1u);
+        if (slot < g_tile_trace_cap) {
+            unsigned hwid = 0, xcc = 0;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o = g_tile_trace + 8ull * slot;
+            o[0] = tt[0]; o[1] = tt[1]; o[2] = tt[2]; o[3] = tt[3];
+            o[4] = ((unsigned long long)xcc << 32) | hwid;
+            o[5] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(COLS * 1000 + EPI * 100 + SAMEX * 10 + SUB);
+            o[6] = ((unsigned long long)Kp << 32) | NP;
+            o[7] = tt[4];
+        }
+    }
+    };
+#else
+    auto trace_end = [] {};
+#endif
     if (po.pm) {                               // split odd half: cosine part +/- sine part (block-uniform branch)
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -294,6 +347,100 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             }
         }
     };
+    // Row passes, EPI_FWD / EPI_INV_O.  While this wave stores its results the other resident block streams f64 MFMAs
+    // on the same SIMD, and a VALU instruction of this wave then gets an issue slot about once per MFMA (64 cycles):
+    // measured, the epilogue takes ~70 cycles per VALU instruction (tools/tile_trace.py) -- 36 us of a 125 us tile with
+    // per-element bounds checks and 64-bit addresses.  So: buffer stores whose lane offsets are computed once per
+    // 16-pair tile, rows advanced through the scalar offset, invalid lanes / rows dropped by the buffer's range check
+    // (offset 2^31 >= num_records) instead of branches; per output element one conversion and one store.
+    if constexpr (!COLS && (EPI == EPI_FWD || EPI == EPI_INV_O)) {
+        const unsigned rows_valid = L - m0 < (unsigned)BM ? L - m0 : (unsigned)BM;
+        const unsigned long long region = (unsigned long long)rows_valid * W * 4ull;
+        if (region < 0x80000000ull && (EPI == EPI_FWD || n == W)) {
+            constexpr unsigned OOB = 0x80000000u;
+            const bool plain = ep.first == 1.0f && ep.base == 1.0f;
+            const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.out + (size_t)m0 * W), 0, (unsigned)region, 0x00020000);
+            const unsigned swm = __builtin_amdgcn_readfirstlane(wm);
+            auto st = [&](float v, unsigned voff, unsigned soff) {
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orr, voff, soff, 0);
+            };
+            if constexpr (EPI == EPI_FWD) {
+                unsigned vo1[NJ], vo2[NJ];
+                float f1[NJ], f2[NJ];
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn) {
+                    const unsigned pair = p0 + wn + 16 * jn + li;
+                    const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
+                    vo1[jn] = (pair < NP && i1 < po.lim ) ? (lq * W + i1) * 4u : OOB;
+                    vo2[jn] = (pair < NP && i2 < po.lim && second_out) ? (lq * W + i2) * 4u : OOB;
+                    f1[jn] = i1 == 0 ? ep.first : ep.base;
+                    f2[jn] = i2 == 0 ? ep.first : ep.base;
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned soff = (swm + 16 * i + 4 * r) * W * 4u;
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn) {
+                            float v1 = (float)acc1[i][jn][r], v2 = (float)acc2[i][jn][r];
+                            if (!plain) { v1 *= f1[jn]; v2 *= f2[jn]; }
+                            st(v1, vo1[jn], soff);
+                            st(v2, vo2[jn], soff);
+                        }
+                    }
+            } else {
+                // x[n1] = E[n1] + a1, x[n-1-n1] = E[n1] - a1, x[n2] = E[n2] + a2, x[n-1-n2] = E[n2] - a2; E read as doubles
+                const __amdgpu_buffer_rsrc_t trr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp + (size_t)m0 * (n / 2)), 0, (unsigned)region, 0x00020000);
+                unsigned vt[NJ][2], vp[NJ][2], vm[NJ][2];
+                float fp[NJ][2];
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn) {
+                    const unsigned pair = p0 + wn + 16 * jn + li;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * pair;
+                        const bool ok = pair < NP && nn < n / 2;
+                        vt[jn][h2] = ok ? (lq * (n / 2) + nn) * 8u : OOB;
+                        vp[jn][h2] = ok ? (lq * W + nn) * 4u : OOB;
+                        vm[jn][h2] = ok ? (lq * W + (n - 1 - nn)) * 4u : OOB;
+                        fp[jn][h2] = nn == 0 ? ep.first : ep.base;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    double e[4][NJ][2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned soff = (swm + 16 * i + 4 * r) * (n / 2) * 8u;
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(trr, vt[jn][h2], soff, 0);
+                                e[r][jn][h2] = __hiloint2double((int)raw[1], (int)raw[0]);
+                            }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned soff = (swm + 16 * i + 4 * r) * W * 4u;
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const double a = h2 ? acc2[i][jn][r] : acc1[i][jn][r];
+                                float vpl = (float)(e[r][jn][h2] + a), vmi = (float)(e[r][jn][h2] - a);
+                                if (!plain) { vpl *= fp[jn][h2]; vmi *= ep.base; }
+                                st(vpl, vp[jn][h2], soff);
+                                st(vmi, vm[jn][h2], soff);
+                            }
+                    }
+                }
+            }
+            trace_end();
+            return;
+        }
+    }
     if constexpr (!COLS) {
 #pragma unroll
         for (int jn = 0; jn < NJ; ++jn) {
@@ -350,6 +497,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                     *reinterpret_cast<f64x2*>(tbase + (size_t)idx * W) = v;
                 }
             }
+        trace_end();
         return;
       }
     } else {
@@ -459,6 +607,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                     }
                 }
         }
+        trace_end();
         return;
       }
     }
@@ -522,6 +671,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 }
         }
     }
+    trace_end();
     };
     // (a tail of at most 16 pairs -- 270 = 4 x 64 + 14 at full HD, the 16-pair classes of the pruned transform -- runs
     // one 16-pair MFMA tile per wave instead of two)
