@@ -561,6 +561,137 @@ __global__ __launch_bounds__(256) void pair_prep8_rows_kernel(const void* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// "Deep" forward pre-pass of a row pass (n % 64 == 0): everything the five GEMM launches of the pass consume, from one
+// sweep over the source (see "Split odd half" above):
+//   level 1   S = x + mirror, D = x - mirror                          (length n/2)
+//   D   -> rotation + fold -> AS, BD, AD, BS        (n/8 each)        odd frequencies          (launches E, O)
+//   level 2   SS = S + mirror, SD = S - mirror                        (length n/4)
+//   SD  -> rotation + fold -> AS2, BD2, AD2, BS2    (n/16 each)       frequencies 2 mod 4      (launches E', O')
+//   level 3   R1 = SS + mirror, R2 = SS - mirror    (n/8 each)        frequencies 0 and 4 mod 8 (launch R)
+// One thread = 4 consecutive e < n/16 of one line: the 16 quads of x that meet in them (quad u mirrors quad 15 - u).
+// Planes are k-blocked, K8 = kpad(n/4) (>= n/8) and K16 = kpad(n/8) (>= n/16) wide, zero padded.
+// ---------------------------------------------------------------------------------------------
+// One unit of the split: four consecutive e = base .. base + 3 of a DCT-IV input d of length M (Mh = M/2) given as
+// ascending quads  dA: d[base + i], dB: d[Mh-4-base + i], dC: d[Mh+base + i], dD: d[M-4-base + i];
+// rot: [0, Mh) cos psi, [Mh, 2 Mh) sin psi.  Same operations in the same order as pair_rotate_kernel.
+template <typename T>
+__device__ inline void split_unit(const vec4_t<T>& dA, const vec4_t<T>& dB, const vec4_t<T>& dC, const vec4_t<T>& dD,
+                                  const double* __restrict__ rot, unsigned base, unsigned Mh,
+                                  vec4_t<T>& as, vec4_t<T>& bd, vec4_t<T>& ad, vec4_t<T>& bs) {
+    const f64x4 c = *reinterpret_cast<const f64x4*>(rot + base), s = *reinterpret_cast<const f64x4*>(rot + Mh + base);
+    const f64x4 cm = *reinterpret_cast<const f64x4*>(rot + Mh - 4 - base), sm = *reinterpret_cast<const f64x4*>(rot + 2 * Mh - 4 - base);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const T d0 = dA[i], d1 = dB[3 - i], d2 = dC[i], d3 = dD[3 - i];
+        const T cc = (T)c[i], ss = (T)s[i], ccm = (T)cm[3 - i], ssm = (T)sm[3 - i];
+        const T a = d0 * cc + d3 * ss, b = d3 * cc - d0 * ss;
+        const T am = d1 * ccm + d2 * ssm, bm = d2 * ccm - d1 * ssm;
+        as[i] = a + am;
+        ad[i] = a - am;
+        bs[i] = b + bm;
+        bd[i] = b - bm;
+    }
+}
+
+struct DeepPlanes {        // device pointers of one pass's operand planes
+    void *as, *bd, *ad, *bs;         // K8 wide
+    void *r1, *r2;                   // K8 wide
+    void *as2, *bd2, *ad2, *bs2;     // K16 wide
+};
+
+template <typename T, int SRC /*0 plane, 1 rgb f32, 2 rgb u8*/, bool WITH_IQ>
+__global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __restrict__ SRCP, DeepPlanes dp,
+                                                              const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                              float* __restrict__ IP, float* __restrict__ QP,
+                                                              unsigned rows, unsigned W, unsigned K8, unsigned K16, unsigned tiles_e) {
+    const unsigned Nh = W / 2, Nq = W / 4, N8 = W / 8, N16 = W / 16;
+    const unsigned e0 = (blockIdx.x % tiles_e) * 32 + (threadIdx.x & 7) * 4;
+    const unsigned row = (blockIdx.x / tiles_e) * 32 + (threadIdx.x >> 3);
+    if (row >= rows || e0 >= K16) return;
+    T* AS = static_cast<T*>(dp.as); T* BD = static_cast<T*>(dp.bd); T* AD = static_cast<T*>(dp.ad); T* BS = static_cast<T*>(dp.bs);
+    T* R1 = static_cast<T*>(dp.r1); T* R2 = static_cast<T*>(dp.r2);
+    T* AS2 = static_cast<T*>(dp.as2); T* BD2 = static_cast<T*>(dp.bd2); T* AD2 = static_cast<T*>(dp.ad2); T* BS2 = static_cast<T*>(dp.bs2);
+    auto put = [&](T* plane, unsigned k, const vec4_t<T>& v) { *reinterpret_cast<vec4_t<T>*>(plane + blk_index<T>(row, k, rows)) = v; };
+    const vec4_t<T> zero = {0, 0, 0, 0};
+    if (e0 >= N16) {                                              // padding of the n/16-wide planes
+        put(AS2, e0, zero); put(BD2, e0, zero); put(AD2, e0, zero); put(BS2, e0, zero);
+        return;
+    }
+    // quads of x, ascending positions inside a quad
+    const unsigned pos[8] = {e0, N8 - 4 - e0, N8 + e0, Nq - 4 - e0, Nq + e0, 3 * N8 - 4 - e0, 3 * N8 + e0, Nh - 4 - e0};
+    f32x4 x[16];
+    if (SRC == 0) {
+        const float* xr = static_cast<const float*>(SRCP) + (size_t)row * W;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = *reinterpret_cast<const f32x4*>(xr + pos[u]);
+            x[15 - u] = *reinterpret_cast<const f32x4*>(xr + (W - 4 - pos[u]));
+        }
+    } else {
+        const void* base = SRC == 2 ? static_cast<const void*>(static_cast<const uint8_t*>(SRCP) + (size_t)row * W * 3)
+                                    : static_cast<const void*>(static_cast<const float*>(SRCP) + (size_t)row * W * 3);
+        f32x4 iv, qv;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const unsigned p = u < 8 ? pos[u] : W - 4 - pos[15 - u];
+            load_yiq4<SRC == 2, WITH_IQ>(base, p, x[u], iv, qv);
+            if (WITH_IQ) {
+                *reinterpret_cast<f32x4*>(IP + (size_t)row * W + p) = iv;
+                *reinterpret_cast<f32x4*>(QP + (size_t)row * W + p) = qv;
+            }
+        }
+    }
+    // level 1 at the positions of quads 0..7
+    vec4_t<T> S[8], D[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            S[u][i] = (T)x[u][i] + (T)x[15 - u][3 - i];
+            D[u][i] = (T)x[u][i] - (T)x[15 - u][3 - i];
+        }
+    // D (DCT-IV input of length n/2): the unit at e0 and its mirror unit at n/8 - 4 - e0
+    {
+        vec4_t<T> as, bd, ad, bs;
+        split_unit<T>(D[0], D[3], D[4], D[7], rot1, e0, Nq, as, bd, ad, bs);
+        put(AS, e0, as); put(BD, e0, bd); put(AD, e0, ad); put(BS, e0, bs);
+        split_unit<T>(D[1], D[2], D[5], D[6], rot1, N8 - 4 - e0, Nq, as, bd, ad, bs);
+        put(AS, N8 - 4 - e0, as); put(BD, N8 - 4 - e0, bd); put(AD, N8 - 4 - e0, ad); put(BS, N8 - 4 - e0, bs);
+    }
+    // level 2 on S (length n/2): quad u mirrors quad 7 - u
+    vec4_t<T> SS[4], SD[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            SS[u][i] = S[u][i] + S[7 - u][3 - i];
+            SD[u][i] = S[u][i] - S[7 - u][3 - i];
+        }
+    // SD (DCT-IV input of length n/4): one unit at e0
+    {
+        vec4_t<T> as, bd, ad, bs;
+        split_unit<T>(SD[0], SD[1], SD[2], SD[3], rot2, e0, N8, as, bd, ad, bs);
+        put(AS2, e0, as); put(BD2, e0, bd); put(AD2, e0, ad); put(BS2, e0, bs);
+    }
+    // level 3 on SS (length n/4): quad 0 mirrors quad 3, quad 1 mirrors quad 2
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        vec4_t<T> r1, r2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            r1[i] = SS[u][i] + SS[3 - u][3 - i];
+            r2[i] = SS[u][i] - SS[3 - u][3 - i];
+        }
+        put(R1, pos[u], r1);
+        put(R2, pos[u], r2);
+    }
+    if (e0 == 0)
+        for (unsigned z = N8; z < K8; z += 4) {
+            put(AS, z, zero); put(BD, z, zero); put(AD, z, zero); put(BS, z, zero); put(R1, z, zero); put(R2, z, zero);
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Three folding levels on a forward COLUMN pass (H % 32 == 0; pays from ~3000 rows: 8K frames): the same
 // folds as pair_prep8_rows_kernel, per column, transposed through LDS.  Lines = (frame, column); one block =
 // 32 eighth-indices e x 32 columns; per (e, column) the 8 rows that meet in e:
@@ -803,6 +934,36 @@ int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t
                                void* r1, void* r2, void* m, void* p) {
     return f64 ? prep8_cols_impl<double>(st, in, n_frames, w, h, (double*)r1, (double*)r2, (double*)m, (double*)p)
                : prep8_cols_impl<float>(st, in, n_frames, w, h, (float*)r1, (float*)r2, (float*)m, (float*)p);
+}
+
+// deep forward row pre-pass: src_kind 0 = f32 plane, 1 / 2 = interleaved RGB f32 / u8 (ip / qp: I, Q planes out or null);
+// base: 6 planes of lines * K8 doubles (AS BD AD BS R1 R2) followed by 4 planes of lines * K16 (AS2 BD2 AD2 BS2)
+bool dct_pair_can_deep_rows(size_t len) { return len % 64 == 0 && len >= 256; }
+size_t dct_pair_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + 4 * dct_pair_split_kpad(len / 2)); }
+int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
+                                const double* rot1, const double* rot2, float* ip, float* qp) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull || !dct_pair_can_deep_rows(w)) return SSW_ERR_BAD_DIMS;
+    const unsigned K8 = (unsigned)dct_pair_split_kpad(w), K16 = (unsigned)dct_pair_split_kpad(w / 2);
+    const unsigned tiles_e = (K16 + 31) / 32;
+    const size_t rows = n_frames * h;
+    const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_e;
+    if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    DeepPlanes dp;
+    double* p = base;
+    const size_t p8 = rows * K8, p16 = rows * K16;
+    dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
+    p += 6 * p8;
+    dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
+    const bool iq = ip && qp;
+#define SSW_PREP16(SRCV, IQV) pair_prep16_rows_kernel<double, SRCV, IQV><<<(unsigned)nblk, 256, 0, st>>>( \
+        src, dp, rot1, rot2, ip, qp, (unsigned)rows, (unsigned)w, K8, K16, tiles_e)
+    if (src_kind == 0) SSW_PREP16(0, false);
+    else if (src_kind == 1) { if (iq) SSW_PREP16(1, true); else SSW_PREP16(1, false); }
+    else                    { if (iq) SSW_PREP16(2, true); else SSW_PREP16(2, false); }
+#undef SSW_PREP16
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
 }
 
 }  // namespace ssw

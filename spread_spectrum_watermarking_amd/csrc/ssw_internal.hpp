@@ -135,6 +135,12 @@ size_t dct_pair_split_basis_rows(size_t len, int which);
 int launch_make_split_basis_blocked(hipStream_t st, size_t n, bool inverse, int which, double* out);
 int launch_make_rot_table(hipStream_t st, size_t n, double* out);
 int launch_dct_pair_rotate(hipStream_t st, const double* p, const double* rot, double* sp, size_t lines, size_t len);
+// deep forward row pre-pass (len % 64 == 0): D and SD split, SS folded a third time, in one sweep over the source
+// (f32 plane or interleaved RGB); base: AS BD AD BS R1 R2 (lines * split_kpad(len) each), AS2 BD2 AD2 BS2 (lines * split_kpad(len/2))
+bool dct_pair_can_deep_rows(size_t len);
+size_t dct_pair_deep_elems(size_t lines, size_t len);
+int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
+                                const double* rot1, const double* rot2, float* ip, float* qp);
 int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const float* y, unsigned cap, unsigned Kp, float* out,
                                          unsigned out_stride, unsigned off, size_t lines);
 
@@ -146,7 +152,7 @@ constexpr uint32_t PRUNE_NEG = 0x40000000u;              // rows[] flag: negate 
 struct PruneClass { unsigned mod, rem, cap, off, rem2 = PRUNE_NO_REM, radd = 0; };
 struct PrunePlan {
     unsigned n_classes = 0;
-    PruneClass c[5];
+    PruneClass c[6];
     unsigned W = 0, cap_total = 0;
 };
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,

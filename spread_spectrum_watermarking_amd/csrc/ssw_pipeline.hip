@@ -199,6 +199,13 @@ double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t
     return 4.0 * lines * np * k;
 }
 
+// doubles of the lane's sixth operand buffer: the split planes of either pass, or the deep row pre-pass's ten planes
+size_t split_scratch_elems(size_t n, size_t w, size_t h) {
+    size_t e = dct_pair_split_elems(n, w, h);
+    if (dct_pair_can_deep_rows(w)) e = std::max(e, dct_pair_deep_elems(n * h, w));
+    return e;
+}
+
 // One pass of the separable transform (src -> dst along rows or columns) appended to `ch`.
 int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass, bool is_row, const float* src, float* dst,
                Epilogue ep, Chain& ch, bool* fused_rgb = nullptr) {
@@ -241,8 +248,39 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
         if (split) {
             for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len, inverse, true, 5 + b, &sb[b]));
             SSW_TRY(get_basis(ctx, len, false, true, 9, &rot));
-            SSW_TRY(grow(ws.operand[5], dct_pair_split_elems(n, w, h) * sizeof(double)));
+            SSW_TRY(grow(ws.operand[5], split_scratch_elems(n, w, h) * sizeof(double)));
             sp = (double*)ws.operand[5].p;
+        }
+        // forward row passes of 64-divisible length: one pre-pass writes the operands of five launches (D and SD split,
+        // SS folded a third time)
+        const bool deep = split && !inverse && is_row && dct_pair_can_deep_rows(len);
+        if (deep) {
+            const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr;
+            SSW_TRY(get_basis(ctx, len / 4, false, true, 3, &e0));
+            SSW_TRY(get_basis(ctx, len / 4, false, true, 4, &e1));
+            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, false, true, 5 + b, &sb2[b]));
+            SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
+            const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
+            double* q = sp + 6 * p8;
+            const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
+            const void *t0 = sb2[0], *t1 = sb2[1], *t2 = sb2[2], *t3 = sb2[3];
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_prep, st, prep_bytes);
+                return launch_dct_pair_prep16_rows(st, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
+                                                   (const double*)rot, (const double*)rot2, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
+            }});
+            const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h);
+            const double f_all = f_main + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
+            ch.push_back({false, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_pass, st, f_all);
+                SSW_TRY(pair_gemm(st, true, is_row, false, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, nullptr, n, w, h, ep));
+                SSW_TRY(pair_gemm(st, true, is_row, false, 3, 1, q, q + p16, t0, t1, dst, nullptr, n, w, h, ep));
+                SSW_TRY(pair_gemm(st, true, is_row, false, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, nullptr, n, w, h, ep));
+                StageTimer tm(ctx, st_main, st, f_main);
+                SSW_TRY(pair_gemm(st, true, is_row, false, 3, 0, sp, sp + p8, sb0, sb1, dst, nullptr, n, w, h, ep));
+                return pair_gemm(st, true, is_row, false, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, nullptr, n, w, h, ep);
+            }});
+            return SSW_OK;
         }
         // the odd half of the full-length transform from the operand plane `odd`: one launch, or rotate + two
         auto odd_rotate = [=](hipStream_t st, const void* odd) -> int {
@@ -584,6 +622,7 @@ struct PruneSetup {
     PrunePlan plan;
     int levels = 0;                 // folding levels of the forward row pass: 2 or 3
     bool split = false;             // odd frequencies through the split odd half (two classes instead of one)
+    bool deep = false;              // deep row pre-pass: frequencies 2 mod 4 split as well, 0 / 4 mod 8 from the third level
 };
 
 // capacity of the compact plane in frequency columns: the index lists of natural spectra use ~3 sqrt(k)
@@ -623,7 +662,13 @@ PruneSetup make_prune_setup(const ssw_ctx* ctx, bool f64, size_t n, size_t w, si
     } else {
         add(2, 1, c / 2);
     }
-    if (three) {
+    ps.deep = ps.split && dct_pair_can_deep_rows(w);
+    if (ps.deep) {                        // v = 2 (8i +/- 1) -> class E' row i (= (v + 2) / 16), v = 2 (8i + 5) | 2 (8i + 3) -> class O' row i
+        add(16, 2, c / 8, 14, 2);
+        add(16, 10, c / 8, 6, 0);
+        add(8, 0, c / 8);
+        add(8, 4, c / 8);
+    } else if (three) {
         add(4, 2, c / 4);
         add(8, 0, c / 8);
         add(8, 4, c / 8);
@@ -653,26 +698,40 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     uint32_t* rows = pos + w;
     // class -> image operand plane(s), cached basis plane(s), padded / true sum length
     struct ClassSrc { const void* x; const void* basis; size_t src_rows, kp, ktrue; const void* x2 = nullptr; const void* basis2 = nullptr; };
-    ClassSrc cs[5];
+    ClassSrc cs[6];
     unsigned ci = 0;
     const size_t lines = n * h;
-    const void* rot = nullptr;
+    const void *rot = nullptr, *rot2 = nullptr;
     double* sp = nullptr;
     if (ps.split) {
         const void* sb[4];
         for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w, false, true, 5 + b, &sb[b]));
         SSW_TRY(get_basis(ctx, w, false, true, 9, &rot));
         const size_t kp8 = dct_pair_split_kpad(w), plane = lines * kp8;
-        SSW_TRY(grow(ws.operand[5], dct_pair_split_elems(n, w, h) * sizeof(double)));
+        SSW_TRY(grow(ws.operand[5], split_scratch_elems(n, w, h) * sizeof(double)));
         sp = (double*)ws.operand[5].p;
         cs[ci++] = {sp, sb[0], dct_pair_split_basis_rows(w, 0), kp8, w / 8, sp + plane, sb[1]};                  // AS x cosE, BD x sinE
         cs[ci++] = {sp + 2 * plane, sb[2], dct_pair_split_basis_rows(w, 2), kp8, w / 8, sp + 3 * plane, sb[3]};  // AD x cosO, BS x sinO
+        if (ps.deep) {
+            const void *sb2[4], *e0 = nullptr, *e1 = nullptr;
+            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w / 2, false, true, 5 + b, &sb2[b]));
+            SSW_TRY(get_basis(ctx, w / 2, false, true, 9, &rot2));
+            SSW_TRY(get_basis(ctx, w / 4, false, true, 3, &e0));
+            SSW_TRY(get_basis(ctx, w / 4, false, true, 4, &e1));
+            const size_t kp16 = dct_pair_split_kpad(w / 2), p16 = lines * kp16;
+            double* q = sp + 6 * plane;
+            cs[ci++] = {q, sb2[0], dct_pair_split_basis_rows(w / 2, 0), kp16, w / 16, q + p16, sb2[1]};              // AS2 x cosE', BD2 x sinE'
+            cs[ci++] = {q + 2 * p16, sb2[2], dct_pair_split_basis_rows(w / 2, 2), kp16, w / 16, q + 3 * p16, sb2[3]}; // AD2 x cosO', BS2 x sinO'
+            cs[ci++] = {sp + 4 * plane, e0, w / 8, kp8, w / 8};                                                      // R1 (SSS): 0 mod 8
+            cs[ci++] = {sp + 5 * plane, e1, w / 8, kp8, w / 8};                                                      // R2 (SS-): 4 mod 8
+        }
     } else {
         const void* b1 = nullptr;
         SSW_TRY(get_basis(ctx, w, false, f64, 4, &b1));
         cs[ci++] = {ws.operand[1].p, b1, w / 2, dct_pair_kpad(f64, w), w / 2};       // x- | D : odd
     }
-    if (ps.levels == 3) {
+    if (ps.deep) {
+    } else if (ps.levels == 3) {
         const void *h1 = nullptr, *e0 = nullptr, *e1 = nullptr;
         SSW_TRY(get_basis(ctx, w / 2, false, f64, 4, &h1));
         SSW_TRY(get_basis(ctx, w / 4, false, f64, 3, &e0));
@@ -688,7 +747,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         cs[ci++] = {ws.operand[3].p, q1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SD : 2 mod 4
     }
     if (ci != plan.n_classes) return SSW_ERR_BAD_ARG;
-    size_t goff[5], goff2[5], gtotal = 0;
+    size_t goff[6], goff2[6], gtotal = 0;
     for (unsigned c = 0; c < plan.n_classes; ++c) {
         goff[c] = gtotal; gtotal += cs[c].kp * plan.c[c].cap * esz;
         goff2[c] = gtotal; if (cs[c].x2) gtotal += cs[c].kp * plan.c[c].cap * esz;
@@ -698,12 +757,14 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     float* t_compact = (float*)ws.compact[0].p;
     void *o0 = ws.operand[0].p, *o1 = ws.operand[1].p, *o2 = ws.operand[2].p, *o3 = ws.operand[3].p;
     const int levels = ps.levels;
+    const bool deep = ps.deep;
     const double px = (double)n * (double)w * (double)h;
     const double prep_bytes = px * ((u8 ? 3.0 : 12.0) + (double)esz);
     // the set of columns, then Reader::derived's colour conversion + operand pre-pass (same kernels as the full path)
     ch.push_back({true, [=](hipStream_t st) -> int {
         SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
         StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, prep_bytes);
+        if (deep) return launch_dct_pair_prep16_rows(st, u8 ? 2 : 1, rgb, n, w, h, sp, (const double*)rot, (const double*)rot2, nullptr, nullptr);
         if (levels == 3) SSW_TRY(launch_dct_pair_prep8_rows(st, f64, u8 ? 2 : 1, rgb, n, w, h, o2, o3, o0, o1, nullptr, nullptr));
         else SSW_TRY(launch_dct_pair_prep4_rows_rgb(st, f64, u8, rgb, n, w, h, o2, o3, o1, nullptr, nullptr));
         return sp ? launch_dct_pair_rotate(st, (const double*)o1, (const double*)rot, sp, lines, w) : SSW_OK;
