@@ -778,6 +778,137 @@ __global__ __launch_bounds__(256) void pair_prep8_cols_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// The deep forward pre-pass of a COLUMN pass (H % 16 == 0): the same planes as pair_prep16_rows_kernel, lines =
+// (frame, column), transposed through LDS.  One block = 32 units e < H/16 x 32 columns; per (e, column) the 16 rows
+// that meet in e (row u mirrors row 15 - u).  Four LDS rounds of four planes each (34 KB):
+//   0: AS BD AD BS at e            1: the same planes at the mirror unit H/8 - 1 - e
+//   2: AS2 BD2 AD2 BS2 at e        3: R1 R2 at e and at H/8 - 1 - e
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ inline void split_one(T d0, T d1, T d2, T d3, const double* __restrict__ rot, unsigned e, unsigned Mh, T& as, T& bd, T& ad, T& bs) {
+    const T cc = (T)rot[e], ss = (T)rot[Mh + e], ccm = (T)rot[Mh - 1 - e], ssm = (T)rot[2 * Mh - 1 - e];
+    const T a = d0 * cc + d3 * ss, b = d3 * cc - d0 * ss;
+    const T am = d1 * ccm + d2 * ssm, bm = d2 * ccm - d1 * ssm;
+    as = a + am;
+    ad = a - am;
+    bs = b + bm;
+    bd = b - bm;
+}
+// v[0 .. nvalid) -> plane positions k0 .. (ascending); one 32-byte store when the run is a whole aligned quad
+template <typename T>
+__device__ inline void store_run(T* __restrict__ plane, size_t line, size_t lines, unsigned k0, const T (&v)[4], unsigned nvalid) {
+    if (nvalid == 4 && (k0 & 3u) == 0) {
+        *reinterpret_cast<vec4_t<T>*>(plane + blk_index<T>(line, k0, lines)) = (vec4_t<T>){v[0], v[1], v[2], v[3]};
+    } else {
+        for (unsigned j = 0; j < nvalid; ++j) plane[blk_index<T>(line, k0 + j, lines)] = v[j];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
+                                                              const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                              unsigned W, unsigned H, unsigned K8, unsigned K16,
+                                                              unsigned n_frames, unsigned tiles_e, unsigned tiles_c) {
+    __shared__ T s[4][32][33];
+    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = H / 16;
+    const unsigned z = blockIdx.x / (tiles_e * tiles_c);
+    const unsigned tt = blockIdx.x % (tiles_e * tiles_c);
+    const unsigned e0 = (tt % tiles_e) * 32, c0 = (tt / tiles_e) * 32;
+    const float* __restrict__ Pz = IN + (size_t)z * H * W;
+    const unsigned tid = threadIdx.x;
+    const unsigned er = tid >> 3, cq = (tid & 7) * 4;              // load side: one e, 4 columns
+    const unsigned cl = tid & 31, kq = (tid >> 5) * 4;             // store side: one column, 4 consecutive e
+    const unsigned cw = c0 + cl, ew = e0 + kq;
+    const size_t line = (size_t)z * W + cw, lines = (size_t)n_frames * W;
+    T* planes8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs),
+                     static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
+    T* planes16[4] = {static_cast<T*>(dp.as2), static_cast<T*>(dp.bd2), static_cast<T*>(dp.ad2), static_cast<T*>(dp.bs2)};
+    const unsigned e = e0 + er;
+    const bool unit_ok = e < H16;
+    const unsigned ec = unit_ok ? e : 0;                           // table indices stay in range
+    f32x4 x[16];
+    {
+        unsigned c = c0 + cq;
+        c = c + 4 <= W ? c : W - 4;                               // W % 4 == 0; duplicates are never written out
+#pragma unroll
+        for (int u = 0; u < 16; ++u) x[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (unit_ok) {
+            const unsigned rp[8] = {e, H8 - 1 - e, H8 + e, Hq - 1 - e, Hq + e, 3 * H8 - 1 - e, 3 * H8 + e, Hh - 1 - e};
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x[u] = *reinterpret_cast<const f32x4*>(Pz + (size_t)rp[u] * W + c);
+                x[15 - u] = *reinterpret_cast<const f32x4*>(Pz + (size_t)(H - 1 - rp[u]) * W + c);
+            }
+        }
+    }
+    const unsigned nvalid = !(cw < W) ? 0u : (ew >= H16 ? 0u : (H16 - ew < 4 ? H16 - ew : 4u));      // valid units of the store quad
+    auto gather = [&](int a, T (&v)[4], bool reverse) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = s[a][cl][kq + j];
+        if (reverse) {                                              // first nvalid entries, reversed
+            T w[4] = {0, 0, 0, 0};
+            for (unsigned j = 0; j < nvalid; ++j) w[j] = v[nvalid - 1 - j];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = w[j];
+        }
+    };
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+        if (round) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            T D[8], S[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                S[u] = (T)x[u][i] + (T)x[15 - u][i];
+                D[u] = (T)x[u][i] - (T)x[15 - u][i];
+            }
+            T o[4] = {0, 0, 0, 0};
+            if (round == 0) {
+                split_one<T>(D[0], D[3], D[4], D[7], rot1, ec, Hq, o[0], o[1], o[2], o[3]);
+            } else if (round == 1) {
+                split_one<T>(D[1], D[2], D[5], D[6], rot1, H8 - 1 - ec, Hq, o[0], o[1], o[2], o[3]);
+            } else {
+                T SS[4], SD[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { SS[u] = S[u] + S[7 - u]; SD[u] = S[u] - S[7 - u]; }
+                if (round == 2) {
+                    split_one<T>(SD[0], SD[1], SD[2], SD[3], rot2, ec, H8, o[0], o[1], o[2], o[3]);
+                } else {
+                    o[0] = SS[0] + SS[3]; o[1] = SS[0] - SS[3];      // R1, R2 at e
+                    o[2] = SS[1] + SS[2]; o[3] = SS[1] - SS[2];      // R1, R2 at H/8 - 1 - e
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) s[a][cq + i][er] = unit_ok ? o[a] : (T)0;
+        }
+        __syncthreads();
+        if (cw < W && ew < K16) {
+            T v[4];
+            if (round == 0) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { gather(a, v, false); store_run<T>(planes8[a], line, lines, ew, v, nvalid); }
+            } else if (round == 1) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { gather(a, v, true); if (nvalid) store_run<T>(planes8[a], line, lines, H8 - ew - nvalid, v, nvalid); }
+            } else if (round == 2) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { gather(a, v, false); store_run<T>(planes16[a], line, lines, ew, v, 4u); }   // zeros beyond H/16
+            } else {
+                gather(0, v, false); store_run<T>(planes8[4], line, lines, ew, v, nvalid);
+                gather(1, v, false); store_run<T>(planes8[5], line, lines, ew, v, nvalid);
+                gather(2, v, true); if (nvalid) store_run<T>(planes8[4], line, lines, H8 - ew - nvalid, v, nvalid);
+                gather(3, v, true); if (nvalid) store_run<T>(planes8[5], line, lines, H8 - ew - nvalid, v, nvalid);
+                if (ew == 0)
+                    for (unsigned k = H8; k < K8; ++k)
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) planes8[a][blk_index<T>(line, k, lines)] = (T)0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
 size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h) {
@@ -962,6 +1093,28 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
     else if (src_kind == 1) { if (iq) SSW_PREP16(1, true); else SSW_PREP16(1, false); }
     else                    { if (iq) SSW_PREP16(2, true); else SSW_PREP16(2, false); }
 #undef SSW_PREP16
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// deep forward column pre-pass (H % 16 == 0): same plane order as the row version, lines = n_frames * w
+bool dct_pair_can_deep_cols(size_t len) { return len % 16 == 0 && len >= 256; }
+int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                                const double* rot1, const double* rot2) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !dct_pair_can_deep_cols(h) || w % 4 != 0) return SSW_ERR_BAD_DIMS;
+    const unsigned K8 = (unsigned)dct_pair_split_kpad(h), K16 = (unsigned)dct_pair_split_kpad(h / 2);
+    const unsigned tiles_e = (K16 + 31) / 32, tiles_c = (unsigned)((w + 31) / 32);
+    const unsigned long long nblk = (unsigned long long)tiles_e * tiles_c * n_frames;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const size_t lines = n_frames * w;
+    DeepPlanes dp;
+    double* p = base;
+    const size_t p8 = lines * K8, p16 = lines * K16;
+    dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
+    p += 6 * p8;
+    dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
+    pair_prep16_cols_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -138,6 +138,9 @@ int launch_dct_pair_rotate(hipStream_t st, const double* p, const double* rot, d
 // deep forward row pre-pass (len % 64 == 0): D and SD split, SS folded a third time, in one sweep over the source
 // (f32 plane or interleaved RGB); base: AS BD AD BS R1 R2 (lines * split_kpad(len) each), AS2 BD2 AD2 BS2 (lines * split_kpad(len/2))
 bool dct_pair_can_deep_rows(size_t len);
+bool dct_pair_can_deep_cols(size_t len);                 // H % 16 == 0
+int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                                const double* rot1, const double* rot2);
 size_t dct_pair_deep_elems(size_t lines, size_t len);
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, float* ip, float* qp);

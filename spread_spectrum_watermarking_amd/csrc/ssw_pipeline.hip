@@ -203,6 +203,7 @@ double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t
 size_t split_scratch_elems(size_t n, size_t w, size_t h) {
     size_t e = dct_pair_split_elems(n, w, h);
     if (dct_pair_can_deep_rows(w)) e = std::max(e, dct_pair_deep_elems(n * h, w));
+    if (dct_pair_can_deep_cols(h)) e = std::max(e, dct_pair_deep_elems(n * w, h));
     return e;
 }
 
@@ -251,9 +252,9 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             SSW_TRY(grow(ws.operand[5], split_scratch_elems(n, w, h) * sizeof(double)));
             sp = (double*)ws.operand[5].p;
         }
-        // forward row passes of 64-divisible length: one pre-pass writes the operands of five launches (D and SD split,
-        // SS folded a third time)
-        const bool deep = split && !inverse && is_row && dct_pair_can_deep_rows(len);
+        // forward passes of 64-divisible (rows) / 16-divisible (columns) length: one pre-pass writes the operands of five
+        // launches (D and SD split, SS folded a third time)
+        const bool deep = split && !inverse && (is_row ? dct_pair_can_deep_rows(len) : dct_pair_can_deep_cols(len) && w % 4 == 0);
         if (deep) {
             const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr;
             SSW_TRY(get_basis(ctx, len / 4, false, true, 3, &e0));
@@ -266,6 +267,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const void *t0 = sb2[0], *t1 = sb2[1], *t2 = sb2[2], *t3 = sb2[3];
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
+                if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2);
                 return launch_dct_pair_prep16_rows(st, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
                                                    (const double*)rot, (const double*)rot2, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
             }});
