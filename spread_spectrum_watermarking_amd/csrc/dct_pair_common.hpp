@@ -32,7 +32,10 @@ __host__ __device__ inline size_t blk_index(size_t line, unsigned k, size_t rows
 //              (y + m1 i) + m2 q per channel, clamped to [0, 1]) and stores the interleaved pixel -- f32, or
 //              8-bit like into_rgb8() (round(clamp * 255)).  The colour conversion's HBM traffic (I, Q in, RGB out)
 //              then runs in the shadow of the other resident block's MFMAs and the Y plane is never written.
-enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4, EPI_INV_O_RGB = 5 };
+//   EPI_INV_OT EPI_INV_O one level down (deep inverse): the odd part of the half-length transform E combined with ITS even
+//              half T2 (`tmp`, length n/2 per line) into E itself, unrounded: T[n1] = T2[n1] + acc, T[n-1-n1] = T2[n1] - acc
+//              (`tmp_out`, length n per line; n = the half-length transform's length)
+enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4, EPI_INV_O_RGB = 5, EPI_INV_OT = 6 };
 
 template <typename T>
 struct PairOutT {
@@ -58,6 +61,7 @@ struct PairOutT {
     // index along the transformed axis is not below `lim` do not exist (the first / last pair of a class).
     unsigned pm = 0;
     unsigned lim = 0xFFFFFFFFu;
+    T* tmp_out = nullptr;     // EPI_INV_OT
 };
 
 // yiq.rs:139-147 (f32::clamp) and :163-165, :173-175: the arithmetic of color.hip / attack.hip, per pixel

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     const unsigned n = po.n, W = po.W, H = po.H;
     // one output line: element idx of the transformed axis lives at lp[idx * es] (and tp[idx * es] in T)
     // element offsets idx * es stay below 2^32 (W * H < 2^32: indices are u32 throughout)
-    auto emit = [&](float* lp, double* tp, unsigned es, unsigned pair, double a1, double a2) {
+    auto emit = [&](float* lp, double* tp, double* to, unsigned es, unsigned pair, double a1, double a2) {
         if (EPI == EPI_FWD || EPI == EPI_FWD_ADJ) {
             const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
             if (EPI == EPI_FWD_ADJ) {
@@ -333,6 +333,10 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
         } else if (EPI == EPI_INV_E) {
             tp[pair * es] = a1 + a2;
             tp[(n / 2 - 1 - pair) * es] = a1 - a2;
+        } else if (EPI == EPI_INV_OT) {
+            const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * pair;
+            if (n1 < n / 2) { const double e1 = tp[n1 * es]; to[n1 * es] = e1 + a1; to[(n - 1 - n1) * es] = e1 - a1; }
+            if (n2 < n / 2) { const double e2 = tp[n2 * es]; to[n2 * es] = e2 + a2; to[(n - 1 - n2) * es] = e2 - a2; }
         } else {
             const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * pair;      // positions in the odd part, < n/2
             if (n1 < n / 2) {
@@ -353,10 +357,10 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     // per-element bounds checks and 64-bit addresses.  So: buffer stores whose lane offsets are computed once per
     // 16-pair tile, rows advanced through the scalar offset, invalid lanes / rows dropped by the buffer's range check
     // (offset 2^31 >= num_records) instead of branches; per output element one conversion and one store.
-    if constexpr (!COLS && (EPI == EPI_FWD || EPI == EPI_INV_O)) {
+    if constexpr (!COLS && (EPI == EPI_FWD || EPI == EPI_INV_O || EPI == EPI_INV_OT)) {
         const unsigned rows_valid = L - m0 < (unsigned)BM ? L - m0 : (unsigned)BM;
         const unsigned long long region = (unsigned long long)rows_valid * W * 4ull;
-        if (region < 0x80000000ull && (EPI == EPI_FWD || n == W)) {
+        if (region < 0x80000000ull && (EPI == EPI_FWD || (EPI == EPI_INV_O && n == W) || (EPI == EPI_INV_OT && 2 * n == W))) {
             constexpr unsigned OOB = 0x80000000u;
             const bool plain = ep.first == 1.0f && ep.base == 1.0f;
             const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.out + (size_t)m0 * W), 0, (unsigned)region, 0x00020000);
@@ -389,6 +393,54 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                             st(v2, vo2[jn], soff);
                         }
                     }
+            } else if constexpr (EPI == EPI_INV_OT) {
+                // T[n1] = T2[n1] + a, T[n-1-n1] = T2[n1] - a as doubles (T lines: n doubles = W * 4 bytes, T2 lines half that)
+                const __amdgpu_buffer_rsrc_t irr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp + (size_t)m0 * (n / 2)), 0, (unsigned)(region / 2), 0x00020000);
+                const __amdgpu_buffer_rsrc_t trr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp_out + (size_t)m0 * n), 0, (unsigned)region, 0x00020000);
+                unsigned vt[NJ][2], vp[NJ][2], vm[NJ][2];
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn) {
+                    const unsigned pair = p0 + wn + 16 * jn + li;
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * pair;
+                        const bool ok = pair < NP && nn < n / 2;
+                        vt[jn][h2] = ok ? (lq * (n / 2) + nn) * 8u : OOB;
+                        vp[jn][h2] = ok ? (lq * n + nn) * 8u : OOB;
+                        vm[jn][h2] = ok ? (lq * n + (n - 1 - nn)) * 8u : OOB;
+                    }
+                }
+                auto std64 = [&](double v, unsigned voff, unsigned soff) {
+                    const u32x2 raw = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+                    __builtin_amdgcn_raw_buffer_store_b64(raw, trr, voff, soff, 0);
+                };
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    double e[4][NJ][2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned soff = (swm + 16 * i + 4 * r) * (n / 2) * 8u;
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(irr, vt[jn][h2], soff, 0);
+                                e[r][jn][h2] = __hiloint2double((int)raw[1], (int)raw[0]);
+                            }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned soff = (swm + 16 * i + 4 * r) * n * 8u;
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const double a = h2 ? acc2[i][jn][r] : acc1[i][jn][r];
+                                std64(e[r][jn][h2] + a, vp[jn][h2], soff);
+                                std64(e[r][jn][h2] - a, vm[jn][h2], soff);
+                            }
+                    }
+                }
             } else {
                 // x[n1] = E[n1] + a1, x[n-1-n1] = E[n1] - a1, x[n2] = E[n2] + a2, x[n-1-n2] = E[n2] - a2; E read as doubles
                 const __amdgpu_buffer_rsrc_t trr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp + (size_t)m0 * (n / 2)), 0, (unsigned)region, 0x00020000);
@@ -452,7 +504,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const unsigned row = m0 + wm + 16 * i + lq + 4 * r;
                     if (row >= L) continue;
-                    emit(po.out + (size_t)row * W, po.tmp + (size_t)row * (n / 2), 1, pair, acc1[i][jn][r], acc2[i][jn][r]);
+                    emit(po.out + (size_t)row * W, po.tmp + (size_t)row * (n / 2), po.tmp_out + (size_t)row * n, 1, pair, acc1[i][jn][r], acc2[i][jn][r]);
                 }
         }
     } else if constexpr (EPI == EPI_INV_E) {
@@ -495,6 +547,69 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                     if (!line_ok || pair >= NP) continue;
                     const unsigned idx = sign ? n / 2 - 1 - pair : pair;
                     *reinterpret_cast<f64x2*>(tbase + (size_t)idx * W) = v;
+                }
+            }
+        trace_end();
+        return;
+      }
+    } else if constexpr (EPI == EPI_INV_OT) {
+      if (po.wide) {
+        // Deep inverse column pass: the odd part of the half-length transform, combined with its even half T2 into T --
+        // doubles out, through the same LDS transpose as EPI_INV_E (16 result rows x CW columns per round).
+        constexpr int CW = 16 * NI, DPR = CW / 2, RPI = 64 / DPR, NRI = 16 / RPI;
+        static_assert(4 * 16 * CW * 8 <= (int)sizeof(lds), "transpose area");
+        __syncthreads();
+        double* tw = lds + wave * (16 * CW);
+        const unsigned wr0 = lq * CW + li;
+        const unsigned dq = lane % DPR, rrow = lane / DPR;
+        const unsigned line = m0 + wm + 2 * dq;
+        const bool line_ok = line < L;
+        const unsigned z = line_ok ? line / W : 0, col = line_ok ? line - z * W : 0;
+        double* tbase = po.tmp_out + (size_t)z * n * W + col;
+        const double* trd = tw + rrow * CW + 2 * dq;
+        auto lds_order = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                double e[NI][4];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const unsigned ln = m0 + wm + 16 * i + li;
+                    const unsigned lz = ln < L ? ln / W : 0, lc = ln < L ? ln - lz * W : 0;
+                    const double* tp2 = po.tmp + (size_t)lz * (n / 2) * W + lc;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
+                        const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * (pair < NP ? pair : 0);
+                        e[i][r] = tp2[(size_t)(nn < n / 2 ? nn : 0) * W];
+                    }
+                }
+#pragma unroll
+                for (int sign = 0; sign < 2; ++sign) {
+                    lds_order();
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double a = h2 ? acc2[i][jn][r] : acc1[i][jn][r];
+                            tw[wr0 + (4 * r) * CW + 16 * i] = sign ? e[i][r] - a : e[i][r] + a;
+                        }
+                    lds_order();
+#pragma unroll
+                    for (int t = 0; t < NRI; ++t) {
+                        const unsigned pair = p0 + wn + 16 * jn + t * RPI + rrow;
+                        const f64x2 v = *reinterpret_cast<const f64x2*>(trd + t * RPI * CW);
+                        if (!line_ok || pair >= NP) continue;
+                        const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * pair;
+                        if (nn >= n / 2) continue;
+                        const unsigned idx = sign ? n - 1 - nn : nn;
+                        *reinterpret_cast<f64x2*>(tbase + (size_t)idx * W) = v;
+                    }
                 }
             }
         trace_end();
@@ -667,7 +782,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 for (int r = 0; r < 4; ++r) {
                     const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
                     if (pair >= NP) continue;
-                    emit(lp, tp, W, pair, acc1[i][jn][r], acc2[i][jn][r]);
+                    emit(lp, tp, po.tmp_out + (size_t)z * n * W + col, W, pair, acc1[i][jn][r], acc2[i][jn][r]);
                 }
         }
     }
@@ -695,18 +810,20 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 // applies to the even part (its frequencies are multiples of 2^sub of the full transform's).
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
-                             size_t h, Epilogue ep, const RgbSink* sink) {
+                             size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t lines = is_row ? n_frames * h : n_frames * w;
     const size_t len = is_row ? w : h;
     if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned L = (unsigned)lines;
-    if (sub < 0 || sub > 8 || (sub > 0 && (inverse || kind == 0))) return SSW_ERR_BAD_ARG;
+    // inverse: sub = 1 serves the deep inverse (the half-length transform E): kind 1 -> its even half T2, kinds 3 / 4 -> E
+    if (sub < 0 || sub > 8 || (sub > 0 && kind == 0) || (sub > 0 && inverse && (sub != 1 || kind == 2))) return SSW_ERR_BAD_ARG;
+    if (inverse && sub == 1 && (kind == 3 || kind == 4) && !tmp_out) return SSW_ERR_BAD_ARG;
     const size_t leff = len >> sub;                           // length of the (sub-)transform this launch serves
     const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
     const bool split = kind == 3 || kind == 4;
-    if (split && (leff % 8 != 0 || (inverse && sub != 0))) return SSW_ERR_BAD_ARG;
+    if (split && leff % 8 != 0) return SSW_ERR_BAD_ARG;
     const unsigned NP = (unsigned)(kind == 0 ? leff / 2 : kind == 3 ? leff / 8 + 1 : kind == 4 ? leff / 8 : leff / 4);
     const unsigned Kp = (unsigned)(split ? pair_kpad<double>(leff / 4) : kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
     const unsigned BN = 64;
@@ -728,10 +845,11 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     }
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-    PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)len, 0, 1, 2};
+    PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)(inverse ? leff : len), 0, 1, 2};
+    po.tmp_out = tmp_out;
     if (kind == 1) { po.c1 = 0; po.c2 = 2 * fs; po.cs = 4 * fs; }
     if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
-    if (inverse && kind == 2) { po.c1 = 0; po.c2 = (unsigned)(len / 4); po.cs = 1; }      // positions pair, pair + n/4 of the odd part
+    if (inverse && kind == 2) { po.c1 = 0; po.c2 = (unsigned)(leff / 4); po.cs = 1; }      // positions pair, pair + n/4 of the odd part
     if (split) {
         // odd frequency u = 2k+1 of the (sub-)transform; class E (kind 3) pair i: k = 4i (+), 4i-1 (-); class O: k = 4i+2 (+), 4i+1 (-)
         po.pm = 1;
@@ -745,7 +863,7 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     po.bn32 = bn32 ? 1u : 0u;
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
-    po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16))) ? 1u : 0u;
+    po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16)) && (!tmp_out || al(tmp_out, 16))) ? 1u : 0u;
     if (sink && sink->rgb && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;
     if ((unsigned long long)Kp * L * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
 #define SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, SUBV, BMV) \
@@ -770,6 +888,7 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
             po.iq_i = sink->iq_i; po.iq_q = sink->iq_q; po.rgb = sink->rgb; po.rgb_u8 = sink->u8 ? 1u : 0u;
             if (split) SSW_LAUNCH_PAIR(true, EPI_INV_O_RGB, false); else SSW_LAUNCH_PAIR(true, EPI_INV_O_RGB, true);
         }
+        else if (split && sub == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_OT, false); else SSW_LAUNCH_PAIR(true, EPI_INV_OT, false); }
         else if (split) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, false); else SSW_LAUNCH_PAIR(true, EPI_INV_O, false); }
         else { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, true); else SSW_LAUNCH_PAIR(true, EPI_INV_O, true); }
     }

@@ -909,6 +909,159 @@ __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// Deep INVERSE pre-passes.  The inverse transform of coefficients c[0 .. n) combines, per axis,
+//   x[m]  = T[m] +/- o[m]      T = half-length inverse of the even coefficients, o = DCT-IV of the odd ones (n/2 each)
+//   T[m]  = T2[m] +/- o2[m]    T2 = quarter-length inverse of c[4q], o2 = DCT-IV of c[4q+2]                (n/4 each)
+//   T2[m] = EEE-part +/- EEO-part: c[8q] and c[8q+4] against the half bases of length n/4                   (n/8 each)
+// and both DCT-IVs are split like the forward ones: the operands are
+//   AS BD AD BS  (n/8 each)   from k -> c[2k+1]  (rotation partners k, n/2-1-k; fold partners n/4-1-k, n/4+k)
+//   AS2 .. BS2   (n/16 each)  from q -> c[4q+2]
+//   R1 = c[8q], R2 = c[8q+4]  (n/8 each)
+// in the DeepPlanes order of the forward pre-passes.
+// Row pass (n % 128 == 0): one thread = the eight 16-element regions of a line that close under those pairings,
+//   g = R, n/4-16-R, n/4+R, n/2-16-R, n/2+R, 3n/4-16-R, 3n/4+R, n-16-R   (R = 16 t): 128 coefficients in, 128 doubles out.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pair_prep16_inv_rows_kernel(const float* __restrict__ X, DeepPlanes dp,
+                                                                  const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                                  unsigned rows, unsigned W, unsigned K8, unsigned K16, unsigned tp_line /*threads per line, power of 2*/) {
+    const unsigned t = threadIdx.x & (tp_line - 1);
+    const unsigned row = blockIdx.x * (256 / tp_line) + threadIdx.x / tp_line;
+    const unsigned R = 16 * t;
+    const unsigned Nh = W / 2, Nq = W / 4, N8 = W / 8, N16 = W / 16;
+    if (row >= rows || R >= N8) return;
+    T* P8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs), static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
+    T* P16[4] = {static_cast<T*>(dp.as2), static_cast<T*>(dp.bd2), static_cast<T*>(dp.ad2), static_cast<T*>(dp.bs2)};
+    auto put4 = [&](T* plane, unsigned k, const vec4_t<T>& v) { *reinterpret_cast<vec4_t<T>*>(plane + blk_index<T>(row, k, rows)) = v; };
+    auto put2 = [&](T* plane, unsigned k, T a, T b) { *reinterpret_cast<vec2_t<T>*>(plane + blk_index<T>(row, k, rows)) = (vec2_t<T>){a, b}; };
+    const unsigned g[8] = {R, Nq - 16 - R, Nq + R, Nh - 16 - R, Nh + R, 3 * Nq - 16 - R, 3 * Nq + R, W - 16 - R};
+    const float* xr = X + (size_t)row * W;
+    f32x4 c[8][4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c[j][q] = *reinterpret_cast<const f32x4*>(xr + g[j] + 4 * q);
+    // odd coefficients of region j as two ascending quads of k: element u = 2 t + 1 -> quad t / 4
+    auto odd = [&](int j, int half) { return (vec4_t<T>){(T)c[j][2 * half][1], (T)c[j][2 * half][3], (T)c[j][2 * half + 1][1], (T)c[j][2 * half + 1][3]}; };
+    // unit A: k = e0 .. e0+7 (e0 = R/2) from regions 0, 3, 4, 7; its mirror unit n/8-8-e0 .. from regions 1, 2, 5, 6
+    const unsigned e0 = R / 2, m0u = N8 - 8 - e0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        vec4_t<T> as, bd, ad, bs;
+        split_unit<T>(odd(0, half), odd(3, 1 - half), odd(4, half), odd(7, 1 - half), rot1, e0 + 4 * half, Nq, as, bd, ad, bs);
+        put4(P8[0], e0 + 4 * half, as); put4(P8[1], e0 + 4 * half, bd); put4(P8[2], e0 + 4 * half, ad); put4(P8[3], e0 + 4 * half, bs);
+        split_unit<T>(odd(1, half), odd(2, 1 - half), odd(5, half), odd(6, 1 - half), rot1, m0u + 4 * half, Nq, as, bd, ad, bs);
+        put4(P8[0], m0u + 4 * half, as); put4(P8[1], m0u + 4 * half, bd); put4(P8[2], m0u + 4 * half, ad); put4(P8[3], m0u + 4 * half, bs);
+    }
+    // c[4q+2]: element 2 of every quad of a region, q ascending
+    auto mid = [&](int j) { return (vec4_t<T>){(T)c[j][0][2], (T)c[j][1][2], (T)c[j][2][2], (T)c[j][3][2]}; };
+    {
+        const unsigned f0 = R / 4, f1 = N16 - 4 - f0;
+        vec4_t<T> as, bd, ad, bs;
+        split_unit<T>(mid(0), mid(3), mid(4), mid(7), rot2, f0, N8, as, bd, ad, bs);
+        put4(P16[0], f0, as); put4(P16[1], f0, bd); put4(P16[2], f0, ad); put4(P16[3], f0, bs);
+        split_unit<T>(mid(1), mid(2), mid(5), mid(6), rot2, f1, N8, as, bd, ad, bs);
+        put4(P16[0], f1, as); put4(P16[1], f1, bd); put4(P16[2], f1, ad); put4(P16[3], f1, bs);
+    }
+    // c[8q] and c[8q+4]: elements 0 of quads 0, 2 and of quads 1, 3
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        put2(P8[4], g[j] / 8, (T)c[j][0][0], (T)c[j][2][0]);
+        put2(P8[5], g[j] / 8, (T)c[j][1][0], (T)c[j][3][0]);
+    }
+    if (t == 0) {
+        const vec4_t<T> zero = {0, 0, 0, 0};
+        for (unsigned z = N8; z < K8; z += 4)
+#pragma unroll
+            for (int a = 0; a < 6; ++a) put4(P8[a], z, zero);
+        for (unsigned z = N16; z < K16; z += 4)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) put4(P16[a], z, zero);
+    }
+}
+
+// Column pass (H % 16 == 0): lines = (frame, column).  One block = 32 columns x one group G of 8 units: thread (column,
+// t) serves the D-split pair (e = 8G + t, H/8 - 1 - e), the level-2 unit e' = 8G + t and the level-3 pairs q = 16G + 2t,
+// +1 -- 16 coefficients in (coalesced across the columns), 16 doubles out, transposed through LDS so that every store
+// is a whole 64-byte piece of one line where the positions allow it.
+template <typename T>
+__global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
+                                                                  const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                                  unsigned W, unsigned H, unsigned K8, unsigned K16,
+                                                                  unsigned n_frames, unsigned groups, unsigned tiles_c) {
+    __shared__ T s[16][32][9];
+    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = H / 16;
+    const unsigned z = blockIdx.x / (groups * tiles_c);
+    const unsigned tt = blockIdx.x % (groups * tiles_c);
+    const unsigned G = tt % groups, c0 = (tt / groups) * 32;
+    const float* __restrict__ Pz = IN + (size_t)z * H * W;
+    const unsigned cl = threadIdx.x & 31, t = threadIdx.x >> 5;
+    const unsigned col = c0 + cl < W ? c0 + cl : W - 1;
+    auto ld = [&](unsigned r) { return (T)Pz[(size_t)r * W + col]; };
+    T* P8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs), static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
+    T* P16[4] = {static_cast<T*>(dp.as2), static_cast<T*>(dp.bd2), static_cast<T*>(dp.ad2), static_cast<T*>(dp.bs2)};
+    const unsigned e = 8 * G + t;                                  // D-split pair index (< H/16) and level-2 unit (< H/16)
+    const bool ok = e < H16;
+    const unsigned ec = ok ? e : 0, em = H8 - 1 - ec;
+    T o[16];
+    {   // odd coefficients: k -> row 2k+1; unit at e: k = e, H/4-1-e, H/4+e, H/2-1-e; mirror unit at em
+        const T d0 = ld(2 * ec + 1), d1 = ld(Hh - 1 - 2 * ec), d2 = ld(Hh + 2 * ec + 1), d3 = ld(H - 1 - 2 * ec);
+        split_one<T>(d0, d1, d2, d3, rot1, ec, Hq, o[0], o[1], o[2], o[3]);
+        const T m0v = ld(2 * em + 1), m1 = ld(Hh - 1 - 2 * em), m2 = ld(Hh + 2 * em + 1), m3 = ld(H - 1 - 2 * em);
+        split_one<T>(m0v, m1, m2, m3, rot1, em, Hq, o[4], o[5], o[6], o[7]);
+        // c[4q+2]: q = e, H/8-1-e, H/8+e, H/4-1-e
+        const T q0 = ld(4 * ec + 2), q1 = ld(Hh - 2 - 4 * ec), q2 = ld(Hh + 4 * ec + 2), q3 = ld(H - 2 - 4 * ec);
+        split_one<T>(q0, q1, q2, q3, rot2, ec, H8, o[8], o[9], o[10], o[11]);
+        // c[8q], c[8q+4] for q = 2e, 2e+1 (< H/8)
+        o[12] = ld(16 * ec); o[13] = ld(16 * ec + 8); o[14] = ld(16 * ec + 4); o[15] = ld(16 * ec + 12);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) s[v][cl][t] = ok ? o[v] : (T)0;
+    __syncthreads();
+    if (c0 + cl >= W) return;
+    const size_t line = (size_t)z * W + c0 + cl, lines = (size_t)n_frames * W;
+    const unsigned nv = 8 * G >= H16 ? 0u : (H16 - 8 * G < 8 ? H16 - 8 * G : 8u);          // valid units of the group
+    const unsigned h = t;                                          // store side: thread h of a column takes value type h
+    {   // AS BD AD BS at e = 8G .. (h < 4) or at the mirror units H/8 - 1 - e, ascending from H/8 - 8G - nv (h >= 4)
+        T* plane = P8[h & 3];
+        if (h < 4) {
+            if (nv == 8) {
+                T* o8 = plane + blk_index<T>(line, 8 * G, lines);
+                *reinterpret_cast<vec4_t<T>*>(o8) = (vec4_t<T>){s[h][cl][0], s[h][cl][1], s[h][cl][2], s[h][cl][3]};
+                *reinterpret_cast<vec4_t<T>*>(o8 + 4) = (vec4_t<T>){s[h][cl][4], s[h][cl][5], s[h][cl][6], s[h][cl][7]};
+            } else {
+                for (unsigned j = 0; j < nv; ++j) plane[blk_index<T>(line, 8 * G + j, lines)] = s[h][cl][j];
+            }
+        } else {
+            const unsigned k0 = H8 - 8 * G - nv;
+            if (nv == 8 && (k0 & 7u) == 0) {
+                T* o8 = plane + blk_index<T>(line, k0, lines);
+                *reinterpret_cast<vec4_t<T>*>(o8) = (vec4_t<T>){s[h][cl][7], s[h][cl][6], s[h][cl][5], s[h][cl][4]};
+                *reinterpret_cast<vec4_t<T>*>(o8 + 4) = (vec4_t<T>){s[h][cl][3], s[h][cl][2], s[h][cl][1], s[h][cl][0]};
+            } else {
+                for (unsigned j = 0; j < nv; ++j) plane[blk_index<T>(line, k0 + j, lines)] = s[h][cl][nv - 1 - j];
+            }
+        }
+    }
+    {   // AS2 .. BS2 at e' = 8G + 4 (h / 4) .. +3: zeros beyond H/16 (the planes are K16 wide)
+        T* plane = P16[h & 3];
+        const unsigned k0 = 8 * G + 4 * (h >> 2), j0 = 4 * (h >> 2);
+        if (k0 < K16) *reinterpret_cast<vec4_t<T>*>(plane + blk_index<T>(line, k0, lines)) = (vec4_t<T>){s[8 + (h & 3)][cl][j0], s[8 + (h & 3)][cl][j0 + 1], s[8 + (h & 3)][cl][j0 + 2], s[8 + (h & 3)][cl][j0 + 3]};
+    }
+    {   // R1 = c[8q], R2 = c[8q+4] at q = 16G + 2h, +1 (units beyond H/16 wrote zeros: padding up to K8 where 16G < K8)
+        const unsigned q0 = 16 * G + 2 * h;
+        if (q0 < K8) {
+            *reinterpret_cast<vec2_t<T>*>(P8[4] + blk_index<T>(line, q0, lines)) = (vec2_t<T>){s[12][cl][h], s[13][cl][h]};
+            *reinterpret_cast<vec2_t<T>*>(P8[5] + blk_index<T>(line, q0, lines)) = (vec2_t<T>){s[14][cl][h], s[15][cl][h]};
+        }
+    }
+    if (G == 0 && h == 0)                                           // AS .. BS beyond H/8
+        for (unsigned k = H8; k < K8; ++k)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) P8[a][blk_index<T>(line, k, lines)] = (T)0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Launchers
 // ---------------------------------------------------------------------------------------------
 size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h) {
@@ -1115,6 +1268,47 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
     p += 6 * p8;
     dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
     pair_prep16_cols_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+// deep inverse pre-passes: same plane order (AS BD AD BS R1 R2 | AS2 BD2 AD2 BS2) with R1 = c[8q], R2 = c[8q+4]
+bool dct_pair_can_deep_inv_rows(size_t len) { return len % 128 == 0 && len >= 256 && len <= 128 * 256; }
+static DeepPlanes deep_planes(double* base, size_t lines, size_t len) {
+    const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
+    DeepPlanes dp;
+    double* p = base;
+    dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
+    p += 6 * p8;
+    dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
+    return dp;
+}
+int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                                    const double* rot1, const double* rot2) {
+    if (n_frames == 0) return SSW_OK;
+    if (!dct_pair_can_deep_inv_rows(w) || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const size_t rows = n_frames * h;
+    if (rows > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    unsigned tp = 1;
+    while (tp < w / 128) tp <<= 1;                                  // threads per line, <= 256
+    const unsigned lpb = 256 / tp;
+    const unsigned long long nblk = (rows + lpb - 1) / lpb;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    pair_prep16_inv_rows_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, deep_planes(base, rows, w), rot1, rot2, (unsigned)rows, (unsigned)w,
+                                                                       (unsigned)dct_pair_split_kpad(w), (unsigned)dct_pair_split_kpad(w / 2), tp);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                                    const double* rot1, const double* rot2) {
+    if (n_frames == 0) return SSW_OK;
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !dct_pair_can_deep_cols(h)) return SSW_ERR_BAD_DIMS;
+    const unsigned K8 = (unsigned)dct_pair_split_kpad(h), K16 = (unsigned)dct_pair_split_kpad(h / 2);
+    const unsigned groups = K16 / 8, tiles_c = (unsigned)((w + 31) / 32);      // K16 % 16 == 0: the groups cover the padding too
+    const unsigned long long nblk = (unsigned long long)groups * tiles_c * n_frames;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    pair_prep16_inv_cols_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, deep_planes(base, n_frames * w, h), rot1, rot2, (unsigned)w, (unsigned)h,
+                                                                       K8, K16, (unsigned)n_frames, groups, tiles_c);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

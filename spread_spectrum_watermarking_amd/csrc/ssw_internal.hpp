@@ -117,7 +117,7 @@ int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t
 // sink (inverse column pass, kind 2 only): colour conversion in the epilogue instead of storing Y
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
-                             size_t h, Epilogue ep, const RgbSink* sink = nullptr);
+                             size_t h, Epilogue ep, const RgbSink* sink = nullptr, double* tmp_out = nullptr);
 int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const float* x1, const float* x2,
                              const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep, const RgbSink* sink = nullptr);
@@ -139,6 +139,12 @@ int launch_dct_pair_rotate(hipStream_t st, const double* p, const double* rot, d
 // (f32 plane or interleaved RGB); base: AS BD AD BS R1 R2 (lines * split_kpad(len) each), AS2 BD2 AD2 BS2 (lines * split_kpad(len/2))
 bool dct_pair_can_deep_rows(size_t len);
 bool dct_pair_can_deep_cols(size_t len);                 // H % 16 == 0
+bool dct_pair_can_deep_inv_rows(size_t len);             // W % 128 == 0
+// deep inverse pre-passes (coefficient plane -> the same ten planes; R1 = c[8q], R2 = c[8q+4])
+int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                                    const double* rot1, const double* rot2);
+int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                                    const double* rot1, const double* rot2);
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2);
 size_t dct_pair_deep_elems(size_t lines, size_t len);

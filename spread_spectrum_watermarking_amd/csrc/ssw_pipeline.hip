@@ -183,9 +183,9 @@ namespace {
 
 int pair_gemm(hipStream_t st, bool f64, bool is_row, bool inverse, int kind, int sub, const void* x1, const void* x2,
               const void* y1, const void* y2, float* dst, void* tmpE, size_t n, size_t w, size_t h, Epilogue ep,
-              const RgbSink* sink = nullptr) {
+              const RgbSink* sink = nullptr, void* tmp_out = nullptr) {
     return f64 ? launch_dct_pair_gemm_f64(st, is_row, inverse, kind, sub, (const double*)x1, (const double*)x2, (const double*)y1,
-                                          (const double*)y2, dst, (double*)tmpE, n, w, h, ep, sink)
+                                          (const double*)y2, dst, (double*)tmpE, n, w, h, ep, sink, (double*)tmp_out)
                : launch_dct_pair_gemm_f32(st, is_row, inverse, kind, sub, (const float*)x1, (const float*)x2, (const float*)y1,
                                           (const float*)y2, dst, (float*)tmpE, n, w, h, ep, sink);
 }
@@ -202,7 +202,7 @@ double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t
 // doubles of the lane's sixth operand buffer: the split planes of either pass, or the deep row pre-pass's ten planes
 size_t split_scratch_elems(size_t n, size_t w, size_t h) {
     size_t e = dct_pair_split_elems(n, w, h);
-    if (dct_pair_can_deep_rows(w)) e = std::max(e, dct_pair_deep_elems(n * h, w));
+    if (dct_pair_can_deep_rows(w) || dct_pair_can_deep_inv_rows(w)) e = std::max(e, dct_pair_deep_elems(n * h, w));
     if (dct_pair_can_deep_cols(h)) e = std::max(e, dct_pair_deep_elems(n * w, h));
     return e;
 }
@@ -295,6 +295,47 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
         };
         const double f_odd = split ? pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h)
                                    : pair_gemm_flop(is_row, 2, 0, n, w, h);
+        // the inverse the same way: c[8q] / c[8q+4] -> T2, the split c[4q+2] part + T2 -> T (the even half E), then the
+        // split odd part + T -> the output; one pre-pass for all five launches
+        const bool deep_inv = split && inverse && (is_row ? dct_pair_can_deep_inv_rows(len) : dct_pair_can_deep_cols(len) && w % 4 == 0);
+        if (deep_inv) {
+            const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr;
+            SSW_TRY(get_basis(ctx, len / 4, true, true, 3, &e0));
+            SSW_TRY(get_basis(ctx, len / 4, true, true, 4, &e1));
+            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, true, true, 5 + b, &sb2[b]));
+            SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
+            SSW_TRY(grow(ws.operand[1], bytes));
+            SSW_TRY(grow(ws.operand[4], bytes));
+            void* T2 = ws.operand[1].p;       // quarter-length even half, unrounded
+            void* TE = ws.operand[4].p;       // the even half E, unrounded
+            const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
+            double* q = sp + 6 * p8;
+            const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
+            const void *t0 = sb2[0], *t1 = sb2[1], *t2 = sb2[2], *t3 = sb2[3];
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_prep, st, prep_bytes);
+                if (!is_row) return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2);
+                return launch_dct_pair_prep16_inv_rows(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2);
+            }});
+            RgbSink sink;
+            if (!first_pass && !is_row && x.rgb_out && x.iq_i && x.iq_q) {
+                sink.iq_i = x.iq_i; sink.iq_q = x.iq_q; sink.rgb = x.rgb_out; sink.u8 = x.rgb_out_u8;
+                if (fused_rgb) *fused_rgb = true;
+            }
+            const bool with_sink = sink.rgb != nullptr;
+            const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h);
+            const double f_all = f_main + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
+            ch.push_back({false, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_pass, st, f_all);
+                SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
+                SSW_TRY(pair_gemm(st, true, is_row, true, 3, 1, q, q + p16, t0, t1, dst, T2, n, w, h, ep, nullptr, TE));
+                SSW_TRY(pair_gemm(st, true, is_row, true, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, T2, n, w, h, ep, nullptr, TE));
+                StageTimer tm(ctx, st_main, st, f_main);
+                SSW_TRY(pair_gemm(st, true, is_row, true, 3, 0, sp, sp + p8, sb0, sb1, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr));
+                return pair_gemm(st, true, is_row, true, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr);
+            }});
+            return SSW_OK;
+        }
         if (three) {
             // forward pass, three levels: x- (odd frequencies), S- (2 mod 4), (SSS, SS-) (0 and 4 mod 8); on a column
             // pass (8K: 4320 rows) the pre-pass transposes like the two-level one
