@@ -140,6 +140,28 @@ def hbm_report(stage, names):
     return out
 
 
+# The launch bench.py's `roofline` block is about: the largest single GEMM launch of a forward transform.
+#   f64 (default): class E of the split odd half of a row pass -- (AS x cosine rows 2i) + (BD x sine rows 2i), W/8 + 1
+#       output pairs, sums of W/8 terms (csrc/dct_pair_prep.hip "Split odd half"); its own template instance (SUB = 4)
+#   f32: the unsplit odd half (the f32 twin keeps exact-operand folding)
+def main_kernel_label(prec_name):
+    return "pair_gemm_f64_kernel<rows, split odd half, class E>" if prec_name == "f64" else "pair_gemm_f32_kernel<rows, odd half>"
+
+
+def main_kernel_instance(prec_name):
+    return "ssw::pair_gemm_f64_kernel<false, 0, false, 4>" if prec_name == "f64" else "ssw::pair_gemm_f32_kernel<false, 0, true, 0>"
+
+
+MAIN_KERNEL_NOTE = {
+    "f64": ("executed flop of one launch (two products of lines x (W/8 + 1) output pairs x W/8 sums: the cosine and the sine "
+            "part of class E of the split odd half, counted by the library per launch) / its average duration from a "
+            "hipEvent pair on the stream it runs on, inside the timed region"),
+    "f32": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency half of the even/odd-"
+            "folded basis GEMM, counted by the library per launch) / its average duration from a hipEvent pair on the "
+            "stream it runs on, inside the timed region"),
+}
+
+
 def attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff):
     """HBM-side traffic of the dominant kernel: PMC counters collected offline exactly as MI355X_MICROARCH.md
     prescribes (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) and committed under profiles/ with the
@@ -154,9 +176,7 @@ def attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff):
                 roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
                 roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
                 roofline["traffic_source"] = f"profiles/{os.path.basename(path)} (collected at commit {pmc.get('commit', '?')})"
-                esz = 8 if prec_name == "f64" else 4     # operand plane in, odd half basis in, f32 odd outputs
-                lines = chunk_eff * H
-                roofline["algorithmic_bytes_per_launch"] = int(lines * (W // 2) * esz + (W // 2) ** 2 * esz + lines * (W // 2) * 4)
+                roofline["algorithmic_bytes_per_launch"] = pmc["kernels"][roofline["kernel"]].get("algorithmic_bytes_per_launch")
                 return
         except (OSError, KeyError, ValueError):
             pass
@@ -197,7 +217,8 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
         peak = PEAK_F64_MFMA_TFLOPS if args.precision == "f64" else PEAK_F32_MFMA_TFLOPS
         main_tf = rate(stage["dct_row_main"]["work"], main_ms) / 1e12
         chunk_eff = ctx.pass_frames(B, W, H)
-        roofline = {"bound": "mfma", "kernel": "pair_gemm_%s_kernel<rows, odd half>" % args.precision,
+        roofline = {"bound": "mfma", "kernel": main_kernel_label(args.precision),
+                    "instance": main_kernel_instance(args.precision),
                     "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(main_tf / peak, 4),
                     "traffic": None, "avg_ms": round(main_ms / main_n, 4), "launches": main_n,
                     "flop_per_launch": stage["dct_row_main"]["work"] / main_n}
@@ -625,14 +646,12 @@ def main():
                               "effective_dense_tflops": round(rate(dense_flop_per_step * steps, gemm_ms) / 1e12, 2)}
         kernels.update(hbm_report(stage, ["rgb_to_yiq", "dct_prep", "select", "yiq_to_rgb"]))
         main = kernels["dct_rows"]["main_launch"]
-        roofline = {"bound": "mfma", "kernel": "pair_gemm_%s_kernel<rows, odd half>" % prec_name,
-                    "instance": "ssw::pair_gemm_%s_kernel<false, 0, true, 0>" % prec_name,
+        roofline = {"bound": "mfma", "kernel": main_kernel_label(prec_name),
+                    "instance": main_kernel_instance(prec_name),
                     "achieved": main["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(main["tflops"] / peak, 4),
                     "traffic": None, "avg_ms": main["avg_ms"], "launches": main["launches"],
                     "flop_per_launch": main["flop_per_launch"],
-                    "note": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency "
-                             "half of the even/odd-folded basis GEMM, counted by the library per launch) / its average "
-                             "duration from a hipEvent pair on the stream it runs on, inside the timed region")}
+                    "note": MAIN_KERNEL_NOTE[prec_name]}
         attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff)
         return kernels, roofline, {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
 

@@ -142,7 +142,7 @@ size_t ssw_ctx_pass_frames(ssw_ctx* ctx, size_t n_frames, size_t w, size_t h);
 /* Batch pipelines (ssw_batch_*): two chunks in flight, each with its own workspace -- the HBM-bound stages
    of one (operand pre-passes, selection, colour conversion) run on a second internal stream while the
    basis GEMMs of the other run on the context's stream; the context's stream is ordered after all of it
-   when the call returns.  Default on, used from three passes per call upwards (2 x 36 B/px of workspace
+   when the call returns.  Default on, used from two passes per call upwards (2 x 36 B/px of workspace
    then); 0 = one chunk at a time on one stream
    (what the per-kernel timings of bench.py's roofline leg use).  Results are bit-identical either way. */
 int ssw_ctx_set_overlap(ssw_ctx* ctx, int enable);
@@ -177,6 +177,18 @@ int ssw_ctx_get_prune_stats(ssw_ctx* ctx, uint64_t* stats);
    level adds one rounding per operand sum (tests/test_gpu_parity.py holds both to their bars). */
 #define SSW_DCT_FOLDING_DEFAULT 5
 int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int level);
+/* f64 precision, folding level 4 and up: the odd half of a folded transform (a DCT-IV of half the length, the one part
+   that does not fold) is computed as a cosine and a sine transform of a quarter of the length each, after one plane
+   rotation of its input pairs -- X[2j] = A[j] + B[j], X[2j-1] = A[j] - B[j] with a[n] = d[n] cos psi_n + d[M-1-n] sin psi_n,
+   b[n] = d[M-1-n] cos psi_n - d[n] sin psi_n, psi_n = pi (2n+1) / (4M) -- and both of those fold once more: a quarter of
+   the odd half's multiply-adds.  On axes whose length allows it (rows % 64 == 0 / columns % 16 == 0 forward, rows % 128 ==
+   0 / columns % 16 == 0 inverse) one pre-pass applies this to the odd halves of two levels ("deep"), otherwise
+   (length % 8 == 0) to the first.  The rotation is the one inexact step ahead of the f64 MFMA sums (relative error
+   2^-52 of the operand); everything else stays an exact fold.  Results: the same f64-accurate transform rounded
+   once to f32 -- equal to the unsplit GEMMs' output except where that rounding was within ~1e-9 ulp of a tie
+   (tests/test_gpu_parity.py::test_odd_split_matches_exact_operands).  Default on; 0 = every operand an exact sum
+   (the round-2 arithmetic, 1.8x the multiply-adds). */
+int ssw_ctx_set_odd_split(ssw_ctx* ctx, int enable);
 
 /* Per-stage device timers (hipEvent pairs on the context's stream).  DCT_ROW / DCT_COL cover the
    GEMM launches of a pass; at folding levels 3 / 4 the pre-passes are timed separately (DCT_PREP). */

@@ -63,6 +63,7 @@ public:
     size_t pass_frames(size_t n_frames, size_t w, size_t h) const { return ssw_ctx_pass_frames(ctx_, n_frames, w, h); }
     void set_overlap(bool on) { check(ssw_ctx_set_overlap(ctx_, on ? 1 : 0), "ssw_ctx_set_overlap"); }
     void set_prune(bool on) { check(ssw_ctx_set_prune(ctx_, on ? 1 : 0), "ssw_ctx_set_prune"); }
+    void set_odd_split(bool on) { check(ssw_ctx_set_odd_split(ctx_, on ? 1 : 0), "ssw_ctx_set_odd_split"); }
     // Host-buffer entry points: copy threads of the pinned staging ring (0 = automatic) and the transfer counters.
     void set_copy_threads(int n) { check(ssw_ctx_set_copy_threads(ctx_, n), "ssw_ctx_set_copy_threads"); }
     std::vector<double> transfer_stats(bool reset = false) {

@@ -102,6 +102,10 @@ class Context:
         """Batch extract: derived frames transformed only where extract reads them (default) or fully."""
         check(self._lib.ssw_ctx_set_prune(self.handle, int(on)), "ssw_ctx_set_prune")
 
+    def set_odd_split(self, on: bool = True):
+        """f64 transforms: odd halves as rotated quarter-length cosine + sine pairs (default) or as exact folded sums."""
+        check(self._lib.ssw_ctx_set_odd_split(self.handle, int(on)), "ssw_ctx_set_odd_split")
+
     def prune_stats(self) -> dict:
         st = (C.c_uint64 * 3)()
         check(self._lib.ssw_ctx_get_prune_stats(self.handle, st), "ssw_ctx_get_prune_stats")

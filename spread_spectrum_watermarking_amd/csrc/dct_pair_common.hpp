@@ -57,11 +57,38 @@ struct PairOutT {
     unsigned bn32 = 0;
     // split odd half (dct_pair_f64.hip, "rotated quarter-length pair"): the two products are a cosine and a sine
     // transform of the rotated operands and the outputs are their sum and difference: 1 = (acc1 + acc2 -> first
-    // output, acc1 - acc2 -> second), 2 = the sum only (gathered rows of the pruned transform).  Outputs whose
-    // index along the transformed axis is not below `lim` do not exist (the first / last pair of a class).
+    // output, acc1 - acc2 -> second), 2 = the sum only (gathered rows of the pruned transform).  The first output of
+    // pairs >= np1 and the second output of pairs < p2lo do not exist (the last / first pair of class E).
     unsigned pm = 0;
-    unsigned lim = 0xFFFFFFFFu;
+    unsigned np1 = 0xFFFFFFFFu, p2lo = 0;
     T* tmp_out = nullptr;     // EPI_INV_OT
+};
+
+// Column order of the intermediate plane between the two passes of a deep forward transform (row pass first): the
+// frequencies of one GEMM launch class side by side, so that a launch stores runs instead of one float in 8 or 16.
+// (The natural order made every row launch rewrite the whole plane: 5 x 4.2 GB of HBM writes per 128 4K frames instead
+// of 4.2 GB -- PMC WRITE_SIZE -- and the clock the chip holds under that load was 10-20 % lower.)
+//   class      R1     R2     E2P      E2M      O2P      O2M      EP     EM     OP     OM
+//   u mod      8: 0   8: 4   16: 2    16: 14   16: 10   16: 6    8: 1   8: 7   8: 5   8: 3
+//   length     n/8    n/8    n/16     n/16     n/16     n/16     n/8    n/8    n/8    n/8
+struct ForwardClassLayout {
+    unsigned n;
+    enum { R1 = 0, R2, E2P, E2M, O2P, O2M, EP, EM, OP, OM };
+    __host__ __device__ unsigned base(int c) const {
+        const unsigned e = n / 8, s = n / 16;
+        return c < 2 ? c * e : c < 6 ? 2 * e + (c - 2) * s : n / 2 + (c - 6) * e;
+    }
+    // natural frequency of memory column p
+    __host__ __device__ unsigned natural(unsigned p) const {
+        const unsigned e = n / 8, s = n / 16;
+        if (p < 2 * e) return p < e ? 8 * p : 8 * (p - e) + 4;
+        if (p < n / 2) {
+            const unsigned q = p - 2 * e, c = q / s, i = q - c * s;
+            return 16 * i + (c == 0 ? 2u : c == 1 ? 14u : c == 2 ? 10u : 6u);
+        }
+        const unsigned q = p - n / 2, c = q / e, i = q - c * e;
+        return 8 * i + (c == 0 ? 1u : c == 1 ? 7u : c == 2 ? 5u : 3u);
+    }
 };
 
 // yiq.rs:139-147 (f32::clamp) and :163-165, :173-175: the arithmetic of color.hip / attack.hip, per pixel

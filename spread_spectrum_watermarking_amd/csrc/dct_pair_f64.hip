@@ -83,6 +83,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 
 #ifdef SSW_TILE_TRACE
     unsigned long long tt[5] = {0, 0, 0, 0, 0};
+    const unsigned long long cyc0 = clock64();
 #endif
     SSW_TT(0);
     unsigned tm, tn;
@@ -290,8 +291,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             unsigned long long* o = g_tile_trace + 8ull * slot;
             o[0] = tt[0]; o[1] = tt[1]; o[2] = tt[2]; o[3] = tt[3];
             o[4] = ((unsigned long long)xcc << 32) | hwid;
-            o[5] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(COLS * 1000 + EPI * 100 + SAMEX * 10 + SUB);
+            o[5] = (unsigned long long)(unsigned)(COLS * 1000 + EPI * 100 + SAMEX * 10 + SUB);
             o[6] = ((unsigned long long)Kp << 32) | NP;
+            o[5] |= ((clock64() - cyc0) & 0xFFFFFFFull) << 36;     // shader cycles of the block (28 bits) above the tag
             o[7] = tt[4];
         }
     }
@@ -324,8 +326,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 const f32x2 v = {apply_epilogue(ep, (float)a1, i1), apply_epilogue(ep, (float)a2, i2)};
                 *reinterpret_cast<f32x2*>(lp + i1) = v;
             } else {
-                if (i1 < po.lim) lp[i1 * es] = apply_epilogue(ep, (float)a1, i1);
-                if (i2 < po.lim && second_out) lp[i2 * es] = apply_epilogue(ep, (float)a2, i2);
+                if (pair < po.np1) lp[i1 * es] = apply_epilogue(ep, (float)a1, i1);
+                if (pair >= po.p2lo && second_out) lp[i2 * es] = apply_epilogue(ep, (float)a2, i2);
             }
         } else if (EPI == EPI_INV) {
             lp[pair * es] = apply_epilogue(ep, (float)(a1 + a2), pair);
@@ -375,8 +377,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                 for (int jn = 0; jn < NJ; ++jn) {
                     const unsigned pair = p0 + wn + 16 * jn + li;
                     const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
-                    vo1[jn] = (pair < NP && i1 < po.lim ) ? (lq * W + i1) * 4u : OOB;
-                    vo2[jn] = (pair < NP && i2 < po.lim && second_out) ? (lq * W + i2) * 4u : OOB;
+                    vo1[jn] = (pair < NP && pair < po.np1) ? (lq * W + i1) * 4u : OOB;
+                    vo2[jn] = (pair < NP && pair >= po.p2lo && second_out) ? (lq * W + i2) * 4u : OOB;
                     f1[jn] = i1 == 0 ? ep.first : ep.base;
                     f2[jn] = i2 == 0 ? ep.first : ep.base;
                 }
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                     const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
                     if (!line_ok || pair >= NP) continue;
                     const unsigned idx = EPI == EPI_FWD ? (set ? po.c2 : po.c1) + po.cs * pair : (set ? n - 1 - pair : pair);
-                    if (EPI == EPI_FWD && (idx >= po.lim || (set && !second_out))) continue;
+                    if (EPI == EPI_FWD && (set ? (pair < po.p2lo || !second_out) : pair >= po.np1)) continue;
                     put_quad(idx, v);
                 }
             }
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 // applies to the even part (its frequencies are multiples of 2^sub of the full transform's).
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
-                             size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out) {
+                             size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out, bool class_major) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t lines = is_row ? n_frames * h : n_frames * w;
@@ -855,10 +857,20 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
         po.pm = 1;
         if (!inverse) {
             po.c1 = (kind == 3 ? 1u : 5u) * fs; po.c2 = kind == 3 ? 0u - fs : 3u * fs; po.cs = 8 * fs;
-            po.lim = (unsigned)len;
+            if (kind == 3) { po.np1 = (unsigned)(leff / 8); po.p2lo = 1; }
         } else {
             po.c1 = kind == 3 ? 0u : 2u; po.c2 = kind == 3 ? 0u - 1u : 1u; po.cs = 4;             // positions of the odd part
         }
+    }
+    if (class_major) {
+        // forward row pass of a deep transform: every launch writes its frequencies side by side (ForwardClassLayout,
+        // dct_pair_common.hpp) instead of 4-byte pieces 16 / 32 bytes apart -- the column pre-pass puts the columns back
+        if (inverse || !is_row || !((kind == 1 && sub == 1) || split) || sub > 1) return SSW_ERR_BAD_ARG;
+        const ForwardClassLayout fl{(unsigned)len};
+        po.cs = 1;
+        if (kind == 1) { po.c1 = fl.base(ForwardClassLayout::R1); po.c2 = fl.base(ForwardClassLayout::R2); }
+        else if (kind == 3) { po.c1 = fl.base(sub ? ForwardClassLayout::E2P : ForwardClassLayout::EP); po.c2 = fl.base(sub ? ForwardClassLayout::E2M : ForwardClassLayout::EM) - 1; }
+        else { po.c1 = fl.base(sub ? ForwardClassLayout::O2P : ForwardClassLayout::OP); po.c2 = fl.base(sub ? ForwardClassLayout::O2M : ForwardClassLayout::OM); }
     }
     const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
     po.bn32 = bn32 ? 1u : 0u;
@@ -876,6 +888,11 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
         if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD_ADJ, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
         else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
         else if (kind == 2) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, true); else SSW_LAUNCH_PAIR(true, EPI_FWD, true); }
+        else if (is_row && kind == 3 && sub == 0) {
+            // class E of the full-length split odd half: the largest single launch of a transform, under its own
+            // instance name (SUB = 4) so that profiles and bench.py's roofline block refer to the same launches
+            if (small) SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 4, 64); else SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 4, 128);
+        }
         else {
             if (small) { if (is_row) SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 3, 64); else SSW_LAUNCH_PAIR_BM(true, EPI_FWD, false, 3, 64); }
             else       { if (is_row) SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 3, 128); else SSW_LAUNCH_PAIR_BM(true, EPI_FWD, false, 3, 128); }

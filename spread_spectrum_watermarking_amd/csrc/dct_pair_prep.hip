@@ -4,6 +4,8 @@
 // layout (dct_pair_common.hpp).  Also the half bases in that layout.
 #include "dct_pair_common.hpp"
 
+#include <cstdlib>
+
 namespace ssw {
 
 // ---------------------------------------------------------------------------------------------
@@ -571,6 +573,17 @@ __global__ __launch_bounds__(256) void pair_prep8_rows_kernel(const void* __rest
 // One thread = 4 consecutive e < n/16 of one line: the 16 quads of x that meet in them (quad u mirrors quad 15 - u).
 // Planes are k-blocked, K8 = kpad(n/4) (>= n/8) and K16 = kpad(n/8) (>= n/16) wide, zero padded.
 // ---------------------------------------------------------------------------------------------
+// the same for a single e (scalar kernels)
+template <typename T>
+__device__ inline void split_one(T d0, T d1, T d2, T d3, const double* __restrict__ rot, unsigned e, unsigned Mh, T& as, T& bd, T& ad, T& bs) {
+    const T cc = (T)rot[e], ss = (T)rot[Mh + e], ccm = (T)rot[Mh - 1 - e], ssm = (T)rot[2 * Mh - 1 - e];
+    const T a = d0 * cc + d3 * ss, b = d3 * cc - d0 * ss;
+    const T am = d1 * ccm + d2 * ssm, bm = d2 * ccm - d1 * ssm;
+    as = a + am;
+    ad = a - am;
+    bs = b + bm;
+    bd = b - bm;
+}
 // One unit of the split: four consecutive e = base .. base + 3 of a DCT-IV input d of length M (Mh = M/2) given as
 // ascending quads  dA: d[base + i], dB: d[Mh-4-base + i], dC: d[Mh+base + i], dD: d[M-4-base + i];
 // rot: [0, Mh) cos psi, [Mh, 2 Mh) sin psi.  Same operations in the same order as pair_rotate_kernel.
@@ -784,16 +797,6 @@ __global__ __launch_bounds__(256) void pair_prep8_cols_kernel(const float* __res
 //   0: AS BD AD BS at e            1: the same planes at the mirror unit H/8 - 1 - e
 //   2: AS2 BD2 AD2 BS2 at e        3: R1 R2 at e and at H/8 - 1 - e
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__device__ inline void split_one(T d0, T d1, T d2, T d3, const double* __restrict__ rot, unsigned e, unsigned Mh, T& as, T& bd, T& ad, T& bs) {
-    const T cc = (T)rot[e], ss = (T)rot[Mh + e], ccm = (T)rot[Mh - 1 - e], ssm = (T)rot[2 * Mh - 1 - e];
-    const T a = d0 * cc + d3 * ss, b = d3 * cc - d0 * ss;
-    const T am = d1 * ccm + d2 * ssm, bm = d2 * ccm - d1 * ssm;
-    as = a + am;
-    ad = a - am;
-    bs = b + bm;
-    bd = b - bm;
-}
 // v[0 .. nvalid) -> plane positions k0 .. (ascending); one 32-byte store when the run is a whole aligned quad
 template <typename T>
 __device__ inline void store_run(T* __restrict__ plane, size_t line, size_t lines, unsigned k0, const T (&v)[4], unsigned nvalid) {
@@ -808,7 +811,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                               const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                               unsigned W, unsigned H, unsigned K8, unsigned K16,
-                                                              unsigned n_frames, unsigned tiles_e, unsigned tiles_c) {
+                                                              unsigned n_frames, unsigned tiles_e, unsigned tiles_c, unsigned class_major) {
     __shared__ T s[4][32][33];
     const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = H / 16;
     const unsigned z = blockIdx.x / (tiles_e * tiles_c);
@@ -819,7 +822,10 @@ __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __re
     const unsigned er = tid >> 3, cq = (tid & 7) * 4;              // load side: one e, 4 columns
     const unsigned cl = tid & 31, kq = (tid >> 5) * 4;             // store side: one column, 4 consecutive e
     const unsigned cw = c0 + cl, ew = e0 + kq;
-    const size_t line = (size_t)z * W + cw, lines = (size_t)n_frames * W;
+    // memory column cw of the intermediate plane holds frequency natural(cw) of the row pass (class-major order): the
+    // operand line -- and with it the output column of the column GEMMs -- is the natural one
+    const unsigned cn = (class_major && cw < W) ? ForwardClassLayout{W}.natural(cw) : cw;
+    const size_t line = (size_t)z * W + cn, lines = (size_t)n_frames * W;
     T* planes8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs),
                      static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
     T* planes16[4] = {static_cast<T*>(dp.as2), static_cast<T*>(dp.bd2), static_cast<T*>(dp.ad2), static_cast<T*>(dp.bs2)};
@@ -1253,7 +1259,7 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
 // deep forward column pre-pass (H % 16 == 0): same plane order as the row version, lines = n_frames * w
 bool dct_pair_can_deep_cols(size_t len) { return len % 16 == 0 && len >= 256; }
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                const double* rot1, const double* rot2) {
+                                const double* rot1, const double* rot2, bool class_major) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !dct_pair_can_deep_cols(h) || w % 4 != 0) return SSW_ERR_BAD_DIMS;
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h), K16 = (unsigned)dct_pair_split_kpad(h / 2);
@@ -1267,7 +1273,7 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
     dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
     p += 6 * p8;
     dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
-    pair_prep16_cols_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c);
+    pair_prep16_cols_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, class_major ? 1u : 0u);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -92,6 +92,11 @@ struct Xform {
     // (iq_i / iq_q are then inputs); build_transform reports through `fused_rgb` whether it did
     void* rgb_out = nullptr;
     bool rgb_out_u8 = false;
+    // intermediate plane of a deep forward transform in class-major column order (dct_pair_common.hpp): decided from
+    // the frame's shape -- `full_h` when this Xform is a band of rows of a taller frame; `natural_order` forces the
+    // natural order (the compact plane of the pruned transform has its own)
+    size_t full_h = 0;
+    bool natural_order = false;
 };
 int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch, bool* fused_rgb = nullptr);
 bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8);
@@ -101,7 +106,7 @@ int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const
 // the same transform as two chains: the row pass of a band of image rows, and the column pass of the whole frame
 bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8);
 int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t w, size_t rows,
-                            float* tmp, float* i, float* q, Chain& ch);
+                            size_t frame_h, float* tmp, float* i, float* q, Chain& ch);
 int build_forward_cols_after_rows(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, size_t w, size_t h, float* tmp, float* y, Chain& ch);
 int run_serial(Chain& ch, hipStream_t st);
 // transform now, on the context's stream, with lane 0's workspace (handles, ssw_dct2d)

@@ -117,7 +117,7 @@ int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t
 // sink (inverse column pass, kind 2 only): colour conversion in the epilogue instead of storing Y
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
-                             size_t h, Epilogue ep, const RgbSink* sink = nullptr, double* tmp_out = nullptr);
+                             size_t h, Epilogue ep, const RgbSink* sink = nullptr, double* tmp_out = nullptr, bool class_major = false);
 int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const float* x1, const float* x2,
                              const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep, const RgbSink* sink = nullptr);
@@ -146,7 +146,7 @@ int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_fr
 int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                     const double* rot1, const double* rot2);
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                const double* rot1, const double* rot2);
+                                const double* rot1, const double* rot2, bool class_major = false);
 size_t dct_pair_deep_elems(size_t lines, size_t len);
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, float* ip, float* qp);

@@ -144,7 +144,7 @@ int forward_from_host(ssw_ctx* ctx, const void* host_rgb, bool u8, size_t w, siz
                 SSW_HIP_CHECK(hipEventRecord(ev, ctx->copy_stream));
                 SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
                 Chain ch;
-                SSW_TRY(build_forward_rows_band(ctx, ctx->lane[0], precision, (char*)fs.buf.p + band * hb, u8, w, h / 2, tmp + band * hp,
+                SSW_TRY(build_forward_rows_band(ctx, ctx->lane[0], precision, (char*)fs.buf.p + band * hb, u8, w, h / 2, h, tmp + band * hp,
                                                 i ? i + band * hp : nullptr, q ? q + band * hp : nullptr, ch));
                 SSW_TRY(run_serial(ch, ctx->stream));
             }
@@ -368,6 +368,12 @@ int ssw_ctx_set_overlap(ssw_ctx* ctx, int enable) {
 int ssw_ctx_set_prune(ssw_ctx* ctx, int enable) {
     if (!ctx) return SSW_ERR_BAD_ARG;
     ctx->prune = enable != 0;
+    return SSW_OK;
+}
+
+int ssw_ctx_set_odd_split(ssw_ctx* ctx, int enable) {
+    if (!ctx) return SSW_ERR_BAD_ARG;
+    ctx->split = enable != 0;
     return SSW_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "ssw_host.hpp"
+#include <cstdlib>
 
 namespace ssw {
 namespace host {
@@ -168,7 +169,7 @@ size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames) 
         size_t free_b = 0, total_b = 0;
         DeviceGuard g(ctx->device);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t lanes = (ctx->overlap && n_frames > 2 * c) ? 2 : 1;
+            const size_t lanes = (ctx->overlap && n_frames > c) ? 2 : 1;
             const size_t budget = (free_b + lane_bytes_held(ctx)) / 2;
             c = std::max<size_t>(1, std::min(c, budget / (lanes * 36 * px)));
         } else {
@@ -183,9 +184,9 @@ namespace {
 
 int pair_gemm(hipStream_t st, bool f64, bool is_row, bool inverse, int kind, int sub, const void* x1, const void* x2,
               const void* y1, const void* y2, float* dst, void* tmpE, size_t n, size_t w, size_t h, Epilogue ep,
-              const RgbSink* sink = nullptr, void* tmp_out = nullptr) {
+              const RgbSink* sink = nullptr, void* tmp_out = nullptr, bool class_major = false) {
     return f64 ? launch_dct_pair_gemm_f64(st, is_row, inverse, kind, sub, (const double*)x1, (const double*)x2, (const double*)y1,
-                                          (const double*)y2, dst, (double*)tmpE, n, w, h, ep, sink, (double*)tmp_out)
+                                          (const double*)y2, dst, (double*)tmpE, n, w, h, ep, sink, (double*)tmp_out, class_major)
                : launch_dct_pair_gemm_f32(st, is_row, inverse, kind, sub, (const float*)x1, (const float*)x2, (const float*)y1,
                                           (const float*)y2, dst, (float*)tmpE, n, w, h, ep, sink);
 }
@@ -265,22 +266,29 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             double* q = sp + 6 * p8;
             const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
             const void *t0 = sb2[0], *t1 = sb2[1], *t2 = sb2[2], *t3 = sb2[3];
+            // rows first and both passes deep: the row launches write class-major, the column pre-pass reads it back
+            const size_t fh = x.full_h ? x.full_h : h;
+            const bool cm = !x.natural_order && w >= fh && w % 4 == 0 && dct_pair_can_deep_rows(w) && dct_pair_can_deep_cols(fh) &&
+                            dct_pair_can_fold2_cols(fh) && (is_row ? first_pass : !first_pass);
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
-                if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2);
+                if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm);
                 return launch_dct_pair_prep16_rows(st, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
                                                    (const double*)rot, (const double*)rot2, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
             }});
-            const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h);
-            const double f_all = f_main + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
+            // the "main" timer brackets ONE launch: class E of the full-length split (the largest launch of the pass)
+            const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h);
+            const double f_all = f_main + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) +
+                                 pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
-                SSW_TRY(pair_gemm(st, true, is_row, false, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, nullptr, n, w, h, ep));
-                SSW_TRY(pair_gemm(st, true, is_row, false, 3, 1, q, q + p16, t0, t1, dst, nullptr, n, w, h, ep));
-                SSW_TRY(pair_gemm(st, true, is_row, false, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, nullptr, n, w, h, ep));
+                const bool rcm = cm && is_row;
+                SSW_TRY(pair_gemm(st, true, is_row, false, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
+                SSW_TRY(pair_gemm(st, true, is_row, false, 3, 1, q, q + p16, t0, t1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
+                SSW_TRY(pair_gemm(st, true, is_row, false, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
+                SSW_TRY(pair_gemm(st, true, is_row, false, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
                 StageTimer tm(ctx, st_main, st, f_main);
-                SSW_TRY(pair_gemm(st, true, is_row, false, 3, 0, sp, sp + p8, sb0, sb1, dst, nullptr, n, w, h, ep));
-                return pair_gemm(st, true, is_row, false, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, nullptr, n, w, h, ep);
+                return pair_gemm(st, true, is_row, false, 3, 0, sp, sp + p8, sb0, sb1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
             }});
             return SSW_OK;
         }
@@ -323,14 +331,13 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 if (fused_rgb) *fused_rgb = true;
             }
             const bool with_sink = sink.rgb != nullptr;
-            const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h);
-            const double f_all = f_main + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
+            const double f_all = pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) +
+                                 pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
                 SSW_TRY(pair_gemm(st, true, is_row, true, 3, 1, q, q + p16, t0, t1, dst, T2, n, w, h, ep, nullptr, TE));
                 SSW_TRY(pair_gemm(st, true, is_row, true, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, T2, n, w, h, ep, nullptr, TE));
-                StageTimer tm(ctx, st_main, st, f_main);
                 SSW_TRY(pair_gemm(st, true, is_row, true, 3, 0, sp, sp + p8, sb0, sb1, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr));
                 return pair_gemm(st, true, is_row, true, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr);
             }});
@@ -522,9 +529,10 @@ bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, co
     return w >= h && h % 16 == 0 && can_fuse_rgb(ctx, f64, w, h, y, tmp, rgb, u8) && can_fuse_rgb(ctx, f64, w, h / 2, y, tmp, rgb, u8);
 }
 int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t w, size_t rows,
-                            float* tmp, float* i, float* q, Chain& ch) {
+                            size_t frame_h, float* tmp, float* i, float* q, Chain& ch) {
     Xform x{SSW_DCT2, precision, 1, w, rows, tmp /* never read or written by this pass */, tmp};
     x.rgb = rgb; x.rgb_u8 = u8; x.iq_i = i; x.iq_q = q;
+    x.full_h = frame_h;
     return build_pass(ctx, ws, x, true, true, tmp, tmp, Epilogue{1.f, 1.f}, ch);
 }
 int build_forward_cols_after_rows(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, size_t w, size_t h, float* tmp, float* y, Chain& ch) {
@@ -597,7 +605,9 @@ int hop(ssw_ctx* ctx, ssw_ctx::Lane& ln, hipStream_t to) {
 }
 
 bool pipeline_uses_two_lanes(const ssw_ctx* ctx, size_t n_chunks) {
-    return ctx->overlap && n_chunks > 2 && ctx->aux_stream != nullptr;
+    // from two passes on (r3: with the pre-passes a quarter of a pass, the second lane's pre-passes fill the gaps between
+    // the first lane's GEMM launches: +2.1 % at 2 x 128 4K frames; r2 measured nothing below three passes)
+    return ctx->overlap && n_chunks >= 2 && ctx->aux_stream != nullptr;
 }
 
 // Runs build(chunk, lane, chain) for every chunk and enqueues the chains: one lane on one stream when
@@ -733,7 +743,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     const PrunePlan plan = ps.plan;
     const size_t cap = plan.cap_total;
     const size_t bytes = dct_pair_operand_elems(f64, n, w, h) * esz;
-    for (int b = 0; b < 4; ++b) SSW_TRY(grow(ws.operand[b], bytes));
+    if (!ps.deep) for (int b = 0; b < 4; ++b) SSW_TRY(grow(ws.operand[b], bytes));      // the deep pre-pass writes into operand[5] only
     for (int b = 0; b < 2; ++b) SSW_TRY(grow(ws.compact[b], n * h * cap * sizeof(float)));
     SSW_TRY(grow(ws.prune_u32, (2 * w + cap + 64) * sizeof(uint32_t)));
     uint32_t* flag = (uint32_t*)ws.prune_u32.p;
@@ -835,6 +845,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     }});
     // column pass on the compact plane: the second pass of the same transform, `cap` columns wide
     Xform xc{SSW_DCT2, precision, n, cap, h, (float*)ws.compact[1].p, t_compact};
+    xc.natural_order = true;                 // the compact plane's columns are the gathered frequencies, in the plan's order
     return build_pass(ctx, ws, xc, false, false, t_compact, (float*)ws.compact[1].p, Epilogue{1.f, 1.f}, ch);
 }
 

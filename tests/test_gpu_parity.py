@@ -170,6 +170,35 @@ def test_dct_operand_ready_path_matches(shape, dct_type, level):
     assert np.abs(three.astype(np.float64) - ref).max() <= 2e-7 * max(ac_max(ref), 1.0)
 
 
+# (H, W): rows deep forward and inverse (W % 128), forward only (W % 64), first level only (W % 8); columns deep (H % 16,
+# >= 256) or first level only (H % 8, or short); plus shapes the split does not take at all
+@pytest.mark.parametrize("shape", [(256, 512), (272, 384), (264, 320), (136, 200), (512, 256), (304, 1024), (1080, 1920), (72, 136)])
+@pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
+def test_odd_split_matches_exact_operands(shape, dct_type):
+    """ssw_ctx_set_odd_split: the odd halves as rotated quarter-length cosine + sine pairs (default; "deep" pre-passes
+    where the lengths allow) against the same transform with every operand an exact folded sum.  Both are the f64-
+    accurate transform rounded once to f32: they agree except where that rounding sat on a tie, and both match the
+    oracle like test_dct_operand_ready_path_matches."""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    x = rng.random((3,) + shape).astype(np.float32)
+    if dct_type == L.DCT3:
+        x = np.stack([O.dct2d(p, O.DCT2) for p in x])
+    split = G.dct2d(x, dct_type, F64)
+    G.ctx().set_odd_split(False)
+    try:
+        exact = G.dct2d(x, dct_type, F64)
+    finally:
+        G.ctx().set_odd_split(True)
+    ref = np.stack([O.dct2d(p, dct_type) for p in x])
+    assert np.mean(split == exact) >= 0.9995
+    assert np.mean(split == ref) >= 0.998 and np.mean(exact == ref) >= 0.998
+    assert np.abs(split.astype(np.float64) - ref).max() <= 2e-7 * max(ac_max(ref), 1.0)
+    # and back: the round trip through both directions of the split transform returns the input (dct2d.rs:213-217)
+    if dct_type == L.DCT2:
+        back = G.dct2d(split, L.DCT3, F64)
+        assert np.abs(back - x).max() <= 4e-7
+
+
 @pytest.mark.parametrize("shape", [(24, 40), (72, 136), (136, 72), (80, 208), (144, 1040), (1080, 1920), (128, 256), (288, 136)])
 @pytest.mark.parametrize("dct_type", [L.DCT2, L.DCT2_ORTHOGONAL, L.DCT3])
 @pytest.mark.parametrize("level", [1, 3, 4, 6])

@@ -36,28 +36,34 @@ def strip_tile(table):      # instance names carry the block-tile template argum
 fetch, write = strip_tile(load(f"{d}/{tag}_pmc_fetch.txt")), strip_tile(load(f"{d}/{tag}_pmc_write.txt"))
 lines_r, lines_c = chunk * H, chunk * W
 esz = 8
+K8 = lambda n: -(-(n // 8) // 16) * 16        # padded sum length of the n/8-wide operand planes
 names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESIGN.md, algorithmic bytes per launch, note)
-    "pair_gemm_f64_kernel<false, 0, true, 0>": ("pair_gemm_f64_kernel<rows, odd half>",
-        lines_r * (W // 2) * esz + (W // 2) ** 2 * esz + lines_r * (W // 2) * 4,
-        "x- operand plane (k-blocked f64) x odd half basis -> the W/2 odd frequencies (f32)"),
-    "pair_gemm_f64_kernel<false, 0, true, 1>": ("pair_gemm_f64_kernel<rows, S- launch>",
-        lines_r * (W // 4) * esz + (W // 4) ** 2 * esz + lines_r * (W // 4) * 4, "frequencies 2 mod 4 (third folding level)"),
+    "pair_gemm_f64_kernel<false, 0, false, 4>": ("pair_gemm_f64_kernel<rows, split odd half, class E>",
+        2 * lines_r * K8(W) * esz + 2 * (W // 8 + 1) * K8(W) * esz + lines_r * (W // 4) * 4,
+        "AS and BD operand planes (k-blocked f64) x cosine / sine rows 2i -> frequencies 8i +/- 1 (f32)"),
+    "pair_gemm_f64_kernel<false, 0, false, 3>": ("pair_gemm_f64_kernel<rows, split odd halves, other classes>",
+        2 * lines_r * K8(W) * esz + 2 * (W // 8) * K8(W) * esz + lines_r * (W // 4) * 4,
+        "class O of the full-length split and both classes of the half-length one (half the size), and the gathered launches of the pruned transform: mean over launches"),
     "pair_gemm_f64_kernel<false, 0, false, 1>": ("pair_gemm_f64_kernel<rows, (SSS, SS-) launch>",
         2 * lines_r * (W // 8) * esz + 2 * (W // 8) ** 2 * esz + lines_r * (W // 4) * 4, "frequencies 0 and 4 mod 8"),
-    "pair_gemm_f64_kernel<true, 0, true, 0>": ("pair_gemm_f64_kernel<cols, odd half>",
-        lines_c * (H // 2) * esz + (H // 2) ** 2 * esz + lines_c * (H // 2) * 4, "forward column pass, odd frequencies"),
-    "pair_gemm_f64_kernel<true, 0, false, 0>": ("pair_gemm_f64_kernel<cols, even half>",
-        2 * lines_c * (H // 4) * esz + 2 * (H // 4) ** 2 * esz + lines_c * (H // 2) * 4, "forward column pass, even frequencies (two levels)"),
-    "pair_gemm_f64_kernel<true, 5, true, 0>": ("pair_gemm_f64_kernel<cols, inverse odd half + yiq->rgb>",
-        lines_c * (H // 2) * esz + (H // 2) ** 2 * esz + lines_c * (H // 2) * esz + lines_c * H * (8 + 12),
-        "last pass of Writer::result: O operand + unrounded even half in, I and Q in, RGB f32 out"),
-    "pair_prep8_rows_kernel<double, 1, false>": ("pair_prep8_rows_kernel<double, rgb>", lines_r * W * (12 + esz),
-        "reader: RGB f32 in, three-level f64 operand planes out"),
-    "pair_prep8_rows_kernel<double, 1, true>": ("pair_prep8_rows_kernel<double, rgb, with I/Q>", lines_r * W * (12 + 8 + esz),
+    "pair_gemm_f64_kernel<true, 0, false, 3>": ("pair_gemm_f64_kernel<cols, split odd halves>",
+        2 * lines_c * K8(H) * esz + 2 * (H // 8) * K8(H) * esz + lines_c * (H // 4) * 4, "forward column pass, classes E / O of both split levels: mean over launches"),
+    "pair_gemm_f64_kernel<true, 0, false, 1>": ("pair_gemm_f64_kernel<cols, (SSS, SS-) launch>",
+        2 * lines_c * (H // 8) * esz + 2 * (H // 8) ** 2 * esz + lines_c * (H // 4) * 4, "forward column pass, frequencies 0 and 4 mod 8"),
+    "pair_gemm_f64_kernel<false, 4, false, 0>": ("pair_gemm_f64_kernel<rows, inverse split odd half>",
+        2 * lines_r * K8(W) * esz + 2 * (W // 8) * K8(W) * esz + lines_r * (W // 4) * esz + lines_r * (W // 2) * 4,
+        "inverse row pass: split odd part + the unrounded even half E -> half of the outputs (f32)"),
+    "pair_gemm_f64_kernel<true, 5, false, 0>": ("pair_gemm_f64_kernel<cols, inverse split odd half + yiq->rgb>",
+        2 * lines_c * K8(H) * esz + 2 * (H // 8) * K8(H) * esz + lines_c * (H // 4) * esz + lines_c * (H // 2) * (8 + 12),
+        "last pass of Writer::result: split odd part + unrounded even half in, I and Q in, RGB f32 out (per launch: half of the rows)"),
+    "pair_prep16_rows_kernel<double, 1, false>": ("pair_prep16_rows_kernel<double, rgb>", lines_r * W * (12 + esz),
+        "reader: RGB f32 in, the ten f64 operand planes of the deep row pass out"),
+    "pair_prep16_rows_kernel<double, 1, true>": ("pair_prep16_rows_kernel<double, rgb, with I/Q>", lines_r * W * (12 + 8 + esz),
         "writer: RGB f32 in, operand planes + I, Q planes out"),
-    "pair_prep4_cols_kernel<double, false>": ("pair_prep4_cols_kernel<double, forward>", lines_r * W * (4 + esz),
-        "f32 plane in, transposed two-level f64 operand planes out (mean over launches incl. the narrow pruned ones)"),
-    "pair_prep4_rows_kernel<double, true>": ("pair_prep4_rows_kernel<double, inverse>", lines_r * W * (4 + esz), "coefficient plane in, (EE, EO, O) out"),
+    "pair_prep16_cols_kernel<double>": ("pair_prep16_cols_kernel<double>", lines_r * W * (4 + esz),
+        "f32 plane in, transposed deep f64 operand planes out (mean over launches incl. the narrow pruned ones)"),
+    "pair_prep16_inv_rows_kernel<double>": ("pair_prep16_inv_rows_kernel<double>", lines_r * W * (4 + esz), "coefficient plane in, deep inverse operand planes out"),
+    "pair_prep16_inv_cols_kernel<double>": ("pair_prep16_inv_cols_kernel<double>", lines_r * W * (4 + esz), "the same, transposed"),
     "select_compact_kernel<true>": ("select_compact_kernel<energy>", lines_r * W * 4, "the one full pass of the top-k selection"),
 }
 out = {"_how": __doc__.strip().split("usage:")[0].strip(), "commit": commit,

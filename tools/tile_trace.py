@@ -37,6 +37,7 @@ raw.ssw_debug_get_tile_trace_count(ctypes.byref(n))
 cnt = min(n.value, CAP)
 t = buf.to_host(np.uint64, (cnt, 8))
 tag = (t[:, 5] & 0xFFFFFFFF).astype(np.int64)
+cyc = ((t[:, 5] >> 36) & 0xFFFFFFF).astype(np.int64)
 kp = (t[:, 6] >> 32).astype(np.int64)
 npairs = (t[:, 6] & 0xFFFFFFFF).astype(np.int64)
 hw = (t[:, 4] & 0xFFFFFFFF).astype(np.int64)
@@ -55,6 +56,7 @@ for key, ids in sorted(groups.items(), key=lambda kv: t[kv[1][0], 0]):
     pro, main, epi = (a[:, 1] - a[:, 0]) / 100.0, (a[:, 2] - a[:, 1]) / 100.0, (a[:, 3] - a[:, 2]) / 100.0   # us (100 MHz)
     issue = (a[:, 7] - a[:, 2]) / 100.0
     span = (a[:, 3].max() - a[:, 0].min()) / 100.0
+    mhz = np.median(cyc[ids] / np.maximum((a[:, 3] - a[:, 0]) / 100.0, 1e-3))
     # per CU: time covered by 0 / 1 / 2+ blocks between first start and last end of the launch
     cov = np.zeros(3)
     gaps = []
@@ -72,7 +74,7 @@ for key, ids in sorted(groups.items(), key=lambda kv: t[kv[1][0], 0]):
             level += d
         cov[0] += end - last
     cov = cov / cov.sum()
-    print(f"tag {key[0]:4d} Kp {key[1]:5d} NP {key[2]:4d}: {len(ids):6d} tiles, launch {span / 1000:7.3f} ms | prologue {pro.mean():6.2f} us, "
+    print(f"[{mhz:6.0f} MHz] tag {key[0]:4d} Kp {key[1]:5d} NP {key[2]:4d}: {len(ids):6d} tiles, launch {span / 1000:7.3f} ms | prologue {pro.mean():6.2f} us, "
           f"main {main.mean():7.2f} (min {main.min():7.2f}), epilogue {epi.mean():6.2f} (issued after {issue.mean():6.2f}) | CU time with 0 / 1 / 2+ blocks in the main loop: "
           f"{cov[0]:.3f} / {cov[1]:.3f} / {cov[2]:.3f}")
 ctx.close()
