@@ -62,6 +62,7 @@ struct PairOutT {
     unsigned pm = 0;
     unsigned np1 = 0xFFFFFFFFu, p2lo = 0;
     T* tmp_out = nullptr;     // EPI_INV_OT
+    unsigned cm = 0;          // inverse row pass: output line (and the E plane) in class-major order (inverse_class_pos)
 };
 
 // Column order of the intermediate plane between the two passes of a deep forward transform (row pass first): the
@@ -90,6 +91,19 @@ struct ForwardClassLayout {
         return 8 * i + (c == 0 ? 1u : c == 1 ? 7u : c == 2 ? 5u : 3u);
     }
 };
+
+// The same idea for a deep INVERSE transform's row pass: a launch of the split odd part produces the positions 4i and
+// 4i-1 (class E) or 4i+2 and 4i+1 (class O) and their mirrors -- residues {0, 3} or {1, 2} mod 4 -- of the output line,
+// and reads / writes the even half E at the same residues.  Class-major order of a line of length len (len % 4 == 0):
+//   [ m = 0 mod 4 | m = 3 mod 4 | m = 1 mod 4 | m = 2 mod 4 ], each len/4 long, m / 4 ascending.
+__host__ __device__ inline unsigned inverse_class_pos(unsigned m, unsigned len) {
+    const unsigned c = m & 3u, q = len / 4;
+    return (c == 0 ? 0u : c == 3 ? q : c == 1 ? 2 * q : 3 * q) + (m >> 2);
+}
+__host__ __device__ inline unsigned inverse_class_natural(unsigned p, unsigned len) {
+    const unsigned q = len / 4, c = p / q, i = p - c * q;
+    return 4 * i + (c == 0 ? 0u : c == 1 ? 3u : c == 2 ? 1u : 2u);
+}
 
 // yiq.rs:139-147 (f32::clamp) and :163-165, :173-175: the arithmetic of color.hip / attack.hip, per pixel
 __device__ inline float pair_clamp01(float x) {

@@ -319,6 +319,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
     const unsigned n = po.n, W = po.W, H = po.H;
     // one output line: element idx of the transformed axis lives at lp[idx * es] (and tp[idx * es] in T)
     // element offsets idx * es stay below 2^32 (W * H < 2^32: indices are u32 throughout)
+    // position of element m of a line of length len: natural, or class-major on the row pass of a deep inverse transform
+    auto opos = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len) : m; };
     auto emit = [&](float* lp, double* tp, double* to, unsigned es, unsigned pair, double a1, double a2) {
         if (EPI == EPI_FWD || EPI == EPI_FWD_ADJ) {
             const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
@@ -337,19 +339,19 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
             tp[(n / 2 - 1 - pair) * es] = a1 - a2;
         } else if (EPI == EPI_INV_OT) {
             const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * pair;
-            if (n1 < n / 2) { const double e1 = tp[n1 * es]; to[n1 * es] = e1 + a1; to[(n - 1 - n1) * es] = e1 - a1; }
-            if (n2 < n / 2) { const double e2 = tp[n2 * es]; to[n2 * es] = e2 + a2; to[(n - 1 - n2) * es] = e2 - a2; }
+            if (n1 < n / 2) { const double e1 = tp[n1 * es]; to[opos(n1, n) * es] = e1 + a1; to[opos(n - 1 - n1, n) * es] = e1 - a1; }
+            if (n2 < n / 2) { const double e2 = tp[n2 * es]; to[opos(n2, n) * es] = e2 + a2; to[opos(n - 1 - n2, n) * es] = e2 - a2; }
         } else {
             const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * pair;      // positions in the odd part, < n/2
             if (n1 < n / 2) {
-                const double e1 = tp[n1 * es];
-                lp[n1 * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
-                lp[(n - 1 - n1) * es] = apply_epilogue(ep, (float)(e1 - a1), n - 1 - n1);
+                const double e1 = tp[opos(n1, n / 2) * es];
+                lp[opos(n1, n) * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
+                lp[opos(n - 1 - n1, n) * es] = apply_epilogue(ep, (float)(e1 - a1), n - 1 - n1);
             }
             if (n2 < n / 2) {
-                const double e2 = tp[n2 * es];
-                lp[n2 * es] = apply_epilogue(ep, (float)(e2 + a2), n2);
-                lp[(n - 1 - n2) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
+                const double e2 = tp[opos(n2, n / 2) * es];
+                lp[opos(n2, n) * es] = apply_epilogue(ep, (float)(e2 + a2), n2);
+                lp[opos(n - 1 - n2, n) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
             }
         }
     };
@@ -408,8 +410,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                         const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * pair;
                         const bool ok = pair < NP && nn < n / 2;
                         vt[jn][h2] = ok ? (lq * (n / 2) + nn) * 8u : OOB;
-                        vp[jn][h2] = ok ? (lq * n + nn) * 8u : OOB;
-                        vm[jn][h2] = ok ? (lq * n + (n - 1 - nn)) * 8u : OOB;
+                        vp[jn][h2] = ok ? (lq * n + opos(nn, n)) * 8u : OOB;
+                        vm[jn][h2] = ok ? (lq * n + opos(n - 1 - nn, n)) * 8u : OOB;
                     }
                 }
                 auto std64 = [&](double v, unsigned voff, unsigned soff) {
@@ -455,9 +457,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * pair;
                         const bool ok = pair < NP && nn < n / 2;
-                        vt[jn][h2] = ok ? (lq * (n / 2) + nn) * 8u : OOB;
-                        vp[jn][h2] = ok ? (lq * W + nn) * 4u : OOB;
-                        vm[jn][h2] = ok ? (lq * W + (n - 1 - nn)) * 4u : OOB;
+                        vt[jn][h2] = ok ? (lq * (n / 2) + opos(nn, n / 2)) * 8u : OOB;
+                        vp[jn][h2] = ok ? (lq * W + opos(nn, n)) * 4u : OOB;
+                        vm[jn][h2] = ok ? (lq * W + opos(n - 1 - nn, n)) * 4u : OOB;
                         fp[jn][h2] = nn == 0 ? ep.first : ep.base;
                     }
                 }
@@ -865,10 +867,16 @@ int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind
     if (class_major) {
         // forward row pass of a deep transform: every launch writes its frequencies side by side (ForwardClassLayout,
         // dct_pair_common.hpp) instead of 4-byte pieces 16 / 32 bytes apart -- the column pre-pass puts the columns back
-        if (inverse || !is_row || !((kind == 1 && sub == 1) || split) || sub > 1) return SSW_ERR_BAD_ARG;
+        if (!is_row || !((kind == 1 && sub == 1) || split) || sub > 1) return SSW_ERR_BAD_ARG;
+        if (inverse) {
+            // the split launches write (and read E) at one pair of residues mod 4: inverse_class_pos; the quarter-length
+            // even half T2 (kind 1) keeps the natural order
+            if (split) po.cm = 1;
+        }
         const ForwardClassLayout fl{(unsigned)len};
-        po.cs = 1;
-        if (kind == 1) { po.c1 = fl.base(ForwardClassLayout::R1); po.c2 = fl.base(ForwardClassLayout::R2); }
+        if (!inverse) po.cs = 1;
+        if (inverse) { }
+        else if (kind == 1) { po.c1 = fl.base(ForwardClassLayout::R1); po.c2 = fl.base(ForwardClassLayout::R2); }
         else if (kind == 3) { po.c1 = fl.base(sub ? ForwardClassLayout::E2P : ForwardClassLayout::EP); po.c2 = fl.base(sub ? ForwardClassLayout::E2M : ForwardClassLayout::EM) - 1; }
         else { po.c1 = fl.base(sub ? ForwardClassLayout::O2P : ForwardClassLayout::OP); po.c2 = fl.base(sub ? ForwardClassLayout::O2M : ForwardClassLayout::OM); }
     }

@@ -994,7 +994,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                                   const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                                   unsigned W, unsigned H, unsigned K8, unsigned K16,
-                                                                  unsigned n_frames, unsigned groups, unsigned tiles_c) {
+                                                                  unsigned n_frames, unsigned groups, unsigned tiles_c, unsigned class_major) {
     __shared__ T s[16][32][9];
     const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = H / 16;
     const unsigned z = blockIdx.x / (groups * tiles_c);
@@ -1025,7 +1025,9 @@ __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* 
     for (int v = 0; v < 16; ++v) s[v][cl][t] = ok ? o[v] : (T)0;
     __syncthreads();
     if (c0 + cl >= W) return;
-    const size_t line = (size_t)z * W + c0 + cl, lines = (size_t)n_frames * W;
+    // memory column c0 + cl of the row pass's output holds position inverse_class_natural(..) of the line (class-major)
+    const unsigned cn = class_major ? inverse_class_natural(c0 + cl, W) : c0 + cl;
+    const size_t line = (size_t)z * W + cn, lines = (size_t)n_frames * W;
     const unsigned nv = 8 * G >= H16 ? 0u : (H16 - 8 * G < 8 ? H16 - 8 * G : 8u);          // valid units of the group
     const unsigned h = t;                                          // store side: thread h of a column takes value type h
     {   // AS BD AD BS at e = 8G .. (h < 4) or at the mirror units H/8 - 1 - e, ascending from H/8 - 8G - nv (h >= 4)
@@ -1306,7 +1308,7 @@ int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_fr
     return SSW_OK;
 }
 int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                    const double* rot1, const double* rot2) {
+                                    const double* rot1, const double* rot2, bool class_major) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !dct_pair_can_deep_cols(h)) return SSW_ERR_BAD_DIMS;
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h), K16 = (unsigned)dct_pair_split_kpad(h / 2);
@@ -1314,7 +1316,7 @@ int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_fr
     const unsigned long long nblk = (unsigned long long)groups * tiles_c * n_frames;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     pair_prep16_inv_cols_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, deep_planes(base, n_frames * w, h), rot1, rot2, (unsigned)w, (unsigned)h,
-                                                                       K8, K16, (unsigned)n_frames, groups, tiles_c);
+                                                                       K8, K16, (unsigned)n_frames, groups, tiles_c, class_major ? 1u : 0u);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -144,7 +144,7 @@ bool dct_pair_can_deep_inv_rows(size_t len);             // W % 128 == 0
 int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                     const double* rot1, const double* rot2);
 int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                    const double* rot1, const double* rot2);
+                                    const double* rot1, const double* rot2, bool class_major = false);
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, bool class_major = false);
 size_t dct_pair_deep_elems(size_t lines, size_t len);

@@ -320,9 +320,13 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             double* q = sp + 6 * p8;
             const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
             const void *t0 = sb2[0], *t1 = sb2[1], *t2 = sb2[2], *t3 = sb2[3];
+            // rows first and both passes deep: the row pass's split launches write (and exchange E) class-major
+            const bool cm = !x.natural_order && w >= h && w % 4 == 0 && dct_pair_can_deep_inv_rows(w) && dct_pair_can_deep_cols(h) &&
+                            dct_pair_can_fold2_cols(h) && (is_row ? first_pass : !first_pass);
+            const bool rcm = cm && is_row;
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
-                if (!is_row) return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2);
+                if (!is_row) return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm);
                 return launch_dct_pair_prep16_inv_rows(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2);
             }});
             RgbSink sink;
@@ -336,10 +340,10 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
-                SSW_TRY(pair_gemm(st, true, is_row, true, 3, 1, q, q + p16, t0, t1, dst, T2, n, w, h, ep, nullptr, TE));
-                SSW_TRY(pair_gemm(st, true, is_row, true, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, T2, n, w, h, ep, nullptr, TE));
-                SSW_TRY(pair_gemm(st, true, is_row, true, 3, 0, sp, sp + p8, sb0, sb1, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr));
-                return pair_gemm(st, true, is_row, true, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr);
+                SSW_TRY(pair_gemm(st, true, is_row, true, 3, 1, q, q + p16, t0, t1, dst, T2, n, w, h, ep, nullptr, TE, rcm));
+                SSW_TRY(pair_gemm(st, true, is_row, true, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, T2, n, w, h, ep, nullptr, TE, rcm));
+                SSW_TRY(pair_gemm(st, true, is_row, true, 3, 0, sp, sp + p8, sb0, sb1, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm));
+                return pair_gemm(st, true, is_row, true, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm);
             }});
             return SSW_OK;
         }
