@@ -1002,7 +1002,10 @@ __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* 
     const unsigned G = tt % groups, c0 = (tt / groups) * 32;
     const float* __restrict__ Pz = IN + (size_t)z * H * W;
     const unsigned cl = threadIdx.x & 31, t = threadIdx.x >> 5;
-    const unsigned col = c0 + cl < W ? c0 + cl : W - 1;
+    // class-major input: lane cl takes NATURAL column c0 + cl, i.e. memory column inverse_class_pos(c0 + cl) -- the loads
+    // of a row are four 32-byte runs (one per residue class) and the stores below stay runs of consecutive operand lines
+    const unsigned coln = c0 + cl < W ? c0 + cl : W - 1;
+    const unsigned col = class_major ? inverse_class_pos(coln, W) : coln;
     auto ld = [&](unsigned r) { return (T)Pz[(size_t)r * W + col]; };
     T* P8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs), static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
     T* P16[4] = {static_cast<T*>(dp.as2), static_cast<T*>(dp.bd2), static_cast<T*>(dp.ad2), static_cast<T*>(dp.bs2)};
@@ -1025,9 +1028,7 @@ __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* 
     for (int v = 0; v < 16; ++v) s[v][cl][t] = ok ? o[v] : (T)0;
     __syncthreads();
     if (c0 + cl >= W) return;
-    // memory column c0 + cl of the row pass's output holds position inverse_class_natural(..) of the line (class-major)
-    const unsigned cn = class_major ? inverse_class_natural(c0 + cl, W) : c0 + cl;
-    const size_t line = (size_t)z * W + cn, lines = (size_t)n_frames * W;
+    const size_t line = (size_t)z * W + c0 + cl, lines = (size_t)n_frames * W;
     const unsigned nv = 8 * G >= H16 ? 0u : (H16 - 8 * G < 8 ? H16 - 8 * G : 8u);          // valid units of the group
     const unsigned h = t;                                          // store side: thread h of a column takes value type h
     {   // AS BD AD BS at e = 8G .. (h < 4) or at the mirror units H/8 - 1 - e, ascending from H/8 - 8G - nv (h >= 4)
