@@ -51,7 +51,7 @@ PM="--batch 128 --steps 1 --warmup 1 --no-overlap $SHORT"      # one 128-frame p
 pmc fetch FETCH_SIZE -- $PM
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $PM
 pmc valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $PM
-pmc mfma SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -- $PM
+pmc mfma SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $PM
 python3 "$R/tools/pmc_traffic_json.py" "$OUT" "$TAG" 3840 2160 128 "$COMMIT" > "$OUT/${TAG}_pmc_traffic.json"
 # the same two traffic passes on one 32-frame pass of configs[4] (8K, 8-bit): roofline.traffic of `--config 4`
 PA="--config 4 --batch 32 --steps 1 --warmup 1 --no-overlap $SHORT"
