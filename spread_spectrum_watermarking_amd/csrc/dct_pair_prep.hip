@@ -807,13 +807,16 @@ __device__ inline void store_run(T* __restrict__ plane, size_t line, size_t line
     }
 }
 
-template <typename T>
+// SPLIT_SD = false ("semi-deep", H % 8 == 0 but not % 16, e.g. 1080 rows): H/16 is not whole, so SD stays one DCT-IV input
+// plane (`dp.as2`, kpad(H/2) wide: the r2 launch of the frequencies 2 mod 4) and the units run to ceil(H/16) -- the
+// middle unit is its own mirror and stores its values twice.
+template <typename T, bool SPLIT_SD>
 __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                               const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                               unsigned W, unsigned H, unsigned K8, unsigned K16,
                                                               unsigned n_frames, unsigned tiles_e, unsigned tiles_c, unsigned class_major) {
     __shared__ T s[4][32][33];
-    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = H / 16;
+    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = SPLIT_SD ? H / 16 : (H / 8 + 1) / 2;      // H16: units
     const unsigned z = blockIdx.x / (tiles_e * tiles_c);
     const unsigned tt = blockIdx.x % (tiles_e * tiles_c);
     const unsigned e0 = (tt % tiles_e) * 32, c0 = (tt / tiles_e) * 32;
@@ -879,7 +882,8 @@ __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __re
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { SS[u] = S[u] + S[7 - u]; SD[u] = S[u] - S[7 - u]; }
                 if (round == 2) {
-                    split_one<T>(SD[0], SD[1], SD[2], SD[3], rot2, ec, H8, o[0], o[1], o[2], o[3]);
+                    if (SPLIT_SD) split_one<T>(SD[0], SD[1], SD[2], SD[3], rot2, ec, H8, o[0], o[1], o[2], o[3]);
+                    else { o[0] = SD[0]; o[1] = SD[1]; o[2] = SD[2]; o[3] = SD[3]; }      // SD at e, H/8-1-e, H/8+e, H/4-1-e
                 } else {
                     o[0] = SS[0] + SS[3]; o[1] = SS[0] - SS[3];      // R1, R2 at e
                     o[2] = SS[1] + SS[2]; o[3] = SS[1] - SS[2];      // R1, R2 at H/8 - 1 - e
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __re
             for (int a = 0; a < 4; ++a) s[a][cq + i][er] = unit_ok ? o[a] : (T)0;
         }
         __syncthreads();
-        if (cw < W && ew < K16) {
+        if (cw < W && ew < (SPLIT_SD ? K16 : ((H16 + 3) & ~3u))) {
             T v[4];
             if (round == 0) {
 #pragma unroll
@@ -898,8 +902,17 @@ __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __re
 #pragma unroll
                 for (int a = 0; a < 4; ++a) { gather(a, v, true); if (nvalid) store_run<T>(planes8[a], line, lines, H8 - ew - nvalid, v, nvalid); }
             } else if (round == 2) {
+                if (SPLIT_SD) {
 #pragma unroll
-                for (int a = 0; a < 4; ++a) { gather(a, v, false); store_run<T>(planes16[a], line, lines, ew, v, 4u); }   // zeros beyond H/16
+                    for (int a = 0; a < 4; ++a) { gather(a, v, false); store_run<T>(planes16[a], line, lines, ew, v, 4u); }   // zeros beyond H/16
+                } else {
+                    T* M = planes16[0];
+                    gather(0, v, false); store_run<T>(M, line, lines, ew, v, nvalid);
+                    gather(2, v, false); store_run<T>(M, line, lines, H8 + ew, v, nvalid);
+                    gather(1, v, true); if (nvalid) store_run<T>(M, line, lines, H8 - ew - nvalid, v, nvalid);
+                    gather(3, v, true); if (nvalid) store_run<T>(M, line, lines, Hq - ew - nvalid, v, nvalid);
+                    if (ew == 0) for (unsigned k = Hq; k < K16; ++k) M[blk_index<T>(line, k, lines)] = (T)0;      // K16: kpad(H/2) here
+                }
             } else {
                 gather(0, v, false); store_run<T>(planes8[4], line, lines, ew, v, nvalid);
                 gather(1, v, false); store_run<T>(planes8[5], line, lines, ew, v, nvalid);
@@ -1261,12 +1274,19 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
 
 // deep forward column pre-pass (H % 16 == 0): same plane order as the row version, lines = n_frames * w
 bool dct_pair_can_deep_cols(size_t len) { return len % 16 == 0 && len >= 256; }
+// semi-deep: H % 8 == 0 but not % 16 (1080 rows): D split, SS folded a third time, SD left whole
+bool dct_pair_can_semi_deep_cols(size_t len) { return len % 8 == 0 && len % 16 != 0 && len >= 256; }
+size_t dct_pair_semi_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + pair_kpad<double>(len / 2)); }
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, bool class_major) {
     if (n_frames == 0) return SSW_OK;
-    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !dct_pair_can_deep_cols(h) || w % 4 != 0) return SSW_ERR_BAD_DIMS;
-    const unsigned K8 = (unsigned)dct_pair_split_kpad(h), K16 = (unsigned)dct_pair_split_kpad(h / 2);
-    const unsigned tiles_e = (K16 + 31) / 32, tiles_c = (unsigned)((w + 31) / 32);
+    const bool semi = dct_pair_can_semi_deep_cols(h);
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !(dct_pair_can_deep_cols(h) || semi) || w % 4 != 0) return SSW_ERR_BAD_DIMS;
+    if (semi && class_major) return SSW_ERR_BAD_ARG;
+    const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
+    const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the SD plane
+    const unsigned units = semi ? (unsigned)(((h / 8 + 1) / 2 + 3) & ~(size_t)3) : K16;
+    const unsigned tiles_e = (units + 31) / 32, tiles_c = (unsigned)((w + 31) / 32);
     const unsigned long long nblk = (unsigned long long)tiles_e * tiles_c * n_frames;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t lines = n_frames * w;
@@ -1275,8 +1295,9 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
     const size_t p8 = lines * K8, p16 = lines * K16;
     dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
     p += 6 * p8;
-    dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
-    pair_prep16_cols_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, class_major ? 1u : 0u);
+    dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;      // semi: as2 = the SD plane, the others unused
+    if (semi) pair_prep16_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, 0u);
+    else      pair_prep16_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, class_major ? 1u : 0u);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -140,6 +140,8 @@ int launch_dct_pair_rotate(hipStream_t st, const double* p, const double* rot, d
 bool dct_pair_can_deep_rows(size_t len);
 bool dct_pair_can_deep_cols(size_t len);                 // H % 16 == 0
 bool dct_pair_can_deep_inv_rows(size_t len);             // W % 128 == 0
+bool dct_pair_can_semi_deep_cols(size_t len);            // H % 8 == 0, not % 16: launch_dct_pair_prep16_cols leaves SD whole
+size_t dct_pair_semi_deep_elems(size_t lines, size_t len);
 // deep inverse pre-passes (coefficient plane -> the same ten planes; R1 = c[8q], R2 = c[8q+4])
 int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                     const double* rot1, const double* rot2);

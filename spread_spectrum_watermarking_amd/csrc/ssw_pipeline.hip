@@ -205,6 +205,7 @@ size_t split_scratch_elems(size_t n, size_t w, size_t h) {
     size_t e = dct_pair_split_elems(n, w, h);
     if (dct_pair_can_deep_rows(w) || dct_pair_can_deep_inv_rows(w)) e = std::max(e, dct_pair_deep_elems(n * h, w));
     if (dct_pair_can_deep_cols(h)) e = std::max(e, dct_pair_deep_elems(n * w, h));
+    if (dct_pair_can_semi_deep_cols(h)) e = std::max(e, dct_pair_semi_deep_elems(n * w, h));
     return e;
 }
 
@@ -303,6 +304,33 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
         };
         const double f_odd = split ? pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h)
                                    : pair_gemm_flop(is_row, 2, 0, n, w, h);
+        // forward column passes of 8- but not 16-divisible length (1080 rows): D split and SS folded a third time in one
+        // pre-pass, SD stays one launch (H/16 is not whole)
+        const bool semi = split && !inverse && !is_row && dct_pair_can_semi_deep_cols(len) && w % 4 == 0;
+        if (semi) {
+            const void *e0 = nullptr, *e1 = nullptr, *h1 = nullptr;
+            SSW_TRY(get_basis(ctx, len / 4, false, true, 3, &e0));
+            SSW_TRY(get_basis(ctx, len / 4, false, true, 4, &e1));
+            SSW_TRY(get_basis(ctx, len / 2, false, true, 4, &h1));
+            const size_t p8 = lines * dct_pair_split_kpad(len);
+            double* m = sp + 6 * p8;
+            const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_prep, st, prep_bytes);
+                return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot, false);
+            }});
+            const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h);
+            const double f_all = f_main + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 2, 1, n, w, h);
+            ch.push_back({false, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_pass, st, f_all);
+                SSW_TRY(pair_gemm(st, true, is_row, false, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, nullptr, n, w, h, ep));
+                SSW_TRY(pair_gemm(st, true, is_row, false, 2, 1, m, m, h1, (const char*)h1 + (len / 8) * 64, dst, nullptr, n, w, h, ep));
+                SSW_TRY(pair_gemm(st, true, is_row, false, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, nullptr, n, w, h, ep));
+                StageTimer tm(ctx, st_main, st, f_main);
+                return pair_gemm(st, true, is_row, false, 3, 0, sp, sp + p8, sb0, sb1, dst, nullptr, n, w, h, ep);
+            }});
+            return SSW_OK;
+        }
         // the inverse the same way: c[8q] / c[8q+4] -> T2, the split c[4q+2] part + T2 -> T (the even half E), then the
         // split odd part + T -> the output; one pre-pass for all five launches
         const bool deep_inv = split && inverse && (is_row ? dct_pair_can_deep_inv_rows(len) : dct_pair_can_deep_cols(len) && w % 4 == 0);
