@@ -177,6 +177,9 @@ def attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff):
                 roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
                 roofline["traffic_source"] = f"profiles/{os.path.basename(path)} (collected at commit {pmc.get('commit', '?')})"
                 roofline["algorithmic_bytes_per_launch"] = pmc["kernels"][roofline["kernel"]].get("algorithmic_bytes_per_launch")
+                busy = pmc["kernels"][roofline["kernel"]].get("mfma_busy_over_active_cycles")
+                if busy is not None:     # cycles, not seconds: what the kernel does with the clock it gets
+                    roofline["mfma_busy_over_active_cycles"] = busy
                 return
         except (OSError, KeyError, ValueError):
             pass

@@ -34,6 +34,11 @@ def strip_tile(table):      # instance names carry the block-tile template argum
 
 
 fetch, write = strip_tile(load(f"{d}/{tag}_pmc_fetch.txt")), strip_tile(load(f"{d}/{tag}_pmc_write.txt"))
+try:        # MFMA pipe occupancy in cycles (independent of the clock the chip holds): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over
+            # GRBM_GUI_ACTIVE / 8 XCDs (rocprofv3 reports sums)
+    mfma = strip_tile(load(f"{d}/{tag}_pmc_mfma.txt"))
+except OSError:
+    mfma = {}
 lines_r, lines_c = chunk * H, chunk * W
 esz = 8
 K8 = lambda n: -(-(n // 8) // 16) * 16        # padded sum length of the n/8-wide operand planes
@@ -78,5 +83,8 @@ for inst, (label, alg, note) in names.items():
                              "launches_averaged": fetch[inst][1], "hbm_bytes_per_launch": hbm,
                              "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None,
                              "algorithmic_bytes_per_launch": int(alg), "traffic_over_algorithmic": round(hbm / alg, 2), "note": note}
+    m = mfma.get(inst, ({}, 0))[0]
+    if m.get("GRBM_GUI_ACTIVE") and m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        out["kernels"][label]["mfma_busy_over_active_cycles"] = round((m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (m["GRBM_GUI_ACTIVE"] / 8.0), 4)
 json.dump(out, sys.stdout, indent=1)
 print()
