@@ -21,6 +21,12 @@
 // forward interleaves (even, odd) frequencies; inverse forms acc1 +/- acc2 for the mirrored
 // positions; results are rounded once to f32 (then the reference's f32 scale factor, if any).
 //
+// r3: the odd halves are split once more (dct_pair_prep.hip, "Split odd half"): their launches feed this kernel two
+// DIFFERENT image operands (the rotated and folded AS | BD or AD | BS) against quarter-length cosine / sine bases and
+// the epilogues emit acc1 +/- acc2 (po.pm); a deep inverse adds EPI_INV_OT (the half-length even half E from its own
+// even half T2 and odd part).  Row passes store through buffer instructions with per-tile lane offsets (epilogue notes
+// below); deep transforms keep the plane between their passes class-major (dct_pair_common.hpp).
+//
 // Block: 256 threads = 4 waves as 2 x 2; block tile 128 lines x 64 pairs x 2 products; k-step 8;
 // per wave 16 MFMA 16x16 tiles = 128 accumulator registers; LDS 48 KB double-buffered (XOR-swizzled
 // 64-byte rows, conflict-free ds_read_b64 / ds_read2_b64), one barrier per k-step, 2 blocks per CU.

@@ -84,6 +84,7 @@ __global__ void make_rot_table_kernel(size_t n, double* out) {
     }
 }
 
+// first-level split through pair_rotate_kernel: any axis whose quarter length folds (rows and columns alike)
 bool dct_pair_can_split(size_t len, bool is_row) { (void)is_row; return len % 8 == 0 && len >= 128; }
 size_t dct_pair_split_kpad(size_t len) { return pair_kpad<double>(len / 4); }
 // doubles in the four split planes of a pass over n frames (the larger of the row and the column pass)

@@ -20,6 +20,11 @@
 //                                                                        v = 0 mod 8 -> SSS x even(W/4)
 // i.e. class = (mod, rem) and the basis row is v / mod.  Compact column of v = class offset + rank of v
 // inside its class (ascending v).
+// With the split odd half (f64, dct_pair_prep.hip) an odd class is two: class E holds v = 8i +/- 1 (row i of the
+// quarter-length cosine and sine bases; for 8i - 1 the output is the cosine part MINUS the sine part, so the gathered
+// sine row is negated -- exact), class O holds v = 8i + 5 and 8i + 3; in deep transforms the frequencies 2 mod 4 split
+// the same way one level down (v = 2 (8i +/- 1), 2 (8i + 5 | 3)).  PruneClass carries the second remainder and the row
+// offset: row = (v + radd) / mod.
 #include "dct_pair_common.hpp"
 
 namespace ssw {
