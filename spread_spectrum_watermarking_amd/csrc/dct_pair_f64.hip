@@ -73,11 +73,24 @@ typedef PairOutT<double> PairOut;
 // SUB only names the instance (launches that serve a deeper folding level show up separately in profiles).
 // BM: lines per block tile.  128 is the tile of every large launch; 64 serves launches whose 128-line grid
 // would leave the chip half empty (a single 4K frame: 17 x 15 = 255 tiles for 512 block slots).
+// One launch serves up to five "classes" -- GEMMs of the same kind (template instance) over the same lines with their own
+// operands, bases, pair counts, sum lengths and output maps: the tile columns of the classes lie side by side in the
+// launch's tile grid.  Batch launches carry one class; the five launches of a deep forward pass (two or three of an
+// inverse pass) of a single frame are merged into one, because each alone fills half of the chip's block slots for one
+// round (a 4K frame's class E: 34 x 8 = 272 blocks of 64 lines for 512 slots).
+struct PairClassArgs {
+    const double *x1, *x2, *y1, *y2;
+    unsigned NP, Kp, yrows, tiles_n;
+    unsigned c1, c2, cs, pm, np1, p2lo, bn32;
+};
+struct PairMulti {
+    PairClassArgs c[5];
+    unsigned n_classes, L, tiles_m, tiles_n_total;
+    PairOut po;                        // the fields the classes share; c1 .. bn32 are overwritten per class
+};
+
 template <bool COLS, int EPI, bool SAMEX, int SUB = 0, int BM = 128>
-__global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
-    const double* __restrict__ X1g, const double* __restrict__ X2g, const double* __restrict__ Y1g,
-    const double* __restrict__ Y2g, PairOut po, unsigned L /*lines*/, unsigned NP /*pairs*/,
-    unsigned Kp, unsigned yrows /*lines of the basis planes*/, unsigned tiles_m, unsigned tiles_n, Epilogue ep) {
+__global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml, Epilogue ep) {
     constexpr int NX = SAMEX ? 1 : 2;
     constexpr int BN = 64, XQ = BM / 64;                                   // XQ: X lines per staging thread
     // operand tiles [buffer][product][rows * 8]; a column pass reuses the region to transpose its results (epilogue)
@@ -93,7 +106,17 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 #endif
     SSW_TT(0);
     unsigned tm, tn;
-    tile_of_block(blockIdx.x, gridDim.x, tiles_m, tiles_n, tm, tn);
+    tile_of_block(blockIdx.x, gridDim.x, ml.tiles_m, ml.tiles_n_total, tm, tn);
+    unsigned cls = 0;
+    while (cls + 1 < ml.n_classes && tn >= ml.c[cls].tiles_n) { tn -= ml.c[cls].tiles_n; ++cls; }      // block-uniform
+    const PairClassArgs& ca = ml.c[cls];
+    const double* __restrict__ X1g = ca.x1;
+    const double* __restrict__ X2g = ca.x2;
+    const double* __restrict__ Y1g = ca.y1;
+    const double* __restrict__ Y2g = ca.y2;
+    const unsigned L = ml.L, NP = ca.NP, Kp = ca.Kp, yrows = ca.yrows;
+    PairOut po = ml.po;
+    po.c1 = ca.c1; po.c2 = ca.c2; po.cs = ca.cs; po.pm = ca.pm; po.np1 = ca.np1; po.p2lo = ca.p2lo; po.bn32 = ca.bn32;
     const unsigned m0 = tm * BM, p0 = tn * (po.bn32 ? 32u : (unsigned)BN);
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
@@ -818,115 +841,171 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(
 // x*, y*: k-blocked planes (y2 of kind 2 = y1 + 8 * len/4: the second row block of the same plane).
 // sub (forward only): the launch belongs to the transform of length len >> sub that a deeper folding level
 // applies to the even part (its frequencies are multiples of 2^sub of the full transform's).
-int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
-                             const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
-                             size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out, bool class_major) {
-    if (n_frames == 0) return SSW_OK;
+namespace {
+// what selects the template instance of a class: all classes of a launch must agree
+struct PairInstance {
+    int epi; bool samex; int subname;
+    bool operator==(const PairInstance& o) const { return epi == o.epi && samex == o.samex && subname == o.subname; }
+};
+
+// the per-class part of a launch: pair count, sum length, basis lines and the output map of (kind, sub)
+int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t len, bool class_major, bool with_sink, bool has_tmp_out,
+                    PairClassArgs& ca, PairInstance& inst) {
+    const int kind = d.kind, sub = d.sub;
+    // inverse: sub = 1 serves the deep inverse (the half-length transform E): kind 1 -> its even half T2, kinds 3 / 4 -> E
+    if (kind < 0 || kind > 4 || sub < 0 || sub > 8 || (sub > 0 && kind == 0) || (sub > 0 && inverse && (sub != 1 || kind == 2))) return SSW_ERR_BAD_ARG;
+    const bool split = kind == 3 || kind == 4;
+    if (inverse && sub == 1 && split && !has_tmp_out) return SSW_ERR_BAD_ARG;
+    const size_t leff = len >> sub;                           // length of the (sub-)transform this class serves
+    const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
+    if (split && leff % 8 != 0) return SSW_ERR_BAD_ARG;
+    ca.x1 = d.x1; ca.x2 = d.x2; ca.y1 = d.y1; ca.y2 = d.y2;
+    ca.NP = (unsigned)(kind == 0 ? leff / 2 : kind == 3 ? leff / 8 + 1 : kind == 4 ? leff / 8 : leff / 4);
+    ca.Kp = (unsigned)(split ? pair_kpad<double>(leff / 4) : kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
+    ca.yrows = kind == 2 ? 2 * ca.NP : ca.NP;                 // lines of the basis plane(s)
+    ca.tiles_n = (ca.NP + 63) / 64;
+    ca.c1 = 0; ca.c2 = 1; ca.cs = 2; ca.pm = 0; ca.np1 = 0xFFFFFFFFu; ca.p2lo = 0; ca.bn32 = 0;
+    if (kind == 1) { ca.c1 = 0; ca.c2 = 2 * fs; ca.cs = 4 * fs; }
+    if (kind == 2) { ca.c1 = fs; ca.c2 = fs + 2 * fs * ca.NP; ca.cs = 2 * fs; }
+    if (inverse && kind == 2) { ca.c1 = 0; ca.c2 = (unsigned)(leff / 4); ca.cs = 1; }      // positions pair, pair + n/4 of the odd part
+    if (split) {
+        // odd frequency u = 2k+1 of the (sub-)transform; class E (kind 3) pair i: k = 4i (+), 4i-1 (-); class O: k = 4i+2 (+), 4i+1 (-)
+        ca.pm = 1;
+        if (!inverse) {
+            ca.c1 = (kind == 3 ? 1u : 5u) * fs; ca.c2 = kind == 3 ? 0u - fs : 3u * fs; ca.cs = 8 * fs;
+            if (kind == 3) { ca.np1 = (unsigned)(leff / 8); ca.p2lo = 1; }
+        } else {
+            ca.c1 = kind == 3 ? 0u : 2u; ca.c2 = kind == 3 ? 0u - 1u : 1u; ca.cs = 4;             // positions of the odd part
+        }
+    }
+    if (class_major) {
+        // forward row pass of a deep transform: every class writes its frequencies side by side (ForwardClassLayout,
+        // dct_pair_common.hpp) instead of 4-byte pieces 16 / 32 bytes apart -- the column pre-pass puts the columns back;
+        // inverse: the split classes write (and read E) at one pair of residues mod 4 (po.cm, inverse_class_pos), the
+        // quarter-length even half T2 (kind 1) keeps the natural order
+        if (!is_row || !((kind == 1 && sub == 1) || split) || sub > 1) return SSW_ERR_BAD_ARG;
+        if (!inverse) {
+            const ForwardClassLayout fl{(unsigned)len};
+            ca.cs = 1;
+            if (kind == 1) { ca.c1 = fl.base(ForwardClassLayout::R1); ca.c2 = fl.base(ForwardClassLayout::R2); }
+            else if (kind == 3) { ca.c1 = fl.base(sub ? ForwardClassLayout::E2P : ForwardClassLayout::EP); ca.c2 = fl.base(sub ? ForwardClassLayout::E2M : ForwardClassLayout::EM) - 1; }
+            else { ca.c1 = fl.base(sub ? ForwardClassLayout::O2P : ForwardClassLayout::OP); ca.c2 = fl.base(sub ? ForwardClassLayout::O2M : ForwardClassLayout::OM); }
+        }
+    }
+    // template instance
+    if (!inverse) {
+        if (kind == 0) inst = {is_row ? EPI_FWD_ADJ : EPI_FWD, false, 0};
+        else if (kind == 1) inst = {EPI_FWD, false, sub ? 1 : 0};
+        else if (kind == 2) inst = {EPI_FWD, true, sub ? 1 : 0};
+        else inst = {EPI_FWD, false, (is_row && kind == 3 && sub == 0) ? 4 : 3};
+    } else {
+        if (kind == 0) inst = {EPI_INV, false, 0};
+        else if (kind == 1) inst = {EPI_INV_E, false, sub ? 1 : 0};
+        else if (with_sink) inst = {EPI_INV_O_RGB, !split, 0};
+        else if (split && sub == 1) inst = {EPI_INV_OT, false, 1};
+        else inst = {EPI_INV_O, !split, 0};
+    }
+    return SSW_OK;
+}
+}  // namespace
+
+// One launch over `n_classes` classes (see PairMulti).  A class is described like the single launches:
+//   kind 0  one folding level (forward: interleave even/odd; inverse: mirror)            pairs = len/2, K = len/2
+//        1  level 2, even half: X = (SS, SD) | (EE, EO), Y = half bases of len/2          pairs = len/4, K = len/4
+//        2  level 2, odd half:  X = D | O (shared), Y = the two halves of the odd basis   pairs = len/4, K = len/2
+//    3 / 4  the odd half split once more (dct_pair_prep.hip "Split odd half"): X = (AS, BD) | (AD, BS), Y = (cosine,
+//           sine) rows 2i | 2i+1 of the quarter-length bases; outputs acc1 +/- acc2          pairs = len/8 + 1 | len/8, K = len/8
+//   sub: the class belongs to the transform of length len >> sub that a deeper folding level applies to the even part.
+int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, int n_classes, const PairClassDesc* desc, float* out,
+                                   double* tmp, size_t n_frames, size_t w, size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out,
+                                   bool class_major) {
+    if (n_frames == 0 || n_classes == 0) return SSW_OK;
+    if (n_classes < 0 || n_classes > 5 || !desc) return SSW_ERR_BAD_ARG;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t lines = is_row ? n_frames * h : n_frames * w;
     const size_t len = is_row ? w : h;
     if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned L = (unsigned)lines;
-    // inverse: sub = 1 serves the deep inverse (the half-length transform E): kind 1 -> its even half T2, kinds 3 / 4 -> E
-    if (sub < 0 || sub > 8 || (sub > 0 && kind == 0) || (sub > 0 && inverse && (sub != 1 || kind == 2))) return SSW_ERR_BAD_ARG;
-    if (inverse && sub == 1 && (kind == 3 || kind == 4) && !tmp_out) return SSW_ERR_BAD_ARG;
-    const size_t leff = len >> sub;                           // length of the (sub-)transform this launch serves
-    const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
-    const bool split = kind == 3 || kind == 4;
-    if (split && leff % 8 != 0) return SSW_ERR_BAD_ARG;
-    const unsigned NP = (unsigned)(kind == 0 ? leff / 2 : kind == 3 ? leff / 8 + 1 : kind == 4 ? leff / 8 : leff / 4);
-    const unsigned Kp = (unsigned)(split ? pair_kpad<double>(leff / 4) : kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
-    const unsigned BN = 64;
-    unsigned tiles_n = (NP + BN - 1) / BN;
+    const bool with_sink = sink && sink->rgb;
+    PairMulti ml;
+    PairInstance inst{0, false, 0};
+    unsigned tiles_n = 0, leff0 = 0;
+    for (int c = 0; c < n_classes; ++c) {
+        PairInstance ic{0, false, 0};
+        SSW_TRY(pair_class_args(desc[c], is_row, inverse, len, class_major, with_sink, tmp_out != nullptr, ml.c[c], ic));
+        if (c == 0) { inst = ic; leff0 = (unsigned)(len >> desc[c].sub); }
+        else if (!(ic == inst) && !(ic.epi == inst.epi && ic.samex == inst.samex && n_classes > 1)) return SSW_ERR_BAD_ARG;
+        if (inverse && (unsigned)(len >> desc[c].sub) != leff0) return SSW_ERR_BAD_ARG;      // po.n is shared
+        if ((unsigned long long)ml.c[c].Kp * L * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
+        tiles_n += ml.c[c].tiles_n;
+    }
+    if (n_classes > 1) inst.subname = inverse ? inst.subname : 3;
     // 64-line tiles when 128-line ones would not fill the 512 block slots of the chip (2 per CU)
     const bool small = (unsigned long long)((L + 127) / 128) * tiles_n < 448;
     const unsigned BM = small ? 64 : 128;
     const unsigned tiles_m = (L + BM - 1) / BM;
-    // ... and 32-pair tiles when that spreads such a launch more evenly over the 256 CUs (all its blocks are resident
-    // at once, so a launch takes as long as the fullest CU): balance = blocks / (256 * ceil(blocks / 256)); the smaller
-    // tiles reuse their basis fragments less, hence the 8 % handicap
-    bool bn32 = false;
-    if (small) {
+    // ... and 32-pair tiles when that spreads such a (single-class) launch more evenly over the 256 CUs (all its blocks are
+    // resident at once, so a launch takes as long as the fullest CU): balance = blocks / (256 * ceil(blocks / 256)); the
+    // smaller tiles reuse their basis fragments less, hence the 8 % handicap
+    if (small && n_classes == 1) {
         static const int force = [] { const char* e = std::getenv("SSW_BN32"); return e ? std::atoi(e) : -1; }();
         auto balance = [](unsigned long long n) { return (double)n / (256.0 * (double)((n + 255) / 256)); };
-        const unsigned tn32 = (NP + 31) / 32;
-        bn32 = force >= 0 ? force != 0 : 0.92 * balance((unsigned long long)tiles_m * tn32) > balance((unsigned long long)tiles_m * tiles_n);
-        if (bn32) tiles_n = tn32;
+        const unsigned tn32 = (ml.c[0].NP + 31) / 32;
+        const bool bn32 = force >= 0 ? force != 0 : 0.92 * balance((unsigned long long)tiles_m * tn32) > balance((unsigned long long)tiles_m * tiles_n);
+        if (bn32) { ml.c[0].tiles_n = tiles_n = tn32; ml.c[0].bn32 = 1; }
     }
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-    PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)(inverse ? leff : len), 0, 1, 2};
+    ml.n_classes = (unsigned)n_classes; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
+    PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)(inverse ? leff0 : len), 0, 1, 2};
     po.tmp_out = tmp_out;
-    if (kind == 1) { po.c1 = 0; po.c2 = 2 * fs; po.cs = 4 * fs; }
-    if (kind == 2) { po.c1 = fs; po.c2 = fs + 2 * fs * NP; po.cs = 2 * fs; }
-    if (inverse && kind == 2) { po.c1 = 0; po.c2 = (unsigned)(leff / 4); po.cs = 1; }      // positions pair, pair + n/4 of the odd part
-    if (split) {
-        // odd frequency u = 2k+1 of the (sub-)transform; class E (kind 3) pair i: k = 4i (+), 4i-1 (-); class O: k = 4i+2 (+), 4i+1 (-)
-        po.pm = 1;
-        if (!inverse) {
-            po.c1 = (kind == 3 ? 1u : 5u) * fs; po.c2 = kind == 3 ? 0u - fs : 3u * fs; po.cs = 8 * fs;
-            if (kind == 3) { po.np1 = (unsigned)(leff / 8); po.p2lo = 1; }
-        } else {
-            po.c1 = kind == 3 ? 0u : 2u; po.c2 = kind == 3 ? 0u - 1u : 1u; po.cs = 4;             // positions of the odd part
-        }
-    }
-    if (class_major) {
-        // forward row pass of a deep transform: every launch writes its frequencies side by side (ForwardClassLayout,
-        // dct_pair_common.hpp) instead of 4-byte pieces 16 / 32 bytes apart -- the column pre-pass puts the columns back
-        if (!is_row || !((kind == 1 && sub == 1) || split) || sub > 1) return SSW_ERR_BAD_ARG;
-        if (inverse) {
-            // the split launches write (and read E) at one pair of residues mod 4: inverse_class_pos; the quarter-length
-            // even half T2 (kind 1) keeps the natural order
-            if (split) po.cm = 1;
-        }
-        const ForwardClassLayout fl{(unsigned)len};
-        if (!inverse) po.cs = 1;
-        if (inverse) { }
-        else if (kind == 1) { po.c1 = fl.base(ForwardClassLayout::R1); po.c2 = fl.base(ForwardClassLayout::R2); }
-        else if (kind == 3) { po.c1 = fl.base(sub ? ForwardClassLayout::E2P : ForwardClassLayout::EP); po.c2 = fl.base(sub ? ForwardClassLayout::E2M : ForwardClassLayout::EM) - 1; }
-        else { po.c1 = fl.base(sub ? ForwardClassLayout::O2P : ForwardClassLayout::OP); po.c2 = fl.base(sub ? ForwardClassLayout::O2M : ForwardClassLayout::OM); }
-    }
-    const unsigned yrows = kind == 2 ? 2 * NP : NP;          // lines of the basis plane(s)
-    po.bn32 = bn32 ? 1u : 0u;
+    if (class_major && inverse && (desc[0].kind == 3 || desc[0].kind == 4)) po.cm = 1;
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16)) && (!tmp_out || al(tmp_out, 16))) ? 1u : 0u;
-    if (sink && sink->rgb && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;
-    if ((unsigned long long)Kp * L * 8 > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;   // scalar k-block offsets are 32-bit
-#define SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, SUBV, BMV) \
-        pair_gemm_f64_kernel<COLS, EPI, SAMEX, SUBV, BMV><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, yrows, tiles_m, tiles_n, ep)
-#define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) do { \
-        if (small) { if (sub == 0) SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, 0, 64); else SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, 1, 64); } \
-        else       { if (sub == 0) SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, 0, 128); else SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, 1, 128); } \
-    } while (0)
-    if (!inverse) {
-        if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD_ADJ, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
-        else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, false); else SSW_LAUNCH_PAIR(true, EPI_FWD, false); }
-        else if (kind == 2) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_FWD, true); else SSW_LAUNCH_PAIR(true, EPI_FWD, true); }
-        else if (is_row && kind == 3 && sub == 0) {
-            // class E of the full-length split odd half: the largest single launch of a transform, under its own
-            // instance name (SUB = 4) so that profiles and bench.py's roofline block refer to the same launches
-            if (small) SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 4, 64); else SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 4, 128);
-        }
-        else {
-            if (small) { if (is_row) SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 3, 64); else SSW_LAUNCH_PAIR_BM(true, EPI_FWD, false, 3, 64); }
-            else       { if (is_row) SSW_LAUNCH_PAIR_BM(false, EPI_FWD, false, 3, 128); else SSW_LAUNCH_PAIR_BM(true, EPI_FWD, false, 3, 128); }
-        }
-    } else {
-        if (kind == 0) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV, false); else SSW_LAUNCH_PAIR(true, EPI_INV, false); }
-        else if (kind == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_E, false); else SSW_LAUNCH_PAIR(true, EPI_INV_E, false); }
-        else if (sink && sink->rgb) {      // last pass of Writer::result: colour conversion in the epilogue
-            if (is_row || sub != 0) return SSW_ERR_BAD_ARG;
-            po.iq_i = sink->iq_i; po.iq_q = sink->iq_q; po.rgb = sink->rgb; po.rgb_u8 = sink->u8 ? 1u : 0u;
-            if (split) SSW_LAUNCH_PAIR(true, EPI_INV_O_RGB, false); else SSW_LAUNCH_PAIR(true, EPI_INV_O_RGB, true);
-        }
-        else if (split && sub == 1) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_OT, false); else SSW_LAUNCH_PAIR(true, EPI_INV_OT, false); }
-        else if (split) { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, false); else SSW_LAUNCH_PAIR(true, EPI_INV_O, false); }
-        else { if (is_row) SSW_LAUNCH_PAIR(false, EPI_INV_O, true); else SSW_LAUNCH_PAIR(true, EPI_INV_O, true); }
+    if (with_sink && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;
+    if (with_sink) {
+        if (is_row) return SSW_ERR_BAD_ARG;
+        po.iq_i = sink->iq_i; po.iq_q = sink->iq_q; po.rgb = sink->rgb; po.rgb_u8 = sink->u8 ? 1u : 0u;
     }
+    ml.po = po;
+#define SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, SUBV, BMV) \
+        pair_gemm_f64_kernel<COLS, EPI, SAMEX, SUBV, BMV><<<(unsigned)nblk, PT, 0, st>>>(ml, ep)
+#define SSW_LAUNCH_PAIR_SUB(COLS, EPI, SAMEX, SUBV) do { if (small) SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, SUBV, 64); else SSW_LAUNCH_PAIR_BM(COLS, EPI, SAMEX, SUBV, 128); } while (0)
+#define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) do { if (inst.subname == 0) SSW_LAUNCH_PAIR_SUB(COLS, EPI, SAMEX, 0); else SSW_LAUNCH_PAIR_SUB(COLS, EPI, SAMEX, 1); } while (0)
+#define SSW_LAUNCH_ROWCOL(EPI, SAMEX) do { if (is_row) SSW_LAUNCH_PAIR(false, EPI, SAMEX); else SSW_LAUNCH_PAIR(true, EPI, SAMEX); } while (0)
+    switch (inst.epi) {
+    case EPI_FWD_ADJ: SSW_LAUNCH_PAIR(false, EPI_FWD_ADJ, false); break;
+    case EPI_FWD:
+        if (inst.subname == 4) SSW_LAUNCH_PAIR_SUB(false, EPI_FWD, false, 4);
+        else if (inst.subname == 3) { if (is_row) SSW_LAUNCH_PAIR_SUB(false, EPI_FWD, false, 3); else SSW_LAUNCH_PAIR_SUB(true, EPI_FWD, false, 3); }
+        else if (inst.samex) SSW_LAUNCH_ROWCOL(EPI_FWD, true);
+        else SSW_LAUNCH_ROWCOL(EPI_FWD, false);
+        break;
+    case EPI_INV: SSW_LAUNCH_ROWCOL(EPI_INV, false); break;
+    case EPI_INV_E: SSW_LAUNCH_ROWCOL(EPI_INV_E, false); break;
+    case EPI_INV_OT: if (is_row) SSW_LAUNCH_PAIR_SUB(false, EPI_INV_OT, false, 1); else SSW_LAUNCH_PAIR_SUB(true, EPI_INV_OT, false, 1); break;
+    case EPI_INV_O_RGB:
+        if (inst.samex) SSW_LAUNCH_PAIR_SUB(true, EPI_INV_O_RGB, true, 0); else SSW_LAUNCH_PAIR_SUB(true, EPI_INV_O_RGB, false, 0);
+        break;
+    case EPI_INV_O:
+        if (inst.samex) SSW_LAUNCH_ROWCOL(EPI_INV_O, true); else SSW_LAUNCH_ROWCOL(EPI_INV_O, false);
+        break;
+    default: return SSW_ERR_BAD_ARG;
+    }
+#undef SSW_LAUNCH_ROWCOL
 #undef SSW_LAUNCH_PAIR
+#undef SSW_LAUNCH_PAIR_SUB
 #undef SSW_LAUNCH_PAIR_BM
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
+}
+
+// One class per launch (the batch paths).
+int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
+                             const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
+                             size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out, bool class_major) {
+    const PairClassDesc d{kind, sub, x1, x2, y1, y2};
+    return launch_dct_pair_gemm_multi_f64(st, is_row, inverse, 1, &d, out, tmp, n_frames, w, h, ep, sink, tmp_out, class_major);
 }
 
 // Forward row pass restricted to a gathered set of frequencies (pruned derived transform, prune.hip): one
@@ -942,9 +1021,12 @@ int launch_dct_pair_gemm_rows_subset_f64(hipStream_t st, const double* x, const 
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     if ((unsigned long long)Kp * L * sizeof(double) > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
-    PairOut po{out, nullptr, out_stride, 0, 0, off, off + NP, 1};
+    PairMulti ml;
+    ml.c[0] = PairClassArgs{x, x, y, y + (size_t)NP * 8, NP, Kp, cap, tiles_n, off, off + NP, 1, 0, 0xFFFFFFFFu, 0, 0};
+    ml.n_classes = 1; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
+    ml.po = PairOut{out, nullptr, out_stride, 0, 0, off, off + NP, 1};
     const Epilogue ep{1.f, 1.f};
-    pair_gemm_f64_kernel<false, EPI_FWD, true, 2><<<(unsigned)nblk, PT, 0, st>>>(x, x, y, y + (size_t)NP * 8, po, L, NP, Kp, cap, tiles_m, tiles_n, ep);
+    pair_gemm_f64_kernel<false, EPI_FWD, true, 2><<<(unsigned)nblk, PT, 0, st>>>(ml, ep);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
@@ -960,10 +1042,12 @@ int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1,
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     if ((unsigned long long)Kp * L * sizeof(double) > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
-    PairOut po{out, nullptr, out_stride, 0, 0, off, 0, 1};
-    po.pm = 2;
+    PairMulti ml;
+    ml.c[0] = PairClassArgs{x1, x2, y1, y2, NP, Kp, cap, tiles_n, off, 0, 1, 2, 0xFFFFFFFFu, 0, 0};
+    ml.n_classes = 1; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
+    ml.po = PairOut{out, nullptr, out_stride, 0, 0, off, 0, 1};
     const Epilogue ep{1.f, 1.f};
-    pair_gemm_f64_kernel<false, EPI_FWD, false, 3><<<(unsigned)nblk, PT, 0, st>>>(x1, x2, y1, y2, po, L, NP, Kp, cap, tiles_m, tiles_n, ep);
+    pair_gemm_f64_kernel<false, EPI_FWD, false, 3><<<(unsigned)nblk, PT, 0, st>>>(ml, ep);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -118,6 +118,11 @@ int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep, const RgbSink* sink = nullptr, double* tmp_out = nullptr, bool class_major = false);
+// several classes (same lines, same template instance) in one launch: single frames, whose launches are too small alone
+struct PairClassDesc { int kind, sub; const double *x1, *x2, *y1, *y2; };
+int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, int n_classes, const PairClassDesc* desc, float* out,
+                                   double* tmp, size_t n_frames, size_t w, size_t h, Epilogue ep, const RgbSink* sink = nullptr,
+                                   double* tmp_out = nullptr, bool class_major = false);
 int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const float* x1, const float* x2,
                              const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep, const RgbSink* sink = nullptr);

@@ -281,9 +281,21 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h);
             const double f_all = f_main + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) +
                                  pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
+            // a single frame's launches are too small alone (class E of a 4K frame: 272 blocks for 512 slots): one launch
+            // over the five classes instead
+            const bool merge = lines <= 8192;
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 const bool rcm = cm && is_row;
+                if (merge) {
+                    const PairClassDesc d[5] = {{1, 1, sp + 4 * p8, sp + 5 * p8, (const double*)e0, (const double*)e1},
+                                                {3, 1, q, q + p16, (const double*)t0, (const double*)t1},
+                                                {4, 1, q + 2 * p16, q + 3 * p16, (const double*)t2, (const double*)t3},
+                                                {4, 0, sp + 2 * p8, sp + 3 * p8, (const double*)sb2_, (const double*)sb3},
+                                                {3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1}};
+                    StageTimer tm(ctx, st_main, st, f_all);
+                    return launch_dct_pair_gemm_multi_f64(st, is_row, false, 5, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
+                }
                 SSW_TRY(pair_gemm(st, true, is_row, false, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
                 SSW_TRY(pair_gemm(st, true, is_row, false, 3, 1, q, q + p16, t0, t1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
                 SSW_TRY(pair_gemm(st, true, is_row, false, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
@@ -321,8 +333,17 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             }});
             const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h);
             const double f_all = f_main + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 2, 1, n, w, h);
+            const bool merge = lines <= 8192;
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
+                if (merge) {      // the SD launch shares its image operand between its two products: another template instance
+                    SSW_TRY(pair_gemm(st, true, is_row, false, 2, 1, m, m, h1, (const char*)h1 + (len / 8) * 64, dst, nullptr, n, w, h, ep));
+                    const PairClassDesc d[3] = {{1, 1, sp + 4 * p8, sp + 5 * p8, (const double*)e0, (const double*)e1},
+                                                {4, 0, sp + 2 * p8, sp + 3 * p8, (const double*)sb2_, (const double*)sb3},
+                                                {3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1}};
+                    StageTimer tm(ctx, st_main, st, f_all - pair_gemm_flop(is_row, 2, 1, n, w, h));
+                    return launch_dct_pair_gemm_multi_f64(st, is_row, false, 3, d, dst, nullptr, n, w, h, ep);
+                }
                 SSW_TRY(pair_gemm(st, true, is_row, false, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, nullptr, n, w, h, ep));
                 SSW_TRY(pair_gemm(st, true, is_row, false, 2, 1, m, m, h1, (const char*)h1 + (len / 8) * 64, dst, nullptr, n, w, h, ep));
                 SSW_TRY(pair_gemm(st, true, is_row, false, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, nullptr, n, w, h, ep));
@@ -368,6 +389,14 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
+                if (lines <= 8192) {          // single frames: the two classes of each dependent stage in one launch
+                    const PairClassDesc d1[2] = {{3, 1, q, q + p16, (const double*)t0, (const double*)t1},
+                                                 {4, 1, q + 2 * p16, q + 3 * p16, (const double*)t2, (const double*)t3}};
+                    SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d1, dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
+                    const PairClassDesc d0[2] = {{3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1},
+                                                 {4, 0, sp + 2 * p8, sp + 3 * p8, (const double*)sb2_, (const double*)sb3}};
+                    return launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d0, dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm);
+                }
                 SSW_TRY(pair_gemm(st, true, is_row, true, 3, 1, q, q + p16, t0, t1, dst, T2, n, w, h, ep, nullptr, TE, rcm));
                 SSW_TRY(pair_gemm(st, true, is_row, true, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, T2, n, w, h, ep, nullptr, TE, rcm));
                 SSW_TRY(pair_gemm(st, true, is_row, true, 3, 0, sp, sp + p8, sb0, sb1, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm));
