@@ -283,7 +283,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                  pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             // a single frame's launches are too small alone (class E of a 4K frame: 272 blocks for 512 slots): one launch
             // over the five classes instead
-            const bool merge = lines <= 8192;
+            const bool merge = lines <= 8192;             // (merging the batch launches as well: measured, no difference)
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 const bool rcm = cm && is_row;
