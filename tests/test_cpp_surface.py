@@ -22,6 +22,16 @@ def build(tmpdir):
     return exe
 
 
+def test_class_major_layout_maps_on_the_host(tmp_path):
+    """csrc/dct_pair_common.hpp's column orders of the intermediate planes (deep transforms): bijections, inverses of each
+    other, and consistent with the output maps of the GEMM launch classes -- compiled for the host, no device code runs."""
+    exe = os.path.join(str(tmp_path), "class_layout_test")
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "cpp", "class_layout_test.cpp"),
+                    "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert out.strip() == "ok"
+
+
 def test_cpp_wrappers_compile_and_link(tmp_path):
     exe = build(tmp_path)
     assert os.path.exists(exe)
