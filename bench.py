@@ -741,7 +741,7 @@ def main():
                                    f" {W}x{H} f32 frames, {K}-coeff mark, {flow}; {workload_tag}",
                        "frames_per_gpu": B, "total_frames": total_frames, "width": W, "height": H, "k": K, "alpha": 0.1,
                        "method": "Option2", "ordering": "Energy", "chunk_frames": chunk_eff,
-                       "dct_folding_level": fold_level,
+                       "dct_folding_level": fold_level, "dct_odd_split": "on (f64: odd halves as rotated quarter-length cosine + sine pairs, deep pre-passes; DESIGN.md 4.1)" if args.precision == "f64" else "off (f32 twin: exact-operand folding)",
                        "overlap": "one chunk at a time on one stream" if args.no_overlap else "two chunks in flight on two streams",
                        "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
