@@ -228,7 +228,7 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
     if (ov) ctx->overlap = std::atoi(ov) != 0;
     const char* pr = std::getenv("SSW_PRUNE");
     if (pr) ctx->prune = std::atoi(pr) != 0;
-    const char* sp = std::getenv("SSW_SPLIT");
+    const char* sp = std::getenv("SSW_ODD_SPLIT");
     if (sp) ctx->split = std::atoi(sp) != 0;
     *out = ctx;
     return SSW_OK;
