@@ -853,9 +853,9 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
                     PairClassArgs& ca, PairInstance& inst) {
     const int kind = d.kind, sub = d.sub;
     // inverse: sub = 1 serves the deep inverse (the half-length transform E): kind 1 -> its even half T2, kinds 3 / 4 -> E
-    if (kind < 0 || kind > 4 || sub < 0 || sub > 8 || (sub > 0 && kind == 0) || (sub > 0 && inverse && (sub != 1 || kind == 2))) return SSW_ERR_BAD_ARG;
+    if (kind < 0 || kind > 4 || sub < 0 || sub > 8 || (sub > 0 && kind == 0) || (sub > 0 && inverse && sub != 1)) return SSW_ERR_BAD_ARG;
     const bool split = kind == 3 || kind == 4;
-    if (inverse && sub == 1 && split && !has_tmp_out) return SSW_ERR_BAD_ARG;
+    if (inverse && sub == 1 && kind != 1 && !has_tmp_out) return SSW_ERR_BAD_ARG;      // the odd part of E needs somewhere to put E
     const size_t leff = len >> sub;                           // length of the (sub-)transform this class serves
     const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
     if (split && leff % 8 != 0) return SSW_ERR_BAD_ARG;
@@ -902,7 +902,7 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
         if (kind == 0) inst = {EPI_INV, false, 0};
         else if (kind == 1) inst = {EPI_INV_E, false, sub ? 1 : 0};
         else if (with_sink) inst = {EPI_INV_O_RGB, !split, 0};
-        else if (split && sub == 1) inst = {EPI_INV_OT, false, 1};
+        else if (sub == 1) inst = {EPI_INV_OT, !split, 1};          // kinds 2 (semi-deep: one shared operand), 3, 4
         else inst = {EPI_INV_O, !split, 0};
     }
     return SSW_OK;
@@ -983,7 +983,11 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
         break;
     case EPI_INV: SSW_LAUNCH_ROWCOL(EPI_INV, false); break;
     case EPI_INV_E: SSW_LAUNCH_ROWCOL(EPI_INV_E, false); break;
-    case EPI_INV_OT: if (is_row) SSW_LAUNCH_PAIR_SUB(false, EPI_INV_OT, false, 1); else SSW_LAUNCH_PAIR_SUB(true, EPI_INV_OT, false, 1); break;
+    case EPI_INV_OT:
+        if (inst.samex) { if (is_row) return SSW_ERR_BAD_ARG; SSW_LAUNCH_PAIR_SUB(true, EPI_INV_OT, true, 1); }
+        else if (is_row) SSW_LAUNCH_PAIR_SUB(false, EPI_INV_OT, false, 1);
+        else SSW_LAUNCH_PAIR_SUB(true, EPI_INV_OT, false, 1);
+        break;
     case EPI_INV_O_RGB:
         if (inst.samex) SSW_LAUNCH_PAIR_SUB(true, EPI_INV_O_RGB, true, 0); else SSW_LAUNCH_PAIR_SUB(true, EPI_INV_O_RGB, false, 0);
         break;

@@ -1014,13 +1014,15 @@ __global__ __launch_bounds__(256) void pair_prep16_inv_rows_kernel(const float* 
 // t) serves the D-split pair (e = 8G + t, H/8 - 1 - e), the level-2 unit e' = 8G + t and the level-3 pairs q = 16G + 2t,
 // +1 -- 16 coefficients in (coalesced across the columns), 16 doubles out, transposed through LDS so that every store
 // is a whole 64-byte piece of one line where the positions allow it.
-template <typename T>
+// SPLIT_MID = false ("semi-deep", H % 8 == 0 but not % 16): c[4q+2] stays one DCT-IV input plane (`dp.as2`, kpad(H/2)
+// wide) and the units run to ceil(H/16); the middle unit is its own mirror and stores its values twice.
+template <typename T, bool SPLIT_MID>
 __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                                   const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                                   unsigned W, unsigned H, unsigned K8, unsigned K16,
                                                                   unsigned n_frames, unsigned groups, unsigned tiles_c, unsigned class_major) {
     __shared__ T s[16][32][9];
-    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = H / 16;
+    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = SPLIT_MID ? H / 16 : (H / 8 + 1) / 2;      // H16: units
     const unsigned z = blockIdx.x / (groups * tiles_c);
     const unsigned tt = blockIdx.x % (groups * tiles_c);
     const unsigned G = tt % groups, c0 = (tt / groups) * 32;
@@ -1044,9 +1046,11 @@ __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* 
         split_one<T>(m0v, m1, m2, m3, rot1, em, Hq, o[4], o[5], o[6], o[7]);
         // c[4q+2]: q = e, H/8-1-e, H/8+e, H/4-1-e
         const T q0 = ld(4 * ec + 2), q1 = ld(Hh - 2 - 4 * ec), q2 = ld(Hh + 4 * ec + 2), q3 = ld(H - 2 - 4 * ec);
-        split_one<T>(q0, q1, q2, q3, rot2, ec, H8, o[8], o[9], o[10], o[11]);
-        // c[8q], c[8q+4] for q = 2e, 2e+1 (< H/8)
-        o[12] = ld(16 * ec); o[13] = ld(16 * ec + 8); o[14] = ld(16 * ec + 4); o[15] = ld(16 * ec + 12);
+        if (SPLIT_MID) split_one<T>(q0, q1, q2, q3, rot2, ec, H8, o[8], o[9], o[10], o[11]);
+        else { o[8] = q0; o[9] = q1; o[10] = q2; o[11] = q3; }          // c[4q+2] itself at q = e, H/8-1-e, H/8+e, H/4-1-e
+        // c[8q], c[8q+4] for q = 2e, 2e+1 (< H/8; with an odd H/8 the last unit has one)
+        const bool q2ok = 2 * ec + 1 < H8;
+        o[12] = ld(16 * ec); o[13] = q2ok ? ld(16 * ec + 8) : (T)0; o[14] = ld(16 * ec + 4); o[15] = q2ok ? ld(16 * ec + 12) : (T)0;
     }
 #pragma unroll
     for (int v = 0; v < 16; ++v) s[v][cl][t] = ok ? o[v] : (T)0;
@@ -1076,10 +1080,15 @@ __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* 
             }
         }
     }
-    {   // AS2 .. BS2 at e' = 8G + 4 (h / 4) .. +3: zeros beyond H/16 (the planes are K16 wide)
+    if (SPLIT_MID) {   // AS2 .. BS2 at e' = 8G + 4 (h / 4) .. +3: zeros beyond H/16 (the planes are K16 wide)
         T* plane = P16[h & 3];
         const unsigned k0 = 8 * G + 4 * (h >> 2), j0 = 4 * (h >> 2);
         if (k0 < K16) *reinterpret_cast<vec4_t<T>*>(plane + blk_index<T>(line, k0, lines)) = (vec4_t<T>){s[8 + (h & 3)][cl][j0], s[8 + (h & 3)][cl][j0 + 1], s[8 + (h & 3)][cl][j0 + 2], s[8 + (h & 3)][cl][j0 + 3]};
+    } else if (h < 4) {   // the c[4q+2] plane: thread h takes the run of value type 8 + h (ascending for h = 0, 2; mirrored for 1, 3)
+        T* plane = P16[0];
+        const unsigned start = h == 0 ? 8 * G : h == 2 ? H8 + 8 * G : (h == 1 ? H8 : Hq) - 8 * G - nv;
+        for (unsigned j = 0; j < nv; ++j) plane[blk_index<T>(line, start + j, lines)] = s[8 + h][cl][(h & 1) ? nv - 1 - j : j];
+        if (G == 0 && h == 0) for (unsigned k = Hq; k < K16; ++k) plane[blk_index<T>(line, k, lines)] = (T)0;      // K16: kpad(H/2) here
     }
     {   // R1 = c[8q], R2 = c[8q+4] at q = 16G + 2h, +1 (units beyond H/16 wrote zeros: padding up to K8 where 16G < K8)
         const unsigned q0 = 16 * G + 2 * h;
@@ -1344,13 +1353,24 @@ int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_fr
 int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                     const double* rot1, const double* rot2, bool class_major) {
     if (n_frames == 0) return SSW_OK;
-    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !dct_pair_can_deep_cols(h)) return SSW_ERR_BAD_DIMS;
-    const unsigned K8 = (unsigned)dct_pair_split_kpad(h), K16 = (unsigned)dct_pair_split_kpad(h / 2);
-    const unsigned groups = K16 / 8, tiles_c = (unsigned)((w + 31) / 32);      // K16 % 16 == 0: the groups cover the padding too
+    const bool semi = dct_pair_can_semi_deep_cols(h);
+    if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !(dct_pair_can_deep_cols(h) || semi)) return SSW_ERR_BAD_DIMS;
+    if (semi && class_major) return SSW_ERR_BAD_ARG;
+    const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
+    const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the c[4q+2] plane
+    // groups of 8 units: K16 / 8 covers the padding of the n/16-wide planes; semi: the units (and the R planes' padding up to K8)
+    const unsigned groups = semi ? (unsigned)((K8 / 2 + 7) / 8) : K16 / 8, tiles_c = (unsigned)((w + 31) / 32);
     const unsigned long long nblk = (unsigned long long)groups * tiles_c * n_frames;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-    pair_prep16_inv_cols_kernel<double><<<(unsigned)nblk, 256, 0, st>>>(in, deep_planes(base, n_frames * w, h), rot1, rot2, (unsigned)w, (unsigned)h,
-                                                                       K8, K16, (unsigned)n_frames, groups, tiles_c, class_major ? 1u : 0u);
+    const size_t lines = n_frames * w;
+    DeepPlanes dp;
+    double* p = base;
+    const size_t p8 = lines * K8, p16 = lines * K16;
+    dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
+    p += 6 * p8;
+    dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;      // semi: as2 = the c[4q+2] plane, the others unused
+    if (semi) pair_prep16_inv_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, 0u);
+    else      pair_prep16_inv_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, class_major ? 1u : 0u);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -352,6 +352,47 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             }});
             return SSW_OK;
         }
+        // ... and the inverse column pass of such a length: c[8q] / c[8q+4] -> T2, the whole c[4q+2] part + T2 -> E, split odd
+        // part + E -> output
+        const bool semi_inv = split && inverse && !is_row && dct_pair_can_semi_deep_cols(len) && w % 4 == 0;
+        if (semi_inv) {
+            const void *e0 = nullptr, *e1 = nullptr, *h1 = nullptr;
+            SSW_TRY(get_basis(ctx, len / 4, true, true, 3, &e0));
+            SSW_TRY(get_basis(ctx, len / 4, true, true, 4, &e1));
+            SSW_TRY(get_basis(ctx, len / 2, true, true, 4, &h1));
+            SSW_TRY(grow(ws.operand[1], bytes));
+            SSW_TRY(grow(ws.operand[4], bytes));
+            void* T2 = ws.operand[1].p;
+            void* TE = ws.operand[4].p;
+            const size_t p8 = lines * dct_pair_split_kpad(len);
+            double* m = sp + 6 * p8;
+            const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_prep, st, prep_bytes);
+                return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot, false);
+            }});
+            RgbSink sink;
+            if (!first_pass && x.rgb_out && x.iq_i && x.iq_q) {
+                sink.iq_i = x.iq_i; sink.iq_q = x.iq_q; sink.rgb = x.rgb_out; sink.u8 = x.rgb_out_u8;
+                if (fused_rgb) *fused_rgb = true;
+            }
+            const bool with_sink = sink.rgb != nullptr;
+            const double f_all = pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) +
+                                 pair_gemm_flop(is_row, 2, 1, n, w, h);
+            ch.push_back({false, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_pass, st, f_all);
+                SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
+                SSW_TRY(pair_gemm(st, true, is_row, true, 2, 1, m, m, h1, (const char*)h1 + (len / 8) * 64, dst, T2, n, w, h, ep, nullptr, TE));
+                if (lines <= 8192) {
+                    const PairClassDesc d0[2] = {{3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1},
+                                                 {4, 0, sp + 2 * p8, sp + 3 * p8, (const double*)sb2_, (const double*)sb3}};
+                    return launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d0, dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr);
+                }
+                SSW_TRY(pair_gemm(st, true, is_row, true, 3, 0, sp, sp + p8, sb0, sb1, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr));
+                return pair_gemm(st, true, is_row, true, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, TE, n, w, h, ep, with_sink ? &sink : nullptr);
+            }});
+            return SSW_OK;
+        }
         // the inverse the same way: c[8q] / c[8q+4] -> T2, the split c[4q+2] part + T2 -> T (the even half E), then the
         // split odd part + T -> the output; one pre-pass for all five launches
         const bool deep_inv = split && inverse && (is_row ? dct_pair_can_deep_inv_rows(len) : dct_pair_can_deep_cols(len) && w % 4 == 0);
