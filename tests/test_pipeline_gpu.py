@@ -313,6 +313,33 @@ def test_pruned_derived_transform_is_bit_identical_to_full(precision, case):
         wm.default_context().set_dct_folding(True)
 
 
+@pytest.mark.parametrize("shape", [(272, 1024), (144, 1040), (1080, 1920)])
+def test_batch_paths_with_the_odd_split_off_agree_with_the_default(shape):
+    """ssw_ctx_set_odd_split(0) -- every GEMM operand an exact folded sum, the round-2 arithmetic -- through the batch
+    entry points: same index lists, extraction and similarity equal to the default (split, deep, class-major where the
+    shape allows: 1024 x 272 takes all of it) within the rounding of single coefficients, and the pruned derived
+    transform stays bit-identical to the full one in that mode too."""
+    h, w = shape
+    n, k = 3, 300
+    rgb = G.synth(13, 1, n, w, h)
+    marks = np.random.default_rng(13).standard_normal((n, k)).astype(np.float32)
+    cfg = G.default_config(F64)
+    ctx = G.ctx()
+    default = _run_batch(rgb, marks, cfg, True, True, 2)
+    ctx.set_odd_split(False)
+    try:
+        exact = _run_batch(rgb, marks, cfg, True, True, 2)
+        exact_full = _run_batch(rgb, marks, cfg, True, False, 2)
+    finally:
+        ctx.set_odd_split(True)
+    assert np.array_equal(exact[3], exact_full[3]) and np.array_equal(exact[4], exact_full[4])
+    assert np.array_equal(default[2], exact[2])                                   # index lists
+    assert np.mean(default[1] == exact[1]) >= 0.9995                              # coefficient planes
+    assert np.abs(default[0] - exact[0]).max() <= 2.4e-7                          # marked frames: single ulps
+    assert np.abs(default[3] - exact[3]).max() <= 1e-5 * max(1.0, float(np.abs(exact[3]).max()))
+    assert np.abs(default[4] - exact[4]).max() <= 1e-4 * float(np.abs(exact[4]).max())
+
+
 def test_pruned_path_falls_back_when_the_columns_do_not_fit():
     """White-noise frames spread their largest coefficients over all frequency columns: the compact plane
     overflows, the chunk is redone with the full transform, and the result still equals the full path."""
