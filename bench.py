@@ -628,7 +628,7 @@ def main():
 
     def kernel_report(prec_name, stage, steps):
         """Per-kernel achieved rates from the live event timers and the work the library counted for the
-        same launches.  GEMMs: EXECUTED flop / time is the utilisation (folding executes 3/8 or 11/32 of
+        same launches.  GEMMs: EXECUTED flop / time is the utilisation (folding and the split odd halves execute about a tenth of
         the dense 2*lines*N*N, the pruned derived transform a few percent of it); the reference's dense
         flop / time is reported separately as "effective"."""
         peak = PEAK_F64_MFMA_TFLOPS if prec_name == "f64" else PEAK_F32_MFMA_TFLOPS
