@@ -142,7 +142,7 @@ def hbm_report(stage, names):
 
 # The launch bench.py's `roofline` block is about: the largest single GEMM launch of a forward transform.
 #   f64 (default): class E of the split odd half of a row pass -- (AS x cosine rows 2i) + (BD x sine rows 2i), W/8 + 1
-#       output pairs, sums of W/8 terms (csrc/dct_pair_prep.hip "Split odd half"); its own template instance (SUB = 4)
+#       output pairs in W/8 slots, sums of W/8 terms (csrc/dct_pair_prep.hip "Split odd half"); its own template instance (SUB = 4)
 #   f32: the unsplit odd half (the f32 twin keeps exact-operand folding)
 def main_kernel_label(prec_name):
     return "pair_gemm_f64_kernel<rows, split odd half, class E>" if prec_name == "f64" else "pair_gemm_f32_kernel<rows, odd half>"
@@ -153,9 +153,9 @@ def main_kernel_instance(prec_name):
 
 
 MAIN_KERNEL_NOTE = {
-    "f64": ("executed flop of one launch (two products of lines x (W/8 + 1) output pairs x W/8 sums: the cosine and the sine "
-            "part of class E of the split odd half, counted by the library per launch) / its average duration from a "
-            "hipEvent pair on the stream it runs on, inside the timed region"),
+    "f64": ("executed flop of one launch (two products of lines x W/8 pair slots x W/8 sums: the cosine and the sine part of "
+            "class E of the split odd half -- W/8 + 1 output pairs, the first and the last sharing a slot -- counted by the "
+            "library per launch) / its average duration from a hipEvent pair on the stream it runs on, inside the timed region"),
     "f32": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency half of the even/odd-"
             "folded basis GEMM, counted by the library per launch) / its average duration from a hipEvent pair on the "
             "stream it runs on, inside the timed region"),

@@ -61,6 +61,10 @@ struct PairOutT {
     // pairs >= np1 and the second output of pairs < p2lo do not exist (the last / first pair of class E).
     unsigned pm = 0;
     unsigned np1 = 0xFFFFFFFFu, p2lo = 0;
+    // class E of the split odd half has n/8 + 1 pairs of which the first has no second output (its sine row is zero) and
+    // the last no first one (its cosine row is zero): with fold0 = n/8 they share pair 0 -- cosine row 0 against sine row
+    // n/8 -- whose outputs are acc1 (as the first output of pair 0) and -acc2 (as the second output of pair n/8)
+    unsigned fold0 = 0;
     T* tmp_out = nullptr;     // EPI_INV_OT
     unsigned cm = 0;          // inverse row pass: output line (and the E plane) in class-major order (inverse_class_pos)
 };

@@ -81,7 +81,7 @@ typedef PairOutT<double> PairOut;
 struct PairClassArgs {
     const double *x1, *x2, *y1, *y2;
     unsigned NP, Kp, yrows, tiles_n;
-    unsigned c1, c2, cs, pm, np1, p2lo, bn32;
+    unsigned c1, c2, cs, pm, np1, p2lo, bn32, fold0;
 };
 struct PairMulti {
     PairClassArgs c[5];
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     const double* __restrict__ Y2g = ca.y2;
     const unsigned L = ml.L, NP = ca.NP, Kp = ca.Kp, yrows = ca.yrows;
     PairOut po = ml.po;
-    po.c1 = ca.c1; po.c2 = ca.c2; po.cs = ca.cs; po.pm = ca.pm; po.np1 = ca.np1; po.p2lo = ca.p2lo; po.bn32 = ca.bn32;
+    po.c1 = ca.c1; po.c2 = ca.c2; po.cs = ca.cs; po.pm = ca.pm; po.np1 = ca.np1; po.p2lo = ca.p2lo; po.bn32 = ca.bn32; po.fold0 = ca.fold0;
     const unsigned m0 = tm * BM, p0 = tn * (po.bn32 ? 32u : (unsigned)BN);
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
@@ -331,18 +331,31 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     auto trace_end = [] {};
 #endif
     if (po.pm) {                               // split odd half: cosine part +/- sine part (block-uniform branch)
+        // fold0 (class E): pair 0 multiplied cosine row 0 and sine row n/8; its outputs are acc1 itself (first output of
+        // pair 0: the sine row of pair 0 is zero) and -acc2 (second output of pair n/8: its cosine row is zero).  Only the
+        // first tile column holds pair 0: block-uniform branch, one select per value there.
+        const bool has0 = po.fold0 != 0 && p0 == 0 && wn == 0;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double s = acc1[i][jn][r] + acc2[i][jn][r];
-                    acc2[i][jn][r] = acc1[i][jn][r] - acc2[i][jn][r];
+                    const double a1 = acc1[i][jn][r], a2 = acc2[i][jn][r];
+                    double s = a1 + a2, d = a1 - a2;
+                    if (jn == 0 && has0) {
+                        // !COLS: the pair runs along the lanes (li); COLS: along the accumulator rows (lq + 4 r)
+                        const bool p = COLS ? (lq == 0 && r == 0) : (li == 0);
+                        s = p ? a1 : s;
+                        d = p ? 0.0 - a2 : d;
+                    }
                     acc1[i][jn][r] = s;
+                    acc2[i][jn][r] = d;
                 }
     }
     const bool second_out = po.pm != 2;
+    // pair whose second output this pair's slot carries (fold0: pair 0 carries pair n/8's)
+    auto p2 = [&](unsigned pair) { return (po.fold0 && pair == 0) ? po.fold0 : pair; };
 
     // D map of 16x16x4 f64: col = lane & 15, row = (lane >> 4) + 4 reg
     const unsigned n = po.n, W = po.W, H = po.H;
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     auto opos = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len) : m; };
     auto emit = [&](float* lp, double* tp, double* to, unsigned es, unsigned pair, double a1, double a2) {
         if (EPI == EPI_FWD || EPI == EPI_FWD_ADJ) {
-            const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
+            const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * p2(pair);
             if (EPI == EPI_FWD_ADJ) {
                 const f32x2 v = {apply_epilogue(ep, (float)a1, i1), apply_epilogue(ep, (float)a2, i2)};
                 *reinterpret_cast<f32x2*>(lp + i1) = v;
@@ -367,11 +380,11 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
             tp[pair * es] = a1 + a2;
             tp[(n / 2 - 1 - pair) * es] = a1 - a2;
         } else if (EPI == EPI_INV_OT) {
-            const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * pair;
+            const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * p2(pair);
             if (n1 < n / 2) { const double e1 = tp[n1 * es]; to[opos(n1, n) * es] = e1 + a1; to[opos(n - 1 - n1, n) * es] = e1 - a1; }
             if (n2 < n / 2) { const double e2 = tp[n2 * es]; to[opos(n2, n) * es] = e2 + a2; to[opos(n - 1 - n2, n) * es] = e2 - a2; }
         } else {
-            const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * pair;      // positions in the odd part, < n/2
+            const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * p2(pair);      // positions in the odd part, < n/2
             if (n1 < n / 2) {
                 const double e1 = tp[opos(n1, n / 2) * es];
                 lp[opos(n1, n) * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn) {
                     const unsigned pair = p0 + wn + 16 * jn + li;
-                    const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * pair;
+                    const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * p2(pair);
                     vo1[jn] = (pair < NP && pair < po.np1) ? (lq * W + i1) * 4u : OOB;
                     vo2[jn] = (pair < NP && pair >= po.p2lo && second_out) ? (lq * W + i2) * 4u : OOB;
                     f1[jn] = i1 == 0 ? ep.first : ep.base;
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                     const unsigned pair = p0 + wn + 16 * jn + li;
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
-                        const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * pair;
+                        const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
                         const bool ok = pair < NP && nn < n / 2;
                         vt[jn][h2] = ok ? (lq * (n / 2) + nn) * 8u : OOB;
                         vp[jn][h2] = ok ? (lq * n + opos(nn, n)) * 8u : OOB;
@@ -484,7 +497,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                     const unsigned pair = p0 + wn + 16 * jn + li;
 #pragma unroll
                     for (int h2 = 0; h2 < 2; ++h2) {
-                        const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * pair;
+                        const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
                         const bool ok = pair < NP && nn < n / 2;
                         vt[jn][h2] = ok ? (lq * (n / 2) + opos(nn, n / 2)) * 8u : OOB;
                         vp[jn][h2] = ok ? (lq * W + opos(nn, n)) * 4u : OOB;
@@ -618,7 +631,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
-                        const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * (pair < NP ? pair : 0);
+                        const unsigned pcl = pair < NP ? pair : 1;
+                        const unsigned nn = h2 ? po.c2 + po.cs * p2(pcl) : po.c1 + po.cs * pcl;
                         e[i][r] = tp2[(size_t)(nn < n / 2 ? nn : 0) * W];
                     }
                 }
@@ -638,7 +652,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                         const unsigned pair = p0 + wn + 16 * jn + t * RPI + rrow;
                         const f64x2 v = *reinterpret_cast<const f64x2*>(trd + t * RPI * CW);
                         if (!line_ok || pair >= NP) continue;
-                        const unsigned nn = (h2 ? po.c2 : po.c1) + po.cs * pair;
+                        const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
                         if (nn >= n / 2) continue;
                         const unsigned idx = sign ? n - 1 - nn : nn;
                         *reinterpret_cast<f64x2*>(tbase + (size_t)idx * W) = v;
@@ -705,7 +719,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                     const unsigned pair = p0 + wn + t * RPI + rrow;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
                     if (!line_ok || pair >= NP) continue;
-                    const unsigned idx = EPI == EPI_FWD ? (set ? po.c2 : po.c1) + po.cs * pair : (set ? n - 1 - pair : pair);
+                    const unsigned idx = EPI == EPI_FWD ? (set ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair) : (set ? n - 1 - pair : pair);
                     if (EPI == EPI_FWD && (set ? (pair < po.p2lo || !second_out) : pair >= po.np1)) continue;
                     put_quad(idx, v);
                 }
@@ -728,7 +742,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                         for (int r = 0; r < 4; ++r) {
                             const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
                             const unsigned pc = pair < NP ? pair : 0;
-                            const unsigned nn = (half ? po.c2 : po.c1) + po.cs * pc;
+                            const unsigned nn = half ? po.c2 + po.cs * p2(pc) : po.c1 + po.cs * pc;
                             e[i][r] = tp[(size_t)(nn < n / 2 ? nn : 0) * W];
                         }
                     }
@@ -749,7 +763,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                         const unsigned pair = p0 + wn + 16 * jn + (srow & 15);
                         const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
                         if (!line_ok || pair >= NP) continue;
-                        const unsigned nn = (half ? po.c2 : po.c1) + po.cs * pair;
+                        const unsigned nn = half ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
                         if (nn >= n / 2) continue;
                         put_quad(srow < 16 ? nn : n - 1 - nn, v);
                     }
@@ -783,7 +797,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                         for (int q = 0; q < 2; ++q) {
                             const unsigned pair = p0 + wn + 16 * jn + lq + 4 * (r + q);
                             const unsigned pc = pair < NP ? pair : 0;
-                            const unsigned n1 = po.c1 + po.cs * pc, n2 = po.c2 + po.cs * pc;
+                            const unsigned n1 = po.c1 + po.cs * pc, n2 = po.c2 + po.cs * p2(pc);
                             ok1[q] = pair < NP && n1 < n / 2;
                             ok2[q] = pair < NP && n2 < n / 2;
                             m1[q] = ok1[q] ? n1 : 0;
@@ -860,20 +874,20 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
     const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
     if (split && leff % 8 != 0) return SSW_ERR_BAD_ARG;
     ca.x1 = d.x1; ca.x2 = d.x2; ca.y1 = d.y1; ca.y2 = d.y2;
-    ca.NP = (unsigned)(kind == 0 ? leff / 2 : kind == 3 ? leff / 8 + 1 : kind == 4 ? leff / 8 : leff / 4);
+    ca.NP = (unsigned)(kind == 0 ? leff / 2 : split ? leff / 8 : leff / 4);      // class E: n/8 + 1 pairs in n/8 slots (fold0)
     ca.Kp = (unsigned)(split ? pair_kpad<double>(leff / 4) : kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
-    ca.yrows = kind == 2 ? 2 * ca.NP : ca.NP;                 // lines of the basis plane(s)
+    ca.yrows = kind == 2 ? 2 * ca.NP : kind == 3 ? ca.NP + 1 : ca.NP;      // lines of the basis plane(s): class E's keep row n/8
     ca.tiles_n = (ca.NP + 63) / 64;
-    ca.c1 = 0; ca.c2 = 1; ca.cs = 2; ca.pm = 0; ca.np1 = 0xFFFFFFFFu; ca.p2lo = 0; ca.bn32 = 0;
+    ca.c1 = 0; ca.c2 = 1; ca.cs = 2; ca.pm = 0; ca.np1 = 0xFFFFFFFFu; ca.p2lo = 0; ca.bn32 = 0; ca.fold0 = 0;
     if (kind == 1) { ca.c1 = 0; ca.c2 = 2 * fs; ca.cs = 4 * fs; }
     if (kind == 2) { ca.c1 = fs; ca.c2 = fs + 2 * fs * ca.NP; ca.cs = 2 * fs; }
     if (inverse && kind == 2) { ca.c1 = 0; ca.c2 = (unsigned)(leff / 4); ca.cs = 1; }      // positions pair, pair + n/4 of the odd part
     if (split) {
         // odd frequency u = 2k+1 of the (sub-)transform; class E (kind 3) pair i: k = 4i (+), 4i-1 (-); class O: k = 4i+2 (+), 4i+1 (-)
         ca.pm = 1;
+        if (kind == 3) ca.fold0 = (unsigned)(leff / 8);       // y2 must be the launch variant of the sine basis (row 0 = row n/8)
         if (!inverse) {
             ca.c1 = (kind == 3 ? 1u : 5u) * fs; ca.c2 = kind == 3 ? 0u - fs : 3u * fs; ca.cs = 8 * fs;
-            if (kind == 3) { ca.np1 = (unsigned)(leff / 8); ca.p2lo = 1; }
         } else {
             ca.c1 = kind == 3 ? 0u : 2u; ca.c2 = kind == 3 ? 0u - 1u : 1u; ca.cs = 4;             // positions of the odd part
         }
@@ -914,7 +928,8 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
 //        1  level 2, even half: X = (SS, SD) | (EE, EO), Y = half bases of len/2          pairs = len/4, K = len/4
 //        2  level 2, odd half:  X = D | O (shared), Y = the two halves of the odd basis   pairs = len/4, K = len/2
 //    3 / 4  the odd half split once more (dct_pair_prep.hip "Split odd half"): X = (AS, BD) | (AD, BS), Y = (cosine,
-//           sine) rows 2i | 2i+1 of the quarter-length bases; outputs acc1 +/- acc2          pairs = len/8 + 1 | len/8, K = len/8
+//           sine) rows 2i | 2i+1 of the quarter-length bases; outputs acc1 +/- acc2          pairs = len/8, K = len/8
+//           (class E's first and last pair share slot 0: its y2 is the launch variant of the sine basis, row 0 = row len/8)
 //   sub: the class belongs to the transform of length len >> sub that a deeper folding level applies to the even part.
 int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, int n_classes, const PairClassDesc* desc, float* out,
                                    double* tmp, size_t n_frames, size_t w, size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out,
@@ -1026,7 +1041,7 @@ int launch_dct_pair_gemm_rows_subset_f64(hipStream_t st, const double* x, const 
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     if ((unsigned long long)Kp * L * sizeof(double) > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     PairMulti ml;
-    ml.c[0] = PairClassArgs{x, x, y, y + (size_t)NP * 8, NP, Kp, cap, tiles_n, off, off + NP, 1, 0, 0xFFFFFFFFu, 0, 0};
+    ml.c[0] = PairClassArgs{x, x, y, y + (size_t)NP * 8, NP, Kp, cap, tiles_n, off, off + NP, 1, 0, 0xFFFFFFFFu, 0, 0, 0};
     ml.n_classes = 1; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
     ml.po = PairOut{out, nullptr, out_stride, 0, 0, off, off + NP, 1};
     const Epilogue ep{1.f, 1.f};
@@ -1047,7 +1062,7 @@ int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1,
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     if ((unsigned long long)Kp * L * sizeof(double) > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     PairMulti ml;
-    ml.c[0] = PairClassArgs{x1, x2, y1, y2, NP, Kp, cap, tiles_n, off, 0, 1, 2, 0xFFFFFFFFu, 0, 0};
+    ml.c[0] = PairClassArgs{x1, x2, y1, y2, NP, Kp, cap, tiles_n, off, 0, 1, 2, 0xFFFFFFFFu, 0, 0, 0};
     ml.n_classes = 1; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
     ml.po = PairOut{out, nullptr, out_stride, 0, 0, off, 0, 1};
     const Epilogue ep{1.f, 1.f};

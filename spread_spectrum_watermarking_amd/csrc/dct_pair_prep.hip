@@ -58,17 +58,17 @@ int launch_make_half_basis_blocked(hipStream_t st, bool f64, size_t n, bool inve
 // 2i + 1 (O, N/8 rows), n < N/8; scale 2 forward, 1/2 inverse as in make_half_basis_blocked_kernel.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void make_split_basis_blocked_kernel(size_t n, bool inverse, int which /*0 cosE, 1 sinE, 2 cosO, 3 sinO*/, size_t kpad,
+__global__ void make_split_basis_blocked_kernel(size_t n, bool inverse, int which /*0 cosE, 1 sinE, 2 cosO, 3 sinO, 4 sinE with row 0 := row n/8*/, size_t kpad,
                                                 size_t rows, T* out) {
     const size_t ktrue = n / 8, total = rows * kpad;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t o = i / kpad, s = i % kpad;
         double v = 0.0;
         if (s < ktrue) {
-            const unsigned long long j = (which & 2) ? 2ull * o + 1ull : 2ull * o;
+            const unsigned long long j = (which & 2) ? 2ull * o + 1ull : (which == 4 && o == 0) ? 2ull * (n / 8) : 2ull * o;
             const unsigned long long a = (j * (2ull * s + 1ull)) % (unsigned long long)n;       // angle 2 pi a / n
             const double arg = (double)(2ull * a) / (double)n;
-            const double c = (which & 1) ? sinpi(arg) : cospi(arg);
+            const double c = ((which & 1) || which == 4) ? sinpi(arg) : cospi(arg);
             v = (inverse ? 0.5 : 2.0) * c;
         }
         out[blk_index<T>(o, (unsigned)s, rows)] = (T)v;
@@ -92,7 +92,7 @@ size_t dct_pair_split_elems(size_t n_frames, size_t w, size_t h) {
     const size_t a = n_frames * h * dct_pair_split_kpad(w), b = n_frames * w * dct_pair_split_kpad(h);
     return 4 * (a > b ? a : b);
 }
-size_t dct_pair_split_basis_rows(size_t len, int which) { return (which & 2) ? len / 8 : len / 8 + 1; }
+size_t dct_pair_split_basis_rows(size_t len, int which) { return (which & 2) ? len / 8 : len / 8 + 1; }      // which 4 like 1
 
 int launch_make_split_basis_blocked(hipStream_t st, size_t n, bool inverse, int which, double* out) {
     const size_t kp = dct_pair_split_kpad(n), rows = dct_pair_split_basis_rows(n, which), total = rows * kp;

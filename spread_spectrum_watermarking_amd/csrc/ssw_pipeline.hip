@@ -105,15 +105,17 @@ int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const vo
     auto it = ctx->basis.find(key);
     if (it != ctx->basis.end()) { *out = it->second; return SSW_OK; }
     void* p = nullptr;
-    // kinds 5..8: split odd half bases (cosE, sinE, cosO, sinO), 9: the rotation table (f64 only)
+    // kinds 5..8: split odd half bases (cosE, sinE, cosO, sinO), 9: the rotation table, 10: sinE for the launches (row 0 =
+    // row n/8: class E's first and last pair share a slot) -- f64 only
+    const int split_which = kind == 10 ? 4 : kind - 5;
     const size_t elems = kind == 0 ? n * dense_basis_kpad(n)
                        : kind == 9 ? n / 2
-                       : kind >= 5 ? dct_pair_split_basis_rows(n, kind - 5) * dct_pair_split_kpad(n)
+                       : kind >= 5 ? dct_pair_split_basis_rows(n, split_which) * dct_pair_split_kpad(n)
                        : kind >= 3 ? (n / 2) * dct_pair_kpad(f64, n) : (n / 2) * half_basis_kpad(n);
     if (kind >= 5 && !f64) return SSW_ERR_BAD_ARG;
     SSW_ALLOC(&p, std::max<size_t>(elems, 1) * (f64 ? sizeof(double) : sizeof(float)));
     int rc = kind == 9 ? launch_make_rot_table(ctx->stream, n, (double*)p)
-             : kind >= 5 ? launch_make_split_basis_blocked(ctx->stream, n, inverse, kind - 5, (double*)p)
+             : kind >= 5 ? launch_make_split_basis_blocked(ctx->stream, n, inverse, split_which, (double*)p)
              : kind >= 3 ? launch_make_half_basis_blocked(ctx->stream, f64, n, inverse, kind - 3, p)
              : kind != 0 ? (f64 ? launch_make_half_basis_f64(ctx->stream, n, inverse, kind - 1, (double*)p)
                               : launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p))
@@ -195,7 +197,7 @@ int pair_gemm(hipStream_t st, bool f64, bool is_row, bool inverse, int kind, int
 double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t h) {
     const double lines = (double)(is_row ? n * h : n * w);
     const size_t leff = (is_row ? w : h) >> sub;
-    if (kind == 3 || kind == 4) return 4.0 * lines * (double)(leff / 8 + (kind == 3 ? 1 : 0)) * (double)(leff / 8);
+    if (kind == 3 || kind == 4) return 4.0 * lines * (double)(leff / 8) * (double)(leff / 8);      // class E: n/8 + 1 pairs in n/8 slots
     const double np = (double)(kind == 0 ? leff / 2 : leff / 4), k = (double)(kind == 1 ? leff / 4 : leff / 2);
     return 4.0 * lines * np * k;
 }
@@ -249,7 +251,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
         const size_t lines = is_row ? n * h : n * w;
         const size_t sp_plane = lines * (split ? dct_pair_split_kpad(len) : 0);
         if (split) {
-            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len, inverse, true, 5 + b, &sb[b]));
+            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len, inverse, true, b == 1 ? 10 : 5 + b, &sb[b]));      // 10: sinE for launches
             SSW_TRY(get_basis(ctx, len, false, true, 9, &rot));
             SSW_TRY(grow(ws.operand[5], split_scratch_elems(n, w, h) * sizeof(double)));
             sp = (double*)ws.operand[5].p;
@@ -261,7 +263,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr;
             SSW_TRY(get_basis(ctx, len / 4, false, true, 3, &e0));
             SSW_TRY(get_basis(ctx, len / 4, false, true, 4, &e1));
-            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, false, true, 5 + b, &sb2[b]));
+            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, false, true, b == 1 ? 10 : 5 + b, &sb2[b]));
             SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
             const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
             double* q = sp + 6 * p8;
@@ -400,7 +402,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr;
             SSW_TRY(get_basis(ctx, len / 4, true, true, 3, &e0));
             SSW_TRY(get_basis(ctx, len / 4, true, true, 4, &e1));
-            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, true, true, 5 + b, &sb2[b]));
+            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, true, true, b == 1 ? 10 : 5 + b, &sb2[b]));
             SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
             SSW_TRY(grow(ws.operand[1], bytes));
             SSW_TRY(grow(ws.operand[4], bytes));

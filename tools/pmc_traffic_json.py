@@ -45,7 +45,7 @@ K8 = lambda n: -(-(n // 8) // 16) * 16        # padded sum length of the n/8-wid
 names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESIGN.md, algorithmic bytes per launch, note)
     "pair_gemm_f64_kernel<false, 0, false, 4>": ("pair_gemm_f64_kernel<rows, split odd half, class E>",
         2 * lines_r * K8(W) * esz + 2 * (W // 8 + 1) * K8(W) * esz + lines_r * (W // 4) * 4,
-        "AS and BD operand planes (k-blocked f64) x cosine / sine rows 2i -> frequencies 8i +/- 1 (f32)"),
+        "AS and BD operand planes (k-blocked f64) x cosine / sine rows 2i -> frequencies 8i +/- 1 (f32); W/8 + 1 pairs in W/8 slots"),
     "pair_gemm_f64_kernel<false, 0, false, 3>": ("pair_gemm_f64_kernel<rows, split odd halves, other classes>",
         2 * lines_r * K8(W) * esz + 2 * (W // 8) * K8(W) * esz + lines_r * (W // 4) * 4,
         "class O of the full-length split and both classes of the half-length one (half the size), and the gathered launches of the pruned transform: mean over launches"),
