@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libssw_hip.so")
+# SSW_LIB_PATH: a diagnostic build of the same library (e.g. -DSSW_TILE_TRACE), never a different implementation
+LIB_PATH = os.environ.get("SSW_LIB_PATH") or os.path.join(_HERE, "lib", "libssw_hip.so")
 
 SSW_OK = 0
 STATUS_NAMES = {

@@ -67,6 +67,11 @@ struct PairOutT {
     unsigned fold0 = 0;
     T* tmp_out = nullptr;     // EPI_INV_OT
     unsigned cm = 0;          // inverse row pass: output line (and the E plane) in class-major order (inverse_class_pos)
+    unsigned cmt = 0;         // ... the output line inside tiles of cmt positions (the E planes: one tile)
+    // forward row pass, class-major inside tiles of ft memory columns (ft != 0): entry e = pair (output 1) or
+    // p2(pair) - e2off (output 2) of its class goes to column c + (e >> gsh) * ft + (e & ((1 << gsh) - 1)); gsh = log2 of the
+    // class's entries per tile (ft a power of two), or 31 for one tile over the whole line
+    unsigned ft = 0, gsh = 31, e2off = 0;
 };
 
 // Column order of the intermediate plane between the two passes of a deep forward transform (row pass first): the
@@ -75,38 +80,61 @@ struct PairOutT {
 // of 4.2 GB -- PMC WRITE_SIZE -- and the clock the chip holds under that load was 10-20 % lower.)
 //   class      R1     R2     E2P      E2M      O2P      O2M      EP     EM     OP     OM
 //   u mod      8: 0   8: 4   16: 2    16: 14   16: 10   16: 6    8: 1   8: 7   8: 5   8: 3
-//   length     n/8    n/8    n/16     n/16     n/16     n/16     n/8    n/8    n/8    n/8
+//   length     t/8    t/8    t/16     t/16     t/16     t/16     t/8    t/8    t/8    t/8
+// r4: the order is class-major INSIDE TILES of t natural frequencies (t = 128 when 128 divides n, else t = n: one tile):
+// the t frequencies [T t, T t + t) occupy the memory columns [T t, T t + t), classes side by side.  A row launch still
+// stores runs (t/8 = 16 entries = the 16 pairs of one MFMA tile), and a block of the column pre-pass now reads ONE
+// contiguous 512-byte run per row for 128 consecutive operand lines (the one-tile order gave it ten runs of 64 / 32
+// bytes, or -- read by memory column -- stores scattered over lines 8 or 16 apart: 2.8 TB/s).
 struct ForwardClassLayout {
-    unsigned n;
+    unsigned n, t;
     enum { R1 = 0, R2, E2P, E2M, O2P, O2M, EP, EM, OP, OM };
+    __host__ __device__ ForwardClassLayout(unsigned n_, unsigned t_ = 0) : n(n_), t(t_ ? t_ : n_) {}
+    // offset of class c inside a tile
     __host__ __device__ unsigned base(int c) const {
-        const unsigned e = n / 8, s = n / 16;
-        return c < 2 ? c * e : c < 6 ? 2 * e + (c - 2) * s : n / 2 + (c - 6) * e;
+        const unsigned e = t / 8, s = t / 16;
+        return c < 2 ? c * e : c < 6 ? 2 * e + (c - 2) * s : t / 2 + (c - 6) * e;
+    }
+    // entries of class c per tile
+    __host__ __device__ unsigned group(int c) const { return (c >= 2 && c < 6) ? t / 16 : t / 8; }
+    // memory column of entry i of class c
+    __host__ __device__ unsigned pos(int c, unsigned i) const {
+        const unsigned g = group(c);
+        return (i / g) * t + base(c) + i % g;
     }
     // natural frequency of memory column p
     __host__ __device__ unsigned natural(unsigned p) const {
-        const unsigned e = n / 8, s = n / 16;
-        if (p < 2 * e) return p < e ? 8 * p : 8 * (p - e) + 4;
-        if (p < n / 2) {
+        const unsigned e = t / 8, s = t / 16, tb = (p / t) * t;
+        p -= tb;
+        if (p < 2 * e) return tb + (p < e ? 8 * p : 8 * (p - e) + 4);
+        if (p < t / 2) {
             const unsigned q = p - 2 * e, c = q / s, i = q - c * s;
-            return 16 * i + (c == 0 ? 2u : c == 1 ? 14u : c == 2 ? 10u : 6u);
+            return tb + 16 * i + (c == 0 ? 2u : c == 1 ? 14u : c == 2 ? 10u : 6u);
         }
-        const unsigned q = p - n / 2, c = q / e, i = q - c * e;
-        return 8 * i + (c == 0 ? 1u : c == 1 ? 7u : c == 2 ? 5u : 3u);
+        const unsigned q = p - t / 2, c = q / e, i = q - c * e;
+        return tb + 8 * i + (c == 0 ? 1u : c == 1 ? 7u : c == 2 ? 5u : 3u);
     }
 };
+// tile width of the class-major orders of a line of length n (both directions): 128 when that divides n
+__host__ __device__ inline unsigned class_tile(unsigned n) { return n % 128 == 0 ? 128u : n; }
 
 // The same idea for a deep INVERSE transform's row pass: a launch of the split odd part produces the positions 4i and
 // 4i-1 (class E) or 4i+2 and 4i+1 (class O) and their mirrors -- residues {0, 3} or {1, 2} mod 4 -- of the output line,
-// and reads / writes the even half E at the same residues.  Class-major order of a line of length len (len % 4 == 0):
-//   [ m = 0 mod 4 | m = 3 mod 4 | m = 1 mod 4 | m = 2 mod 4 ], each len/4 long, m / 4 ascending.
-__host__ __device__ inline unsigned inverse_class_pos(unsigned m, unsigned len) {
-    const unsigned c = m & 3u, q = len / 4;
-    return (c == 0 ? 0u : c == 3 ? q : c == 1 ? 2 * q : 3 * q) + (m >> 2);
+// and reads / writes the even half E at the same residues.  Class-major order of a line of length len (len % 4 == 0),
+// inside tiles of t positions (t % 4 == 0, t divides len; t = len: one tile -- the order of the E planes, which only
+// GEMM epilogues exchange):
+//   [ m = 0 mod 4 | m = 3 mod 4 | m = 1 mod 4 | m = 2 mod 4 ], each t/4 long, m / 4 ascending.
+__host__ __device__ inline unsigned inverse_class_pos(unsigned m, unsigned len, unsigned t = 0) {
+    t = t ? t : len;
+    const unsigned tb = (m / t) * t, r = m - tb;
+    const unsigned c = r & 3u, q = t / 4;
+    return tb + (c == 0 ? 0u : c == 3 ? q : c == 1 ? 2 * q : 3 * q) + (r >> 2);
 }
-__host__ __device__ inline unsigned inverse_class_natural(unsigned p, unsigned len) {
-    const unsigned q = len / 4, c = p / q, i = p - c * q;
-    return 4 * i + (c == 0 ? 0u : c == 1 ? 3u : c == 2 ? 1u : 2u);
+__host__ __device__ inline unsigned inverse_class_natural(unsigned p, unsigned len, unsigned t = 0) {
+    t = t ? t : len;
+    const unsigned tb = (p / t) * t, r = p - tb;
+    const unsigned q = t / 4, c = r / q, i = r - c * q;
+    return tb + 4 * i + (c == 0 ? 0u : c == 1 ? 3u : c == 2 ? 1u : 2u);
 }
 
 // yiq.rs:139-147 (f32::clamp) and :163-165, :173-175: the arithmetic of color.hip / attack.hip, per pixel

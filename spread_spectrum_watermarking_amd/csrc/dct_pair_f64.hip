@@ -82,6 +82,7 @@ struct PairClassArgs {
     const double *x1, *x2, *y1, *y2;
     unsigned NP, Kp, yrows, tiles_n;
     unsigned c1, c2, cs, pm, np1, p2lo, bn32, fold0;
+    unsigned gsh, e2off;               // forward class-major output map (PairOutT::ft)
 };
 struct PairMulti {
     PairClassArgs c[5];
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     const unsigned L = ml.L, NP = ca.NP, Kp = ca.Kp, yrows = ca.yrows;
     PairOut po = ml.po;
     po.c1 = ca.c1; po.c2 = ca.c2; po.cs = ca.cs; po.pm = ca.pm; po.np1 = ca.np1; po.p2lo = ca.p2lo; po.bn32 = ca.bn32; po.fold0 = ca.fold0;
+    po.gsh = ca.gsh; po.e2off = ca.e2off;
     const unsigned m0 = tm * BM, p0 = tn * (po.bn32 ? 32u : (unsigned)BN);
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
@@ -363,9 +365,19 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     // element offsets idx * es stay below 2^32 (W * H < 2^32: indices are u32 throughout)
     // position of element m of a line of length len: natural, or class-major on the row pass of a deep inverse transform
     auto opos = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len) : m; };
+    // ... of the f32 output line (class-major inside tiles of po.cmt positions; the E planes above: one tile)
+    auto oposf = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len, po.cmt) : m; };
+    // forward outputs of a pair: natural c + cs pair, or the class-major column of its entry (PairOutT::ft)
+    auto fpos1 = [&](unsigned pair) {
+        return po.ft ? po.c1 + (pair >> po.gsh) * po.ft + (pair & ((1u << po.gsh) - 1u)) : po.c1 + po.cs * pair;
+    };
+    auto fpos2 = [&](unsigned pair) {
+        const unsigned q = p2(pair), e = q - po.e2off;
+        return po.ft ? po.c2 + (e >> po.gsh) * po.ft + (e & ((1u << po.gsh) - 1u)) : po.c2 + po.cs * q;
+    };
     auto emit = [&](float* lp, double* tp, double* to, unsigned es, unsigned pair, double a1, double a2) {
         if (EPI == EPI_FWD || EPI == EPI_FWD_ADJ) {
-            const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * p2(pair);
+            const unsigned i1 = fpos1(pair), i2 = fpos2(pair);
             if (EPI == EPI_FWD_ADJ) {
                 const f32x2 v = {apply_epilogue(ep, (float)a1, i1), apply_epilogue(ep, (float)a2, i2)};
                 *reinterpret_cast<f32x2*>(lp + i1) = v;
@@ -387,13 +399,13 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
             const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * p2(pair);      // positions in the odd part, < n/2
             if (n1 < n / 2) {
                 const double e1 = tp[opos(n1, n / 2) * es];
-                lp[opos(n1, n) * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
-                lp[opos(n - 1 - n1, n) * es] = apply_epilogue(ep, (float)(e1 - a1), n - 1 - n1);
+                lp[oposf(n1, n) * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
+                lp[oposf(n - 1 - n1, n) * es] = apply_epilogue(ep, (float)(e1 - a1), n - 1 - n1);
             }
             if (n2 < n / 2) {
                 const double e2 = tp[opos(n2, n / 2) * es];
-                lp[opos(n2, n) * es] = apply_epilogue(ep, (float)(e2 + a2), n2);
-                lp[opos(n - 1 - n2, n) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
+                lp[oposf(n2, n) * es] = apply_epilogue(ep, (float)(e2 + a2), n2);
+                lp[oposf(n - 1 - n2, n) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
             }
         }
     };
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn) {
                     const unsigned pair = p0 + wn + 16 * jn + li;
-                    const unsigned i1 = po.c1 + po.cs * pair, i2 = po.c2 + po.cs * p2(pair);
+                    const unsigned i1 = fpos1(pair), i2 = fpos2(pair);
                     vo1[jn] = (pair < NP && pair < po.np1) ? (lq * W + i1) * 4u : OOB;
                     vo2[jn] = (pair < NP && pair >= po.p2lo && second_out) ? (lq * W + i2) * 4u : OOB;
                     f1[jn] = i1 == 0 ? ep.first : ep.base;
@@ -500,8 +512,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                         const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
                         const bool ok = pair < NP && nn < n / 2;
                         vt[jn][h2] = ok ? (lq * (n / 2) + opos(nn, n / 2)) * 8u : OOB;
-                        vp[jn][h2] = ok ? (lq * W + opos(nn, n)) * 4u : OOB;
-                        vm[jn][h2] = ok ? (lq * W + opos(n - 1 - nn, n)) * 4u : OOB;
+                        vp[jn][h2] = ok ? (lq * W + oposf(nn, n)) * 4u : OOB;
+                        vm[jn][h2] = ok ? (lq * W + oposf(n - 1 - nn, n)) * 4u : OOB;
                         fp[jn][h2] = nn == 0 ? ep.first : ep.base;
                     }
                 }
@@ -879,6 +891,7 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
     ca.yrows = kind == 2 ? 2 * ca.NP : kind == 3 ? ca.NP + 1 : ca.NP;      // lines of the basis plane(s): class E's keep row n/8
     ca.tiles_n = (ca.NP + 63) / 64;
     ca.c1 = 0; ca.c2 = 1; ca.cs = 2; ca.pm = 0; ca.np1 = 0xFFFFFFFFu; ca.p2lo = 0; ca.bn32 = 0; ca.fold0 = 0;
+    ca.gsh = 31; ca.e2off = 0;
     if (kind == 1) { ca.c1 = 0; ca.c2 = 2 * fs; ca.cs = 4 * fs; }
     if (kind == 2) { ca.c1 = fs; ca.c2 = fs + 2 * fs * ca.NP; ca.cs = 2 * fs; }
     if (inverse && kind == 2) { ca.c1 = 0; ca.c2 = (unsigned)(leff / 4); ca.cs = 1; }      // positions pair, pair + n/4 of the odd part
@@ -899,11 +912,21 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
         // quarter-length even half T2 (kind 1) keeps the natural order
         if (!is_row || !((kind == 1 && sub == 1) || split) || sub > 1) return SSW_ERR_BAD_ARG;
         if (!inverse) {
-            const ForwardClassLayout fl{(unsigned)len};
+            // po.ft = the tile: entry e of a class -> column base + (e >> gsh) * ft + (e & (2^gsh - 1)); class E's second
+            // output of pair p is entry p - 1 of its "-" class (frequency 8 p - 1)
+            const ForwardClassLayout fl{(unsigned)len, dct_pair_class_tile(len)};
+            const int k1 = kind == 1 ? ForwardClassLayout::R1 : kind == 3 ? (sub ? ForwardClassLayout::E2P : ForwardClassLayout::EP)
+                                                                          : (sub ? ForwardClassLayout::O2P : ForwardClassLayout::OP);
             ca.cs = 1;
-            if (kind == 1) { ca.c1 = fl.base(ForwardClassLayout::R1); ca.c2 = fl.base(ForwardClassLayout::R2); }
-            else if (kind == 3) { ca.c1 = fl.base(sub ? ForwardClassLayout::E2P : ForwardClassLayout::EP); ca.c2 = fl.base(sub ? ForwardClassLayout::E2M : ForwardClassLayout::EM) - 1; }
-            else { ca.c1 = fl.base(sub ? ForwardClassLayout::O2P : ForwardClassLayout::OP); ca.c2 = fl.base(sub ? ForwardClassLayout::O2M : ForwardClassLayout::OM); }
+            ca.c1 = fl.base(k1); ca.c2 = fl.base(k1 + 1);
+            ca.e2off = kind == 3 ? 1u : 0u;
+            ca.gsh = 31;
+            if (fl.t != fl.n) {
+                const unsigned g = fl.group(k1);
+                if (g == 0 || (g & (g - 1)) != 0) return SSW_ERR_BAD_ARG;
+                ca.gsh = 0;
+                while ((1u << ca.gsh) < g) ++ca.gsh;
+            }
         }
     }
     // template instance
@@ -974,7 +997,8 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     ml.n_classes = (unsigned)n_classes; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)(inverse ? leff0 : len), 0, 1, 2};
     po.tmp_out = tmp_out;
-    if (class_major && inverse && (desc[0].kind == 3 || desc[0].kind == 4)) po.cm = 1;
+    if (class_major && inverse && (desc[0].kind == 3 || desc[0].kind == 4)) { po.cm = 1; po.cmt = dct_pair_class_tile(len); }
+    if (class_major && !inverse) po.ft = dct_pair_class_tile(len);
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16)) && (!tmp_out || al(tmp_out, 16))) ? 1u : 0u;
     if (with_sink && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;

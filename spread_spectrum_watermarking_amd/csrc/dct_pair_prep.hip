@@ -2,7 +2,7 @@
 // the image operand of a pass once, already folded (forward) or split (inverse), in the precision the
 // MFMA consumes (T = double: every sum exact; T = float: one rounding per sum) and in the k-blocked
 // layout (dct_pair_common.hpp).  Also the half bases in that layout.
-#include "dct_pair_common.hpp"
+#include "dct_pair_split.hpp"
 
 #include <cstdlib>
 
@@ -85,6 +85,12 @@ __global__ void make_rot_table_kernel(size_t n, double* out) {
 }
 
 // first-level split through pair_rotate_kernel: any axis whose quarter length folds (rows and columns alike)
+// tile width of the class-major plane orders of a line of length len (dct_pair_common.hpp); SSW_CLASS_TILE=0: one tile
+// (the r3 order)
+unsigned dct_pair_class_tile(size_t len) {
+    static const int one_tile = [] { const char* e = std::getenv("SSW_CLASS_TILE"); return (e && std::atoi(e) == 0) ? 1 : 0; }();
+    return one_tile ? (unsigned)len : class_tile((unsigned)len);
+}
 bool dct_pair_can_split(size_t len, bool is_row) { (void)is_row; return len % 8 == 0 && len >= 128; }
 size_t dct_pair_split_kpad(size_t len) { return pair_kpad<double>(len / 4); }
 // doubles in the four split planes of a pass over n frames (the larger of the row and the column pass)
@@ -574,45 +580,6 @@ __global__ __launch_bounds__(256) void pair_prep8_rows_kernel(const void* __rest
 // One thread = 4 consecutive e < n/16 of one line: the 16 quads of x that meet in them (quad u mirrors quad 15 - u).
 // Planes are k-blocked, K8 = kpad(n/4) (>= n/8) and K16 = kpad(n/8) (>= n/16) wide, zero padded.
 // ---------------------------------------------------------------------------------------------
-// the same for a single e (scalar kernels)
-template <typename T>
-__device__ inline void split_one(T d0, T d1, T d2, T d3, const double* __restrict__ rot, unsigned e, unsigned Mh, T& as, T& bd, T& ad, T& bs) {
-    const T cc = (T)rot[e], ss = (T)rot[Mh + e], ccm = (T)rot[Mh - 1 - e], ssm = (T)rot[2 * Mh - 1 - e];
-    const T a = d0 * cc + d3 * ss, b = d3 * cc - d0 * ss;
-    const T am = d1 * ccm + d2 * ssm, bm = d2 * ccm - d1 * ssm;
-    as = a + am;
-    ad = a - am;
-    bs = b + bm;
-    bd = b - bm;
-}
-// One unit of the split: four consecutive e = base .. base + 3 of a DCT-IV input d of length M (Mh = M/2) given as
-// ascending quads  dA: d[base + i], dB: d[Mh-4-base + i], dC: d[Mh+base + i], dD: d[M-4-base + i];
-// rot: [0, Mh) cos psi, [Mh, 2 Mh) sin psi.  Same operations in the same order as pair_rotate_kernel.
-template <typename T>
-__device__ inline void split_unit(const vec4_t<T>& dA, const vec4_t<T>& dB, const vec4_t<T>& dC, const vec4_t<T>& dD,
-                                  const double* __restrict__ rot, unsigned base, unsigned Mh,
-                                  vec4_t<T>& as, vec4_t<T>& bd, vec4_t<T>& ad, vec4_t<T>& bs) {
-    const f64x4 c = *reinterpret_cast<const f64x4*>(rot + base), s = *reinterpret_cast<const f64x4*>(rot + Mh + base);
-    const f64x4 cm = *reinterpret_cast<const f64x4*>(rot + Mh - 4 - base), sm = *reinterpret_cast<const f64x4*>(rot + 2 * Mh - 4 - base);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const T d0 = dA[i], d1 = dB[3 - i], d2 = dC[i], d3 = dD[3 - i];
-        const T cc = (T)c[i], ss = (T)s[i], ccm = (T)cm[3 - i], ssm = (T)sm[3 - i];
-        const T a = d0 * cc + d3 * ss, b = d3 * cc - d0 * ss;
-        const T am = d1 * ccm + d2 * ssm, bm = d2 * ccm - d1 * ssm;
-        as[i] = a + am;
-        ad[i] = a - am;
-        bs[i] = b + bm;
-        bd[i] = b - bm;
-    }
-}
-
-struct DeepPlanes {        // device pointers of one pass's operand planes
-    void *as, *bd, *ad, *bs;         // K8 wide
-    void *r1, *r2;                   // K8 wide
-    void *as2, *bd2, *ad2, *bs2;     // K16 wide
-};
-
 template <typename T, int SRC /*0 plane, 1 rgb f32, 2 rgb u8*/, bool WITH_IQ>
 __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __restrict__ SRCP, DeepPlanes dp,
                                                               const double* __restrict__ rot1, const double* __restrict__ rot2,
@@ -815,7 +782,7 @@ template <typename T, bool SPLIT_SD>
 __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                               const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                               unsigned W, unsigned H, unsigned K8, unsigned K16,
-                                                              unsigned n_frames, unsigned tiles_e, unsigned tiles_c, unsigned class_major) {
+                                                              unsigned n_frames, unsigned tiles_e, unsigned tiles_c, unsigned class_major, unsigned ctile) {
     __shared__ T s[4][32][33];
     const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = SPLIT_SD ? H / 16 : (H / 8 + 1) / 2;      // H16: units
     const unsigned z = blockIdx.x / (tiles_e * tiles_c);
@@ -832,12 +799,12 @@ __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __re
     for (unsigned sub = 0; sub < nsub; ++sub) {
     if (sub) __syncthreads();
     const unsigned wd = (class_major == 2 && sub >= 2 && sub < 6) ? 16u : 32u;
-    const unsigned c0 = class_major == 2 ? ForwardClassLayout{W}.base((int)sub) + tile * wd : tile * 32;
+    const unsigned c0 = class_major == 2 ? ForwardClassLayout{W}.base((int)sub) + tile * wd : tile * 32;      // 2: one tile (ctile == W)
     const bool col_ok = cl < wd && c0 + cl < W;
     const unsigned cw = c0 + cl, ew = e0 + kq;
     // memory column cw of the intermediate plane holds frequency natural(cw) of the row pass (class-major order): the
     // operand line -- and with it the output column of the column GEMMs -- is the natural one
-    const unsigned cn = (class_major && col_ok) ? ForwardClassLayout{W}.natural(cw) : cw;
+    const unsigned cn = (class_major && col_ok) ? ForwardClassLayout{W, ctile}.natural(cw) : cw;
     const size_t line = (size_t)z * W + cn, lines = (size_t)n_frames * W;
     T* planes8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs),
                      static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
@@ -1020,7 +987,7 @@ template <typename T, bool SPLIT_MID>
 __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                                   const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                                   unsigned W, unsigned H, unsigned K8, unsigned K16,
-                                                                  unsigned n_frames, unsigned groups, unsigned tiles_c, unsigned class_major) {
+                                                                  unsigned n_frames, unsigned groups, unsigned tiles_c, unsigned class_major, unsigned ctile) {
     __shared__ T s[16][32][9];
     const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = SPLIT_MID ? H / 16 : (H / 8 + 1) / 2;      // H16: units
     const unsigned z = blockIdx.x / (groups * tiles_c);
@@ -1031,7 +998,7 @@ __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* 
     // class-major input: lane cl takes NATURAL column c0 + cl, i.e. memory column inverse_class_pos(c0 + cl) -- the loads
     // of a row are four 32-byte runs (one per residue class) and the stores below stay runs of consecutive operand lines
     const unsigned coln = c0 + cl < W ? c0 + cl : W - 1;
-    const unsigned col = class_major ? inverse_class_pos(coln, W) : coln;
+    const unsigned col = class_major ? inverse_class_pos(coln, W, ctile) : coln;
     auto ld = [&](unsigned r) { return (T)Pz[(size_t)r * W + col]; };
     T* P8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs), static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
     T* P16[4] = {static_cast<T*>(dp.as2), static_cast<T*>(dp.bd2), static_cast<T*>(dp.ad2), static_cast<T*>(dp.bs2)};
@@ -1305,8 +1272,11 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
     if (semi && class_major) return SSW_ERR_BAD_ARG;
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
     const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the SD plane
+    if (dct_pair_prep_staged_cols_ok(w, class_major))
+        return launch_prep16_cols_staged(st, in, n_frames, w, h, base, rot1, rot2, class_major, semi, K8, K16);
     const unsigned units = semi ? (unsigned)(((h / 8 + 1) / 2 + 3) & ~(size_t)3) : K16;
-    const unsigned cm = !class_major ? 0u : (w % 256 == 0 && w >= 6144) ? 2u : 1u;      // 8K: 7.1 -> 6.5 ms; 4K: 7.6 -> 7.8
+    const unsigned ctile = dct_pair_class_tile(w);
+    const unsigned cm = !class_major ? 0u : (ctile == w && w % 256 == 0 && w >= 6144) ? 2u : 1u;      // 8K: 7.1 -> 6.5 ms; 4K: 7.6 -> 7.8
     const unsigned tiles_e = (units + 31) / 32, tiles_c = cm == 2 ? (unsigned)(w / 256) : (unsigned)((w + 31) / 32);
     const unsigned long long nblk = (unsigned long long)tiles_e * tiles_c * n_frames;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
@@ -1317,8 +1287,8 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
     dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
     p += 6 * p8;
     dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;      // semi: as2 = the SD plane, the others unused
-    if (semi) pair_prep16_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, 0u);
-    else      pair_prep16_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, cm);
+    if (semi) pair_prep16_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, 0u, ctile);
+    else      pair_prep16_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, cm, ctile);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
@@ -1340,6 +1310,8 @@ int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_fr
     if (!dct_pair_can_deep_inv_rows(w) || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t rows = n_frames * h;
     if (rows > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if (dct_pair_prep_staged_rows_ok())
+        return launch_prep16_inv_rows_staged(st, in, rows, w, base, rot1, rot2, (unsigned)dct_pair_split_kpad(w), (unsigned)dct_pair_split_kpad(w / 2));
     unsigned tp = 1;
     while (tp < w / 128) tp <<= 1;                                  // threads per line, <= 256
     const unsigned lpb = 256 / tp;
@@ -1358,6 +1330,8 @@ int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_fr
     if (semi && class_major) return SSW_ERR_BAD_ARG;
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
     const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the c[4q+2] plane
+    if (dct_pair_prep_staged_cols_ok(w, class_major))
+        return launch_prep16_inv_cols_staged(st, in, n_frames, w, h, base, rot1, rot2, class_major, semi, K8, K16);
     // groups of 8 units: K16 / 8 covers the padding of the n/16-wide planes; semi: the units (and the R planes' padding up to K8)
     const unsigned groups = semi ? (unsigned)((K8 / 2 + 7) / 8) : K16 / 8, tiles_c = (unsigned)((w + 31) / 32);
     const unsigned long long nblk = (unsigned long long)groups * tiles_c * n_frames;
@@ -1369,8 +1343,8 @@ int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_fr
     dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
     p += 6 * p8;
     dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;      // semi: as2 = the c[4q+2] plane, the others unused
-    if (semi) pair_prep16_inv_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, 0u);
-    else      pair_prep16_inv_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, class_major ? 1u : 0u);
+    if (semi) pair_prep16_inv_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, 0u, (unsigned)w);
+    else      pair_prep16_inv_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, class_major ? 1u : 0u, dct_pair_class_tile(w));
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

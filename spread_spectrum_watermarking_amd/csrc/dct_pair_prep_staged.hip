@@ -1,0 +1,587 @@
+// Deep pre-passes, r4: the three HBM-bound pre-passes that r3 left at 31-43 % of HBM -- forward columns, inverse rows,
+// inverse columns (dct_pair_prep.hip: pair_prep16_cols_kernel, pair_prep16_inv_rows_kernel, pair_prep16_inv_cols_kernel)
+// -- with every result staged through LDS in the layout of the k-blocked operand planes, so that
+//   * a global read is a run of >= 512 contiguous bytes per row (column passes: one class-major tile of 128 memory
+//     columns, dct_pair_common.hpp) or >= 512 bytes per line (row pass: 8 neighbouring 64-byte regions), and
+//   * a global store instruction writes 16 bytes per lane of ONE contiguous run: the 64-byte k-block pieces of 128
+//     (column passes) or 32 (row pass) consecutive operand lines = 8 KB / 2 KB.
+// (r3: 32-byte pieces of lines 8 or 16 apart, 8-byte stores for the mirrored halves at 4K, four 32-byte read runs per
+// row: PMC traffic 1.4-2.1 x the algorithmic bytes.)  Same operations in the same order per operand element as the r3
+// kernels -- the operand planes are bit-identical (tools/prep_check.py), so is every result downstream.
+//
+// Reference: src/dct2d.rs:172-206 is the column pass whose strided gather / scatter these kernels replace; the f32
+// store between the two passes (:152-168) stays where it was (the input of the column kernels IS that f32 plane).
+#include "dct_pair_split.hpp"
+
+#include <cstdlib>
+
+namespace ssw {
+
+namespace {
+
+constexpr unsigned CT = 128;                  // operand lines of a column-pass block = the class-major tile
+constexpr unsigned SLABD = CT * 8;            // doubles of one LDS slab: CT lines x one 64-byte k-block piece
+
+// Slab addressing: double j of line l sits at l * 8 + (j ^ sw(l)).  sw() spreads the lines that the 16 lanes of a
+// ds_write_b64 group touch (4 columns apart in memory = 4, 8 or 16 lines apart) over the LDS banks.
+// MODE 0: natural column order, 1: forward class-major tile, 2: inverse class-major tile.
+template <int MODE>
+__device__ inline unsigned slab_sw(unsigned l) {
+    if (MODE == 1) return ((2u * ((l >> 5) & 3u)) | ((l >> 2) & 1u)) ^ (2u * ((l >> 3) & 1u));
+    if (MODE == 2) return (l >> 4) & 7u;
+    return (l >> 2) & 7u;
+}
+// operand line (inside the tile) of memory column m of the tile
+template <int MODE>
+__device__ inline unsigned tile_line(unsigned m) {
+    if (MODE == 1) return ForwardClassLayout{CT, CT}.natural(m);
+    if (MODE == 2) return inverse_class_natural(m, CT, CT);
+    return m;
+}
+// memory quad (4 columns) of lane l32 of a half-wave.  Forward tile: the quads of the classes with odd lines (EP EM OP
+// OM) are interleaved with the even ones, so that a 16-lane write group holds 8 even and 8 odd lines.
+template <int MODE>
+__device__ inline unsigned lane_quad(unsigned l32) {
+    return MODE == 1 ? ((l32 & 7u) | ((l32 & 8u) << 1) | ((l32 & 16u) >> 1)) : l32;
+}
+
+// Entries j (bit j of `mask`, block-uniform) of all lines of a slab -> plane[k0 + j] of the operand lines
+// line_base + l, l < nl.  Consecutive lanes store consecutive 16-byte chunks: 16 lines x 64 bytes per wave instruction
+// when the piece is whole.  An odd k0 (semi-deep: H/8 odd) stores single doubles.
+template <int MODE>
+__device__ inline void slab_store(const double* __restrict__ slab, double* __restrict__ plane, size_t lines_total, size_t line_base,
+                                  unsigned nl, unsigned k0, unsigned mask, unsigned tid) {
+    if (mask == 0) return;
+    if ((k0 & 1u) == 0) {
+#pragma unroll
+        for (unsigned it = 0; it < CT * 4 / 256; ++it) {
+            const unsigned w = tid + 256 * it, l = w >> 2, c = w & 3u;
+            const unsigned m2 = (mask >> (2 * c)) & 3u;
+            if (l >= nl || m2 == 0) continue;
+            const unsigned sw = slab_sw<MODE>(l);
+            f64x2 v = *reinterpret_cast<const f64x2*>(slab + l * 8 + 2 * (c ^ (sw >> 1)));
+            if (sw & 1u) v = (f64x2){v[1], v[0]};
+            const unsigned k = k0 + 2 * c;
+            double* o = plane + ((size_t)(k >> 3) * lines_total + line_base + l) * 8 + (k & 7u);
+            if (m2 == 3u) *reinterpret_cast<f64x2*>(o) = v;
+            else if (m2 == 1u) o[0] = v[0];
+            else o[1] = v[1];
+        }
+    } else {
+#pragma unroll
+        for (unsigned it = 0; it < CT * 8 / 256; ++it) {
+            const unsigned w = tid + 256 * it, l = w >> 3, j = w & 7u;
+            if (l >= nl || !((mask >> j) & 1u)) continue;
+            const unsigned k = k0 + j;
+            plane[((size_t)(k >> 3) * lines_total + line_base + l) * 8 + (k & 7u)] = slab[l * 8 + (j ^ slab_sw<MODE>(l))];
+        }
+    }
+}
+
+// zeros for plane[k] of the lines line_base + l (l < nl), k in [ka, kb)
+__device__ inline void zero_range(double* __restrict__ plane, size_t lines_total, size_t line_base, unsigned nl, unsigned ka, unsigned kb, unsigned tid) {
+    const unsigned nk = kb > ka ? kb - ka : 0;
+    for (unsigned w = tid; w < nl * nk; w += 256) {
+        const unsigned l = w / nk, k = ka + w % nk;
+        plane[((size_t)(k >> 3) * lines_total + line_base + l) * 8 + (k & 7u)] = 0.0;
+    }
+}
+
+// split_one (dct_pair_split.hpp) with the four table values already in registers: {cos e, sin e, cos m, sin m} of the unit
+// and its rotation partner -- the table reads are issued with the data loads instead of after them
+struct Rot4 { double cc, ss, ccm, ssm; };
+__device__ inline Rot4 rot_load(const double* __restrict__ rot, unsigned e, unsigned Mh) {
+    return Rot4{rot[e], rot[Mh + e], rot[Mh - 1 - e], rot[2 * Mh - 1 - e]};
+}
+__device__ inline void split_one_r(double d0, double d1, double d2, double d3, const Rot4& r, double& as, double& bd, double& ad, double& bs) {
+    const double a = d0 * r.cc + d3 * r.ss, b = d3 * r.cc - d0 * r.ss;
+    const double am = d1 * r.ccm + d2 * r.ssm, bm = d2 * r.ccm - d1 * r.ssm;
+    as = a + am;
+    ad = a - am;
+    bs = b + bm;
+    bd = b - bm;
+}
+
+// XCD-aware block order: blocks b, b + 8, ... run on one XCD; give each XCD a contiguous run of work ids, so that the
+// blocks that complete each other's partly written 128-byte lines (neighbouring unit groups) share an L2
+__device__ inline unsigned xcd_contiguous_id(unsigned bid, unsigned nblk) {
+    const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward column pass (H % 16 == 0; SPLIT_SD = false: "semi-deep", H % 8 == 0 only -- see pair_prep16_cols_kernel).
+// Block = one class-major tile of CT memory columns x one group of 8 units e = 8 g + u; thread = (unit u, memory quad):
+// the 16 rows that meet in e (row v mirrors row 15 - v), 4 columns each.  Three LDS rounds of up to six slabs:
+//   A  AS BD AD BS R1 R2 at unit e                       -> k-block g, whole 64-byte pieces
+//   B  the same planes at the mirror units H/8 - 1 - e' of e' = 8 g - s + u, s = (8 - H/8 mod 8) mod 8: the shift makes
+//      the mirrored range a whole k-block too (4K: H/8 = 270, s = 2; measured with the unshifted range, whose stores
+//      are 16 + 48 bytes of two pieces: 3.42 ms per 128 frames against 2.92 with whole pieces).  These outputs need
+//      rows 1, 2, 5, 6 (and their mirrors) of e' only: for s != 0 the thread loads those 8 rows again -- 6 of the 8
+//      units are this block's own (cache hits), the other s the previous group's (same XCD: xcd_contiguous_id)
+//   C  AS2 BD2 AD2 BS2 at e (semi-deep: SD at e, H/8-1-e, H/8+e, H/4-1-e)
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool SPLIT_SD>
+__global__ __launch_bounds__(256) void prep16_cols_staged_kernel(const float* __restrict__ IN, DeepPlanes dp,
+                                                                 const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                                 unsigned W, unsigned H, unsigned K8, unsigned K16,
+                                                                 unsigned n_frames, unsigned groups, unsigned tiles_c, unsigned nwork) {
+    __shared__ __attribute__((aligned(16))) double lds[6 * SLABD];
+    const unsigned id = xcd_contiguous_id(blockIdx.x, nwork);
+    const unsigned g = id % groups, zt = id / groups, ct = zt % tiles_c, z = zt / tiles_c;
+    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, HU = SPLIT_SD ? H / 16 : (H / 8 + 1) / 2;      // HU: units
+    const unsigned tid = threadIdx.x, u = tid >> 5;
+    const unsigned mq = lane_quad<MODE>(tid & 31u);
+    const unsigned col0 = ct * CT;
+    const unsigned nl = W - col0 < CT ? W - col0 : CT;              // lines of this tile (MODE 0 only: the last tile may be short)
+    unsigned off[4], sws[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned l = tile_line<MODE>(4 * mq + i);
+        sws[i] = slab_sw<MODE>(l);
+        off[i] = l * 8;
+    }
+    const unsigned e = 8 * g + u;
+    const bool unit_ok = e < HU;
+    const unsigned ec = unit_ok ? e : 0;                            // table indices stay in range
+    const unsigned sh = (8u - (H8 & 7u)) & 7u;                      // round B's units: e' = e - sh
+    const bool unitb_ok = e >= sh && e - sh < HU;
+    const unsigned eb = unitb_ok ? e - sh : 0;
+    f32x4 x[16], xb[8];
+    const Rot4 ra = rot_load(rot1, ec, Hq), rb = rot_load(rot1, H8 - 1 - eb, Hq);
+    const Rot4 rc = SPLIT_SD ? rot_load(rot2, ec, H8) : Rot4{0, 0, 0, 0};
+    {
+        unsigned c = col0 + 4 * mq;
+        c = c + 4 <= W ? c : W - 4;                                // W % 4 == 0; duplicates are never stored (l >= nl)
+        const float* __restrict__ Pz = IN + (size_t)z * H * W + c;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) x[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (unit_ok) {
+            const unsigned rp[8] = {e, H8 - 1 - e, H8 + e, Hq - 1 - e, Hq + e, 3 * H8 - 1 - e, 3 * H8 + e, Hh - 1 - e};
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                x[v] = *reinterpret_cast<const f32x4*>(Pz + (size_t)rp[v] * W);
+                x[15 - v] = *reinterpret_cast<const f32x4*>(Pz + (size_t)(H - 1 - rp[v]) * W);
+            }
+        }
+        // rows 1, 2, 5, 6 of unit e' and their mirrors (rows 14, 13, 10, 9)
+        if (sh == 0) {
+            xb[0] = x[1]; xb[1] = x[2]; xb[2] = x[5]; xb[3] = x[6]; xb[4] = x[14]; xb[5] = x[13]; xb[6] = x[10]; xb[7] = x[9];
+        } else {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) xb[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (unitb_ok) {
+                const unsigned rq[4] = {H8 - 1 - eb, H8 + eb, 3 * H8 - 1 - eb, 3 * H8 + eb};
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    xb[v] = *reinterpret_cast<const f32x4*>(Pz + (size_t)rq[v] * W);
+                    xb[4 + v] = *reinterpret_cast<const f32x4*>(Pz + (size_t)(H - 1 - rq[v]) * W);
+                }
+            }
+        }
+    }
+    double* P8[6] = {static_cast<double*>(dp.as), static_cast<double*>(dp.bd), static_cast<double*>(dp.ad), static_cast<double*>(dp.bs),
+                     static_cast<double*>(dp.r1), static_cast<double*>(dp.r2)};
+    double* P16[4] = {static_cast<double*>(dp.as2), static_cast<double*>(dp.bd2), static_cast<double*>(dp.ad2), static_cast<double*>(dp.bs2)};
+    const size_t lines = (size_t)n_frames * W, line_base = (size_t)z * W + col0;
+    const unsigned nv = 8 * g >= HU ? 0u : (HU - 8 * g < 8 ? HU - 8 * g : 8u);       // valid units of the group
+    const unsigned mlo = (1u << nv) - 1u, mhi = (0xFFu << (8 - nv)) & 0xFFu;           // entries u / 7 - u of the valid units
+    // round B: entries 7 - u of the units e' < HU; e' < 0 are k >= H/8: the planes' zero padding (K8 >= the whole piece)
+    const unsigned nvb = 8 * g >= HU + sh ? 0u : (HU + sh - 8 * g < 8 ? HU + sh - 8 * g : 8u);
+    const unsigned mhib = (0xFFu << (8 - nvb)) & 0xFFu;
+    const unsigned um = 7 - u;
+
+    // ---- round A: unit e
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double D[8], S[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            S[v] = (double)x[v][i] + (double)x[15 - v][i];
+            D[v] = (double)x[v][i] - (double)x[15 - v][i];
+        }
+        double o[6] = {0, 0, 0, 0, 0, 0};
+        split_one_r(D[0], D[3], D[4], D[7], ra, o[0], o[1], o[2], o[3]);
+        const double ss0 = S[0] + S[7], ss3 = S[3] + S[4];
+        o[4] = ss0 + ss3;
+        o[5] = ss0 - ss3;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) lds[a * SLABD + off[i] + (u ^ sws[i])] = unit_ok ? o[a] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 6; ++a) slab_store<MODE>(lds + a * SLABD, P8[a], lines, line_base, nl, 8 * g, mlo, tid);
+    __syncthreads();
+    // ---- round B: the mirror units H/8 - 1 - e' (a whole k-block: H/8 + sh is a multiple of 8)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double S1 = (double)xb[0][i] + (double)xb[4][i], D1 = (double)xb[0][i] - (double)xb[4][i];
+        const double S2 = (double)xb[1][i] + (double)xb[5][i], D2 = (double)xb[1][i] - (double)xb[5][i];
+        const double S5 = (double)xb[2][i] + (double)xb[6][i], D5 = (double)xb[2][i] - (double)xb[6][i];
+        const double S6 = (double)xb[3][i] + (double)xb[7][i], D6 = (double)xb[3][i] - (double)xb[7][i];
+        double o[6] = {0, 0, 0, 0, 0, 0};
+        split_one_r(D1, D2, D5, D6, rb, o[0], o[1], o[2], o[3]);
+        const double ss1 = S1 + S6, ss2 = S2 + S5;
+        o[4] = ss1 + ss2;
+        o[5] = ss1 - ss2;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) lds[a * SLABD + off[i] + (um ^ sws[i])] = unitb_ok ? o[a] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 6; ++a) slab_store<MODE>(lds + a * SLABD, P8[a], lines, line_base, nl, H8 + sh - 8 * g - 8, mhib, tid);
+    __syncthreads();
+    // ---- round C: the level-2 difference SD
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double S[8], SD[4];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) S[v] = (double)x[v][i] + (double)x[15 - v][i];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) SD[v] = S[v] - S[7 - v];
+        double o[4] = {0, 0, 0, 0};
+        if (SPLIT_SD) split_one_r(SD[0], SD[1], SD[2], SD[3], rc, o[0], o[1], o[2], o[3]);
+        else { o[0] = SD[0]; o[1] = SD[1]; o[2] = SD[2]; o[3] = SD[3]; }      // SD at e, H/8-1-e, H/8+e, H/4-1-e
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const unsigned ent = (SPLIT_SD || !(a & 1)) ? u : um;
+            lds[a * SLABD + off[i] + (ent ^ sws[i])] = unit_ok ? o[a] : 0.0;
+        }
+    }
+    __syncthreads();
+    if (SPLIT_SD) {
+        // zeros beyond H/16 up to the end of the group (the planes are K16 >= 8 groups wide)
+        const unsigned mk = 8 * g + 8 <= K16 ? 0xFFu : (8 * g >= K16 ? 0u : (1u << (K16 - 8 * g)) - 1u);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) slab_store<MODE>(lds + a * SLABD, P16[a], lines, line_base, nl, 8 * g, mk, tid);
+    } else {
+        double* M = P16[0];
+        slab_store<MODE>(lds + 0 * SLABD, M, lines, line_base, nl, 8 * g, mlo, tid);
+        slab_store<MODE>(lds + 1 * SLABD, M, lines, line_base, nl, H8 - 8 * g - 8, mhi, tid);
+        slab_store<MODE>(lds + 2 * SLABD, M, lines, line_base, nl, H8 + 8 * g, mlo, tid);
+        slab_store<MODE>(lds + 3 * SLABD, M, lines, line_base, nl, Hq - 8 * g - 8, mhi, tid);
+    }
+    if (g == 0) {                                                   // padding of the planes up to their k-padded widths
+#pragma unroll
+        for (int a = 0; a < 6; ++a) zero_range(P8[a], lines, line_base, nl, H8, K8, tid);
+        if (SPLIT_SD) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) zero_range(P16[a], lines, line_base, nl, 8 * groups, K16, tid);
+        } else {
+            zero_range(P16[0], lines, line_base, nl, Hq, K16, tid);                    // K16: kpad(H/2) here
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inverse column pass.  Every operand element of the inverse depends on its own four (or one) coefficient rows only:
+//   AS BD AD BS at unit k < H/8:    rows 2k+1, H/2-1-2k, H/2+2k+1, H-1-2k        (rotation table of H, half length H/4)
+//   R1[k] = row 8k, R2[k] = row 8k+4
+//   AS2 .. BS2 at unit e < H/16:    rows 4e+2, H/2-2-4e, H/2+4e+2, H-2-4e        (table of H/2)
+//   semi-deep (SPLIT_MID = false):  M[q] = row 4q+2, q < H/4
+// so a block takes one k-block (8 units) of one plane group for one tile of CT memory columns and every store is a whole
+// 64-byte piece: task kb < K8/8: AS BD AD BS R1 R2 (six slabs); then kb < K16/8: AS2 BD2 AD2 BS2 (semi-deep: four
+// k-blocks of M per block).  Units beyond the axis store the planes' zero padding.
+// ---------------------------------------------------------------------------------------------
+template <int MODE, bool SPLIT_MID>
+__global__ __launch_bounds__(256) void prep16_inv_cols_staged_kernel(const float* __restrict__ IN, DeepPlanes dp,
+                                                                     const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                                     unsigned W, unsigned H, unsigned K8, unsigned K16,
+                                                                     unsigned n_frames, unsigned tasks0, unsigned tasks1, unsigned tiles_c, unsigned nwork) {
+    __shared__ __attribute__((aligned(16))) double lds[6 * SLABD];
+    const unsigned id = xcd_contiguous_id(blockIdx.x, nwork);
+    const unsigned tasks = tasks0 + tasks1;
+    const unsigned task = id % tasks, zt = id / tasks, ct = zt % tiles_c, z = zt / tiles_c;
+    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = H / 16;
+    const unsigned tid = threadIdx.x, u = tid >> 5;
+    const unsigned mq = lane_quad<MODE>(tid & 31u);
+    const unsigned col0 = ct * CT;
+    const unsigned nl = W - col0 < CT ? W - col0 : CT;
+    unsigned off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned l = tile_line<MODE>(4 * mq + i);
+        off[i] = l * 8 + (u ^ slab_sw<MODE>(l));
+    }
+    unsigned c = col0 + 4 * mq;
+    c = c + 4 <= W ? c : W - 4;
+    const float* __restrict__ Pz = IN + (size_t)z * H * W + c;
+    auto ld = [&](unsigned r) { return *reinterpret_cast<const f32x4*>(Pz + (size_t)r * W); };
+    double* P8[6] = {static_cast<double*>(dp.as), static_cast<double*>(dp.bd), static_cast<double*>(dp.ad), static_cast<double*>(dp.bs),
+                     static_cast<double*>(dp.r1), static_cast<double*>(dp.r2)};
+    double* P16[4] = {static_cast<double*>(dp.as2), static_cast<double*>(dp.bd2), static_cast<double*>(dp.ad2), static_cast<double*>(dp.bs2)};
+    const size_t lines = (size_t)n_frames * W, line_base = (size_t)z * W + col0;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if (task < tasks0) {
+        const unsigned k = 8 * task + u;
+        const bool ok = k < H8;
+        const unsigned kc = ok ? k : 0;
+        const f32x4 d0 = ok ? ld(2 * kc + 1) : z4, d1 = ok ? ld(Hh - 1 - 2 * kc) : z4, d2 = ok ? ld(Hh + 2 * kc + 1) : z4, d3 = ok ? ld(H - 1 - 2 * kc) : z4;
+        const f32x4 r1 = ok ? ld(8 * kc) : z4, r2 = ok ? ld(8 * kc + 4) : z4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double o[4];
+            split_one<double>((double)d0[i], (double)d1[i], (double)d2[i], (double)d3[i], rot1, kc, Hq, o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) lds[a * SLABD + off[i]] = ok ? o[a] : 0.0;
+            lds[4 * SLABD + off[i]] = (double)r1[i];
+            lds[5 * SLABD + off[i]] = (double)r2[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 6; ++a) slab_store<MODE>(lds + a * SLABD, P8[a], lines, line_base, nl, 8 * task, 0xFFu, tid);
+    } else if (SPLIT_MID) {
+        const unsigned kb = task - tasks0, e = 8 * kb + u;
+        const bool ok = e < H16;
+        const unsigned ec = ok ? e : 0;
+        const f32x4 q0 = ok ? ld(4 * ec + 2) : z4, q1 = ok ? ld(Hh - 2 - 4 * ec) : z4, q2 = ok ? ld(Hh + 4 * ec + 2) : z4, q3 = ok ? ld(H - 2 - 4 * ec) : z4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double o[4];
+            split_one<double>((double)q0[i], (double)q1[i], (double)q2[i], (double)q3[i], rot2, ec, H8, o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) lds[a * SLABD + off[i]] = ok ? o[a] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) slab_store<MODE>(lds + a * SLABD, P16[a], lines, line_base, nl, 8 * kb, 0xFFu, tid);
+    } else {
+        const unsigned kb0 = 4 * (task - tasks0);                      // four k-blocks of M = c[4q+2], K16 = kpad(H/2) wide
+        f32x4 v[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const unsigned q = 8 * (kb0 + s) + u;
+            v[s] = q < Hq ? ld(4 * q + 2) : z4;
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds[s * SLABD + off[i]] = (double)v[s][i];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (8 * (kb0 + s) < K16) slab_store<MODE>(lds + s * SLABD, P16[0], lines, line_base, nl, 8 * (kb0 + s), 0xFFu, tid);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inverse row pass (n % 128 == 0).  The eight regions of a thread of pair_prep16_inv_rows_kernel are two independent
+// sets of four; here a thread = (line, tau), tau < n/64, takes the four 16-coefficient regions
+//   g = 16 tau, n/2 - 16 - 16 tau, n/2 + 16 tau, n - 16 - 16 tau
+// that meet in the units k = 8 tau .. 8 tau + 7 of the odd part (c[2k+1]: AS BD AD BS, k-block tau), in the units
+// 4 tau .. 4 tau + 3 of the level-2 odd part (c[4q+2]: AS2 BD2 AD2 BS2, half a k-block) and hold two doubles of R1 = c[8q]
+// and R2 = c[8q+4] each: 64 coefficients in, 64 doubles out.  Block = 32 lines x 8 neighbouring tau: every region is
+// read as 8 x 64 = 512 contiguous bytes per line, and the doubles leave through LDS slabs that are images of the
+// stored runs -- one slab = one 64-byte k-block piece of one plane for the block's 32 lines = 2 KB contiguous in the
+// operand plane.  Four rounds of up to 24 slabs.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned RL = 32;                   // lines per block
+constexpr unsigned RSL = RL * 8 + 2;          // doubles per row-pass slab: 2 KB + 16 bytes (bank spread of the 8 tau of a line)
+constexpr unsigned RNS = 24;                  // slabs
+
+// chunk c (16 bytes) of line l of slab s -> piece `piece` of `plane`; two slabs per sweep of the block
+__device__ inline void rows_store(const double* __restrict__ lds, unsigned nslabs, double* const* planes, const unsigned* pieces, const unsigned* masks,
+                                  size_t rows_total, size_t row_base, unsigned nl, unsigned tid) {
+    const unsigned l = (tid & 127u) >> 2, c = tid & 3u;
+    for (unsigned s = tid >> 7; s < nslabs; s += 2) {
+        if (l >= nl || !((masks[s] >> c) & 1u)) continue;
+        const f64x2 v = *reinterpret_cast<const f64x2*>(lds + s * RSL + l * 8 + 2 * c);
+        *reinterpret_cast<f64x2*>(planes[s] + ((size_t)pieces[s] * rows_total + row_base + l) * 8 + 2 * c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void prep16_inv_rows_staged_kernel(const float* __restrict__ X, DeepPlanes dp,
+                                                                     const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                                     unsigned rows, unsigned W, unsigned K8, unsigned K16, unsigned tblocks) {
+    __shared__ __attribute__((aligned(16))) double lds[RNS * RSL];
+    __shared__ double* s_plane[RNS];
+    __shared__ unsigned s_piece[RNS], s_mask[RNS];
+    const unsigned tid = threadIdx.x, t = tid & 7u, lr = tid >> 3;
+    const unsigned tb = blockIdx.x % tblocks, lb = blockIdx.x / tblocks;
+    const unsigned NT = W / 64;                                     // region sets per line
+    const unsigned tg = 8 * tb + t;
+    const size_t row_base = (size_t)lb * RL;
+    const unsigned nl = rows - row_base < RL ? (unsigned)(rows - row_base) : RL;
+    const bool tok = tg < NT, ok = tok && lr < nl;
+    const unsigned nt = NT - 8 * tb < 8 ? NT - 8 * tb : 8u;         // valid tau of the block
+    const unsigned R = 16 * (tok ? tg : 0);
+    const unsigned Nh = W / 2, Nq = W / 4, N8 = W / 8, N16 = W / 16;
+    // planes 0 .. 5: AS BD AD BS R1 R2 (rows * K8 doubles apart), 6 .. 9: AS2 BD2 AD2 BS2 (rows * K16 apart)
+    auto plane = [&](unsigned a) {
+        return a < 6 ? static_cast<double*>(dp.as) + (size_t)a * rows * K8 : static_cast<double*>(dp.as2) + (size_t)(a - 6) * rows * K16;
+    };
+    const unsigned g[4] = {R, Nh - 16 - R, Nh + R, W - 16 - R};
+    f32x4 c[4][4];
+    if (ok) {
+        const float* xr = X + (row_base + lr) * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[j][q] = *reinterpret_cast<const f32x4*>(xr + g[j] + 4 * q);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // odd coefficients of region j as two ascending quads of k: element 2 i + 1 -> quad i / 4
+    auto odd = [&](int j, int half) { return (f64x4){(double)c[j][2 * half][1], (double)c[j][2 * half][3], (double)c[j][2 * half + 1][1], (double)c[j][2 * half + 1][3]}; };
+    // c[4q+2]: element 2 of every quad of a region, q ascending
+    auto mid = [&](int j) { return (f64x4){(double)c[j][0][2], (double)c[j][1][2], (double)c[j][2][2], (double)c[j][3][2]}; };
+    auto put4 = [&](unsigned slab, unsigned at, const f64x4& v) {
+        *reinterpret_cast<f64x2*>(lds + slab * RSL + lr * 8 + at) = (f64x2){v[0], v[1]};
+        *reinterpret_cast<f64x2*>(lds + slab * RSL + lr * 8 + at + 2) = (f64x2){v[2], v[3]};
+    };
+    auto flush = [&](unsigned nslabs) {
+        __syncthreads();
+        rows_store(lds, nslabs, s_plane, s_piece, s_mask, rows, row_base, nl, tid);
+        __syncthreads();
+    };
+    // ---- rounds 1, 2: AS BD, then AD BS, at k-block tau (the same operations as the units A / mirror of the r3 kernel)
+    {
+        f64x4 as[2], bd[2], ad[2], bs[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            split_unit<double>(odd(0, half), odd(1, 1 - half), odd(2, half), odd(3, 1 - half), rot1, R / 2 + 4 * half, Nq, as[half], bd[half], ad[half], bs[half]);
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (tid < 16) {
+                const unsigned tt = tid & 7u, pp = tid >> 3;
+                s_plane[tid] = plane(2 * rnd + pp);
+                s_piece[tid] = 8 * tb + tt;
+                s_mask[tid] = tt < nt ? 0xFu : 0u;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                put4(t, 4 * half, rnd ? ad[half] : as[half]);
+                put4(8 + t, 4 * half, rnd ? bs[half] : bd[half]);
+            }
+            flush(16);
+        }
+    }
+    // ---- round 3: AS2 BD2 AD2 BS2 at the units 4 tau .. 4 tau + 3: half tau & 1 of piece tau / 2 (8 tb is even)
+    {
+        if (tid < 16) {
+            const unsigned pi = tid & 3u, pp = tid >> 2;            // piece pi of the block (tau = 2 pi, 2 pi + 1), plane pp
+            const unsigned v0 = 2 * pi < nt ? 1u : 0u, v1 = 2 * pi + 1 < nt ? 1u : 0u;
+            s_plane[tid] = plane(6 + pp);
+            s_piece[tid] = 4 * tb + pi;
+            s_mask[tid] = (v0 ? 0x3u : 0u) | (v1 ? 0xCu : 0u);
+        }
+        f64x4 as, bd, ad, bs;
+        split_unit<double>(mid(0), mid(1), mid(2), mid(3), rot2, R / 4, N8, as, bd, ad, bs);
+        const unsigned at = 4 * (t & 1u), sl = t >> 1;
+        put4(sl, at, as); put4(4 + sl, at, bd); put4(8 + sl, at, ad); put4(12 + sl, at, bs);
+        flush(16);
+    }
+    // ---- round 4: R1 = c[8q] (elements 0 of quads 0, 2), R2 = c[8q+4] (quads 1, 3): region j holds the doubles
+    // k = g[j] / 8, k + 1.  The 8 tau of the block cover 16 consecutive doubles per region = two or three pieces:
+    // slab 12 plane + 3 j + (piece - first piece of the block for j)
+    {
+        // k of tau' for region j: ascending regions base + 2 tau', descending ones base - 2 tau'
+        auto kbase = [&](unsigned j) { return j == 0 ? 0u : j == 1 ? Nh / 8 - 2 : j == 2 ? Nh / 8 : W / 8 - 2; };
+        auto kfirst = [&](unsigned j) {                             // smallest k of the block's valid tau
+            return (j & 1u) ? kbase(j) - 2 * (8 * tb + nt - 1) : kbase(j) + 2 * (8 * tb);
+        };
+        if (tid < 24) {
+            const unsigned pl = tid / 12, j = (tid % 12) / 3, pi = tid % 3;
+            const unsigned p0 = kfirst(j) >> 3;
+            unsigned m = 0;
+            for (unsigned tt = 0; tt < nt; ++tt) {
+                const unsigned k = (j & 1u) ? kbase(j) - 2 * (8 * tb + tt) : kbase(j) + 2 * (8 * tb + tt);
+                if ((k >> 3) == p0 + pi) m |= 1u << ((k & 7u) >> 1);
+            }
+            s_plane[tid] = plane(4 + pl);
+            s_piece[tid] = p0 + pi;
+            s_mask[tid] = m;
+        }
+        if (tok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned k = g[j] / 8;
+                const unsigned sl = 3 * j + ((k >> 3) - (kfirst(j) >> 3));
+                *reinterpret_cast<f64x2*>(lds + sl * RSL + lr * 8 + (k & 7u)) = (f64x2){(double)c[j][0][0], (double)c[j][2][0]};
+                *reinterpret_cast<f64x2*>(lds + (12 + sl) * RSL + lr * 8 + (k & 7u)) = (f64x2){(double)c[j][1][0], (double)c[j][3][0]};
+            }
+        }
+        flush(24);
+    }
+    if (tb == 0) {                                                  // zero padding [n/8, K8) and [n/16, K16): whole pieces
+        const unsigned l = tid >> 3, ch = tid & 7u;                  // thread = (line, double of a piece)
+        if (l < nl) {
+            for (unsigned k = N8 + ch; k < K8; k += 8)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) plane(a)[((size_t)(k >> 3) * rows + row_base + l) * 8 + (k & 7u)] = 0.0;
+            for (unsigned k = N16 + ch; k < K16; k += 8)
+#pragma unroll
+                for (int a = 6; a < 10; ++a) plane(a)[((size_t)(k >> 3) * rows + row_base + l) * 8 + (k & 7u)] = 0.0;
+        }
+    }
+}
+
+bool staged_enabled() {
+    static const int on = [] { const char* e = std::getenv("SSW_PREP_STAGED"); return e ? std::atoi(e) : 1; }();
+    return on != 0;
+}
+
+DeepPlanes planes_of(double* base, size_t lines, unsigned K8, unsigned K16) {
+    DeepPlanes dp;
+    double* p = base;
+    const size_t p8 = lines * K8, p16 = lines * K16;
+    dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
+    p += 6 * p8;
+    dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
+    return dp;
+}
+
+}  // namespace
+
+// The staged kernels take: natural column order (any W % 4 == 0), or class-major tiles of exactly CT columns.
+bool dct_pair_prep_staged_cols_ok(size_t w, bool class_major) {
+    return staged_enabled() && w % 4 == 0 && w >= 4 && (!class_major || dct_pair_class_tile(w) == CT);
+}
+bool dct_pair_prep_staged_rows_ok() { return staged_enabled(); }
+
+int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                              const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16) {
+    const unsigned HU = semi ? (unsigned)((h / 8 + 1) / 2) : (unsigned)(h / 16);
+    const unsigned sh = (8u - (unsigned)((h / 8) & 7)) & 7u;       // shift of the mirrored units (kernel comment, round B)
+    const unsigned groups = (HU + sh + 7) / 8, tiles_c = (unsigned)((w + CT - 1) / CT);
+    const unsigned long long nwork = (unsigned long long)groups * tiles_c * n_frames;
+    if (nwork > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const DeepPlanes dp = planes_of(base, n_frames * w, K8, K16);
+#define SSW_L(MODEV, SPLITV) prep16_cols_staged_kernel<MODEV, SPLITV><<<(unsigned)nwork, 256, 0, st>>>( \
+        in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, (unsigned)nwork)
+    if (class_major) { if (semi) SSW_L(1, false); else SSW_L(1, true); }
+    else             { if (semi) SSW_L(0, false); else SSW_L(0, true); }
+#undef SSW_L
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+int launch_prep16_inv_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                                  const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16) {
+    const unsigned tasks0 = K8 / 8, tasks1 = semi ? (K16 / 8 + 3) / 4 : K16 / 8, tiles_c = (unsigned)((w + CT - 1) / CT);
+    const unsigned long long nwork = (unsigned long long)(tasks0 + tasks1) * tiles_c * n_frames;
+    if (nwork > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const DeepPlanes dp = planes_of(base, n_frames * w, K8, K16);
+#define SSW_L(MODEV, SPLITV) prep16_inv_cols_staged_kernel<MODEV, SPLITV><<<(unsigned)nwork, 256, 0, st>>>( \
+        in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tasks0, tasks1, tiles_c, (unsigned)nwork)
+    if (class_major) { if (semi) SSW_L(2, false); else SSW_L(2, true); }
+    else             { if (semi) SSW_L(0, false); else SSW_L(0, true); }
+#undef SSW_L
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+int launch_prep16_inv_rows_staged(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
+                                  const double* rot1, const double* rot2, unsigned K8, unsigned K16) {
+    const unsigned NT = (unsigned)(w / 64), tblocks = (NT + 7) / 8;
+    const unsigned long long nblk = (unsigned long long)((rows + RL - 1) / RL) * tblocks;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    prep16_inv_rows_staged_kernel<<<(unsigned)nblk, 256, 0, st>>>(in, planes_of(base, rows, K8, K16), rot1, rot2, (unsigned)rows, (unsigned)w, K8, K16, tblocks);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+}  // namespace ssw

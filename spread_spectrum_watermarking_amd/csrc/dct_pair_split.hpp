@@ -1,0 +1,48 @@
+// The rotation + fold of the split odd half (dct_pair_prep.hip, "Split odd half") and the operand planes of a deep
+// pass: shared by the pre-pass kernels of dct_pair_prep.hip and dct_pair_prep_staged.hip.
+#pragma once
+#include "dct_pair_common.hpp"
+
+namespace ssw {
+
+// the same for a single e (scalar kernels)
+template <typename T>
+__device__ inline void split_one(T d0, T d1, T d2, T d3, const double* __restrict__ rot, unsigned e, unsigned Mh, T& as, T& bd, T& ad, T& bs) {
+    const T cc = (T)rot[e], ss = (T)rot[Mh + e], ccm = (T)rot[Mh - 1 - e], ssm = (T)rot[2 * Mh - 1 - e];
+    const T a = d0 * cc + d3 * ss, b = d3 * cc - d0 * ss;
+    const T am = d1 * ccm + d2 * ssm, bm = d2 * ccm - d1 * ssm;
+    as = a + am;
+    ad = a - am;
+    bs = b + bm;
+    bd = b - bm;
+}
+// One unit of the split: four consecutive e = base .. base + 3 of a DCT-IV input d of length M (Mh = M/2) given as
+// ascending quads  dA: d[base + i], dB: d[Mh-4-base + i], dC: d[Mh+base + i], dD: d[M-4-base + i];
+// rot: [0, Mh) cos psi, [Mh, 2 Mh) sin psi.  Same operations in the same order as pair_rotate_kernel.
+template <typename T>
+__device__ inline void split_unit(const vec4_t<T>& dA, const vec4_t<T>& dB, const vec4_t<T>& dC, const vec4_t<T>& dD,
+                                  const double* __restrict__ rot, unsigned base, unsigned Mh,
+                                  vec4_t<T>& as, vec4_t<T>& bd, vec4_t<T>& ad, vec4_t<T>& bs) {
+    const f64x4 c = *reinterpret_cast<const f64x4*>(rot + base), s = *reinterpret_cast<const f64x4*>(rot + Mh + base);
+    const f64x4 cm = *reinterpret_cast<const f64x4*>(rot + Mh - 4 - base), sm = *reinterpret_cast<const f64x4*>(rot + 2 * Mh - 4 - base);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const T d0 = dA[i], d1 = dB[3 - i], d2 = dC[i], d3 = dD[3 - i];
+        const T cc = (T)c[i], ss = (T)s[i], ccm = (T)cm[3 - i], ssm = (T)sm[3 - i];
+        const T a = d0 * cc + d3 * ss, b = d3 * cc - d0 * ss;
+        const T am = d1 * ccm + d2 * ssm, bm = d2 * ccm - d1 * ssm;
+        as[i] = a + am;
+        ad[i] = a - am;
+        bs[i] = b + bm;
+        bd[i] = b - bm;
+    }
+}
+
+struct DeepPlanes {        // device pointers of one pass's operand planes
+    void *as, *bd, *ad, *bs;         // K8 wide
+    void *r1, *r2;                   // K8 wide
+    void *as2, *bd2, *ad2, *bs2;     // K16 wide
+};
+
+
+}  // namespace ssw

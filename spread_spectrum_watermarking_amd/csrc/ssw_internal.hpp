@@ -135,6 +135,16 @@ int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1,
 // 2 cosO, 3 sinO), the rotation table of an axis, and the pass that turns an odd operand plane into AS | BD | AD | BS
 bool dct_pair_can_split(size_t len, bool is_row);
 size_t dct_pair_split_kpad(size_t len);
+unsigned dct_pair_class_tile(size_t len);               // tile width of the class-major plane orders (dct_pair_common.hpp)
+// LDS-staged forms of the deep pre-passes (dct_pair_prep_staged.hip; SSW_PREP_STAGED=0 keeps the r3 kernels)
+bool dct_pair_prep_staged_cols_ok(size_t w, bool class_major);
+bool dct_pair_prep_staged_rows_ok();
+int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                              const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16);
+int launch_prep16_inv_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                                  const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16);
+int launch_prep16_inv_rows_staged(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
+                                  const double* rot1, const double* rot2, unsigned K8, unsigned K16);
 size_t dct_pair_split_elems(size_t n_frames, size_t w, size_t h);
 size_t dct_pair_split_basis_rows(size_t len, int which);
 int launch_make_split_basis_blocked(hipStream_t st, size_t n, bool inverse, int which, double* out);
