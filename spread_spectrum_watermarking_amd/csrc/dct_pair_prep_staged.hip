@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void prep16_cols_staged_kernel(const float* __
 //   AS2 .. BS2 at unit e < H/16:    rows 4e+2, H/2-2-4e, H/2+4e+2, H-2-4e        (table of H/2)
 //   semi-deep (SPLIT_MID = false):  M[q] = row 4q+2, q < H/4
 // so a block takes one k-block (8 units) of one plane group for one tile of CT memory columns and every store is a whole
-// 64-byte piece: task kb < K8/8: AS BD AD BS R1 R2 (six slabs); then kb < K16/8: AS2 BD2 AD2 BS2 (semi-deep: four
+// 64-byte piece: task kb < K8/8: AS BD AD BS R1 R2 (six slabs); then kb < K16/8: AS2 BD2 AD2 BS2 (semi-deep: three
 // k-blocks of M per block).  Units beyond the axis store the planes' zero padding.
 // ---------------------------------------------------------------------------------------------
 template <int MODE, bool SPLIT_MID>
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void prep16_inv_cols_staged_kernel(const float
                                                                      const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                                      unsigned W, unsigned H, unsigned K8, unsigned K16,
                                                                      unsigned n_frames, unsigned tasks0, unsigned tasks1, unsigned tiles_c, unsigned nwork) {
-    __shared__ __attribute__((aligned(16))) double lds[6 * SLABD];
+    __shared__ __attribute__((aligned(16))) double lds[3 * SLABD];
     const unsigned id = xcd_contiguous_id(blockIdx.x, nwork);
     const unsigned tasks = tasks0 + tasks1;
     const unsigned task = id % tasks, zt = id / tasks, ct = zt % tiles_c, z = zt / tiles_c;
@@ -318,48 +318,61 @@ __global__ __launch_bounds__(256) void prep16_inv_cols_staged_kernel(const float
         const unsigned kc = ok ? k : 0;
         const f32x4 d0 = ok ? ld(2 * kc + 1) : z4, d1 = ok ? ld(Hh - 1 - 2 * kc) : z4, d2 = ok ? ld(Hh + 2 * kc + 1) : z4, d3 = ok ? ld(H - 1 - 2 * kc) : z4;
         const f32x4 r1 = ok ? ld(8 * kc) : z4, r2 = ok ? ld(8 * kc + 4) : z4;
+        const Rot4 rr = rot_load(rot1, kc, Hq);
+        double o[4][6];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            double o[4];
-            split_one<double>((double)d0[i], (double)d1[i], (double)d2[i], (double)d3[i], rot1, kc, Hq, o[0], o[1], o[2], o[3]);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) lds[a * SLABD + off[i]] = ok ? o[a] : 0.0;
-            lds[4 * SLABD + off[i]] = (double)r1[i];
-            lds[5 * SLABD + off[i]] = (double)r2[i];
+            split_one_r((double)d0[i], (double)d1[i], (double)d2[i], (double)d3[i], rr, o[i][0], o[i][1], o[i][2], o[i][3]);
+            o[i][4] = (double)r1[i];
+            o[i][5] = (double)r2[i];
         }
-        __syncthreads();
+        // two rounds of three slabs (24 KB of LDS: six blocks per CU)
 #pragma unroll
-        for (int a = 0; a < 6; ++a) slab_store<MODE>(lds + a * SLABD, P8[a], lines, line_base, nl, 8 * task, 0xFFu, tid);
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (rnd) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) lds[a * SLABD + off[i]] = ok ? o[i][3 * rnd + a] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 3; ++a) slab_store<MODE>(lds + a * SLABD, P8[3 * rnd + a], lines, line_base, nl, 8 * task, 0xFFu, tid);
+        }
     } else if (SPLIT_MID) {
         const unsigned kb = task - tasks0, e = 8 * kb + u;
         const bool ok = e < H16;
         const unsigned ec = ok ? e : 0;
         const f32x4 q0 = ok ? ld(4 * ec + 2) : z4, q1 = ok ? ld(Hh - 2 - 4 * ec) : z4, q2 = ok ? ld(Hh + 4 * ec + 2) : z4, q3 = ok ? ld(H - 2 - 4 * ec) : z4;
+        const Rot4 rr = rot_load(rot2, ec, H8);
+        double o[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double o[4];
-            split_one<double>((double)q0[i], (double)q1[i], (double)q2[i], (double)q3[i], rot2, ec, H8, o[0], o[1], o[2], o[3]);
+        for (int i = 0; i < 4; ++i) split_one_r((double)q0[i], (double)q1[i], (double)q2[i], (double)q3[i], rr, o[i][0], o[i][1], o[i][2], o[i][3]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) lds[a * SLABD + off[i]] = ok ? o[a] : 0.0;
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (rnd) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) lds[a * SLABD + off[i]] = ok ? o[i][2 * rnd + a] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 2; ++a) slab_store<MODE>(lds + a * SLABD, P16[2 * rnd + a], lines, line_base, nl, 8 * kb, 0xFFu, tid);
         }
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 4; ++a) slab_store<MODE>(lds + a * SLABD, P16[a], lines, line_base, nl, 8 * kb, 0xFFu, tid);
     } else {
-        const unsigned kb0 = 4 * (task - tasks0);                      // four k-blocks of M = c[4q+2], K16 = kpad(H/2) wide
-        f32x4 v[4];
+        const unsigned kb0 = 3 * (task - tasks0);                      // three k-blocks of M = c[4q+2], K16 = kpad(H/2) wide
+        f32x4 v[3];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < 3; ++s) {
             const unsigned q = 8 * (kb0 + s) + u;
             v[s] = q < Hq ? ld(4 * q + 2) : z4;
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 3; ++s)
 #pragma unroll
             for (int i = 0; i < 4; ++i) lds[s * SLABD + off[i]] = (double)v[s][i];
         __syncthreads();
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 3; ++s)
             if (8 * (kb0 + s) < K16) slab_store<MODE>(lds + s * SLABD, P16[0], lines, line_base, nl, 8 * (kb0 + s), 0xFFu, tid);
     }
 }
@@ -561,7 +574,7 @@ int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, 
 
 int launch_prep16_inv_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                   const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16) {
-    const unsigned tasks0 = K8 / 8, tasks1 = semi ? (K16 / 8 + 3) / 4 : K16 / 8, tiles_c = (unsigned)((w + CT - 1) / CT);
+    const unsigned tasks0 = K8 / 8, tasks1 = semi ? (K16 / 8 + 2) / 3 : K16 / 8, tiles_c = (unsigned)((w + CT - 1) / CT);
     const unsigned long long nwork = (unsigned long long)(tasks0 + tasks1) * tiles_c * n_frames;
     if (nwork > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     const DeepPlanes dp = planes_of(base, n_frames * w, K8, K16);
