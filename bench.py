@@ -162,27 +162,93 @@ MAIN_KERNEL_NOTE = {
 }
 
 
-def attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff):
-    """HBM-side traffic of the dominant kernel: PMC counters collected offline exactly as MI355X_MICROARCH.md
-    prescribes (separate --pmc passes, gfx950 FETCH_SIZE x2 correction) and committed under profiles/ with the
-    commit they were collected at; quoted only for the workload they were collected on."""
+def load_pmc(W, H, chunk_eff):
+    """The newest committed PMC summary for this workload (profiles/r*_pmc_traffic*.json): HBM-side traffic collected
+    offline exactly as MI355X_MICROARCH.md prescribes (separate --pmc passes, gfx950 FETCH_SIZE x2 correction), stamped
+    with the commit it was collected at; quoted only for the workload it was collected on."""
     import glob
-    names = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True)
-    for path in names:
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             pmc = json.load(open(path))
             wl = pmc["workload"]
-            if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, chunk_eff) and roofline["kernel"] in pmc["kernels"]:
-                roofline["traffic"] = pmc["kernels"][roofline["kernel"]]["hbm_bytes_per_launch"]
-                roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
-                roofline["traffic_source"] = f"profiles/{os.path.basename(path)} (collected at commit {pmc.get('commit', '?')})"
-                roofline["algorithmic_bytes_per_launch"] = pmc["kernels"][roofline["kernel"]].get("algorithmic_bytes_per_launch")
-                busy = pmc["kernels"][roofline["kernel"]].get("mfma_busy_over_active_cycles")
-                if busy is not None:     # cycles, not seconds: what the kernel does with the clock it gets (DESIGN.md 4.1)
-                    roofline["mfma_busy_over_active_cycles"] = busy
-                return
+            if (wl["width"], wl["height"], wl["chunk_frames"]) == (W, H, chunk_eff):
+                pmc["_source"] = f"profiles/{os.path.basename(path)} (collected at commit {pmc.get('commit', '?')})"
+                return pmc
         except (OSError, KeyError, ValueError):
             pass
+    return None
+
+
+def attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff):
+    """Per-launch traffic of one named launch (the `best_launch` sub-block)."""
+    pmc = load_pmc(W, H, chunk_eff)
+    if pmc and roofline["kernel"] in pmc.get("kernels", {}):
+        k = pmc["kernels"][roofline["kernel"]]
+        roofline["traffic"] = k["hbm_bytes_per_launch"]
+        roofline["traffic_unit"] = "bytes/launch (L2<->fabric, incl. Infinity-Cache hits)"
+        roofline["traffic_source"] = pmc["_source"]
+        roofline["algorithmic_bytes_per_launch"] = k.get("algorithmic_bytes_per_launch")
+        if k.get("mfma_busy_over_active_cycles") is not None:     # cycles, not seconds: what the kernel does with the clock it gets
+            roofline["mfma_busy_over_active_cycles"] = k["mfma_busy_over_active_cycles"]
+
+
+def family_rooflines(prec_name, stage, steps, W, H, chunk_eff, frames_per_step):
+    """The two blocks that describe the STEP (verdict r3 #2): `roofline` = every GEMM launch of the step (the
+    pair_gemm kernel family: row and column passes of the forward, inverse and pruned transforms), executed flop /
+    summed duration; `roofline_hbm` = every deep pre-pass launch (rocprofv3 names containing "prep16": the RGB -> operand
+    pre-passes timed as stage rgb_to_yiq and the transposing / inverse ones timed as stage dct_prep), algorithmic bytes /
+    summed duration.  Flop and bytes are counted by the library per launch; durations are hipEvent pairs on the stream
+    each stage runs on.  `share_of_step` = the family's share of the summed kernel time of all stages (two lanes overlap in
+    wall time).  `best_launch` keeps r3's single-launch block (class E of the split odd half of a forward row pass)."""
+    peak = PEAK_F64_MFMA_TFLOPS if prec_name == "f64" else PEAK_F32_MFMA_TFLOPS
+    all_ms = sum(v["ms"] for k, v in stage.items() if not k.endswith("_main"))
+    gemm_ms = stage["dct_row"]["ms"] + stage["dct_col"]["ms"]
+    executed = stage["dct_row"]["work"] + stage["dct_col"]["work"]
+    tf = rate(executed, gemm_ms) / 1e12
+    fam = f"pair_gemm_{prec_name}_kernel"
+    main_ms, main_n = stage["dct_row_main"]["ms"], max(stage["dct_row_main"]["launches"], 1)
+    main_tf = rate(stage["dct_row_main"]["work"], main_ms) / 1e12
+    best = {"kernel": main_kernel_label(prec_name), "instance": main_kernel_instance(prec_name),
+            "achieved": round(main_tf, 2), "frac": round(main_tf / peak, 4), "traffic": None,
+            "avg_ms": round(main_ms / main_n, 4), "launches": main_n, "flop_per_launch": stage["dct_row_main"]["work"] / main_n,
+            "note": MAIN_KERNEL_NOTE[prec_name]}
+    attach_pmc_traffic(best, prec_name, W, H, chunk_eff)
+    roofline = {"bound": "mfma", "kernel": f"{fam} (family: every GEMM launch of the step)", "name_match": f"ssw::{fam}<",
+                "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+                "share_of_step": round(gemm_ms / all_ms, 4) if all_ms else None,
+                "executed_flop_per_step": executed / steps, "kernel_ms_per_step": round(gemm_ms / steps, 3),
+                "by_pass": {"rows": {"tflops": round(rate(stage["dct_row"]["work"], stage["dct_row"]["ms"]) / 1e12, 2),
+                                     "ms_per_step": round(stage["dct_row"]["ms"] / steps, 3)},
+                            "cols": {"tflops": round(rate(stage["dct_col"]["work"], stage["dct_col"]["ms"]) / 1e12, 2),
+                                     "ms_per_step": round(stage["dct_col"]["ms"] / steps, 3)}},
+                "how": "sum of executed flop of all launches of the family / sum of their durations; recompute from a rocprofv3 "
+                       "kernel-trace summary as executed_flop_per_step x steps / (sum of TotalDurationNs over the rows whose Name "
+                       "starts with name_match)",
+                "best_launch": best}
+    pre_ms = stage["rgb_to_yiq"]["ms"] + stage["dct_prep"]["ms"]
+    pre_bytes = stage["rgb_to_yiq"]["work"] + stage["dct_prep"]["work"]
+    gbs = rate(pre_bytes, pre_ms) / 1e9
+    members = hbm_report(stage, ["rgb_to_yiq", "dct_prep"])
+    roofline_hbm = {"bound": "hbm", "kernel": "deep operand pre-passes (family: pair_prep16_rows_kernel<rgb>, prep16_cols_staged_kernel, "
+                                               "prep16_inv_rows_staged_kernel, prep16_inv_cols_staged_kernel)", "name_match": "prep16",
+                    "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                    "share_of_step": round(pre_ms / all_ms, 4) if all_ms else None,
+                    "algorithmic_bytes_per_step": pre_bytes / steps, "kernel_ms_per_step": round(pre_ms / steps, 3),
+                    "members": members,
+                    "how": "algorithmic bytes (SURVEY 8(d): what each pre-pass must read and write once, counted per launch) of all "
+                           "launches of the family / sum of their durations"}
+    pmc = load_pmc(W, H, chunk_eff)
+    if pmc and "families" in pmc:
+        scale = frames_per_step / float(chunk_eff)                 # the PMC run profiles steps of ONE pass of chunk_eff frames
+        for block, key in ((roofline, "gemm"), (roofline_hbm, "prepass")):
+            fm = pmc["families"].get(key)
+            if fm:
+                block["traffic"] = int(fm["hbm_bytes_per_step"] * scale)
+                block["traffic_unit"] = "bytes/step over all launches of the family (L2<->fabric, incl. Infinity-Cache hits)"
+                block["traffic_source"] = pmc["_source"]
+                if "traffic_over_algorithmic" in fm:
+                    block["traffic_over_algorithmic"] = fm["traffic_over_algorithmic"]
+    return roofline, roofline_hbm
 
 
 def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb_out, marks, marks_host,
@@ -216,16 +282,8 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
     dump(sims_host, extracted.cpu().numpy())
     result = None
     if rank == 0:
-        main_ms, main_n = stage["dct_row_main"]["ms"], max(stage["dct_row_main"]["launches"], 1)
-        peak = PEAK_F64_MFMA_TFLOPS if args.precision == "f64" else PEAK_F32_MFMA_TFLOPS
-        main_tf = rate(stage["dct_row_main"]["work"], main_ms) / 1e12
         chunk_eff = ctx.pass_frames(B, W, H)
-        roofline = {"bound": "mfma", "kernel": main_kernel_label(args.precision),
-                    "instance": main_kernel_instance(args.precision),
-                    "achieved": round(main_tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(main_tf / peak, 4),
-                    "traffic": None, "avg_ms": round(main_ms / main_n, 4), "launches": main_n,
-                    "flop_per_launch": stage["dct_row_main"]["work"] / main_n}
-        attach_pmc_traffic(roofline, args.precision, W, H, chunk_eff)
+        roofline, roofline_hbm = family_rooflines(args.precision, stage, args.steps, W, H, chunk_eff, B)
         result = {
             "metric": "Mpixels/sec embed + resize attack (12.5 %) + extract",
             "value": round(float(total_frames) * W * H * args.steps / 1e6 / elapsed, 2),
@@ -237,6 +295,7 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
                        "frames_per_gpu": B, "total_frames": total_frames, "width": W, "height": H, "k": K,
                        "chunk_frames": chunk_eff, "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
             "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in stage.items()},
             "hbm_kernels": hbm_report(stage, ["rgb_to_yiq", "dct_prep", "select", "yiq_to_rgb", "resize"]),
             "pruned_derived_transform": prune,
@@ -648,18 +707,11 @@ def main():
         kernels["dct_all"] = {"executed_fraction_of_dense": round(executed / (dense_flop_per_step * steps), 4) if steps else 0.0,
                               "effective_dense_tflops": round(rate(dense_flop_per_step * steps, gemm_ms) / 1e12, 2)}
         kernels.update(hbm_report(stage, ["rgb_to_yiq", "dct_prep", "select", "yiq_to_rgb"]))
-        main = kernels["dct_rows"]["main_launch"]
-        roofline = {"bound": "mfma", "kernel": main_kernel_label(prec_name),
-                    "instance": main_kernel_instance(prec_name),
-                    "achieved": main["tflops"], "peak": peak, "unit": "TFLOP/s", "frac": round(main["tflops"] / peak, 4),
-                    "traffic": None, "avg_ms": main["avg_ms"], "launches": main["launches"],
-                    "flop_per_launch": main["flop_per_launch"],
-                    "note": MAIN_KERNEL_NOTE[prec_name]}
-        attach_pmc_traffic(roofline, prec_name, W, H, chunk_eff)
-        return kernels, roofline, {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
+        roofline, roofline_hbm = family_rooflines(prec_name, stage, steps, W, H, chunk_eff, B)
+        return kernels, (roofline, roofline_hbm), {k: round(v["ms"] / steps, 3) for k, v in stage.items()}
 
     own, elapsed, stage, prune, sims_host, ext_host = measure(args.precision)
-    kernels, roofline, stage_ms = kernel_report(args.precision, stage, steps)
+    kernels, (roofline, roofline_hbm), stage_ms = kernel_report(args.precision, stage, steps)
     ranks = rank_report(own)
     dump(sims_host, ext_host)
 
@@ -669,10 +721,10 @@ def main():
         keep = args.steps
         args.steps = max(1, min(args.steps, 5))
         s_own, s_elapsed, s_stage, _, s_sims, s_ext = measure(args.precision, overlap=False)
-        s_kernels, s_roofline, s_stage_ms = kernel_report(args.precision, s_stage, args.steps)
+        s_kernels, (s_roofline, s_roofline_hbm), s_stage_ms = kernel_report(args.precision, s_stage, args.steps)
         serial = {"value": round(float(total_frames) * W * H * args.steps / 1e6 / s_elapsed, 2), "unit": "Mpix/s",
                   "ms_per_step": round(s_elapsed / args.steps * 1e3, 3), "steps": args.steps,
-                  "roofline": s_roofline, "kernels": s_kernels, "stage_ms_per_step": s_stage_ms,
+                  "roofline": s_roofline, "roofline_hbm": s_roofline_hbm, "kernels": s_kernels, "stage_ms_per_step": s_stage_ms,
                   "bit_identical_to_overlapped": bool(np.array_equal(s_sims, sims_host) and np.array_equal(s_ext, ext_host))}
         args.steps = keep
 
@@ -712,7 +764,7 @@ def main():
     if not args.no_alt:
         alt_name = "f32" if args.precision == "f64" else "f64"
         _, alt_elapsed, alt_stage, _, alt_sims, _ = measure(alt_name)
-        alt_kernels, alt_roofline, _ = kernel_report(alt_name, alt_stage, steps)
+        alt_kernels, (alt_roofline, _), _ = kernel_report(alt_name, alt_stage, steps)
         alt = {"dtype": alt_name, "value": round(job_px_total / 1e6 / alt_elapsed, 2), "unit": "Mpix/s",
                "ms_per_step": round(alt_elapsed / steps * 1e3, 3), "roofline": alt_roofline,
                "kernels": {k: alt_kernels[k] for k in ("dct_rows", "dct_cols")},
@@ -745,6 +797,7 @@ def main():
                        "overlap": "one chunk at a time on one stream" if args.no_overlap else "two chunks in flight on two streams",
                        "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
             "kernels": kernels,
             "stage_ms_per_step": stage_ms,
             "pruned_derived_transform": prune,

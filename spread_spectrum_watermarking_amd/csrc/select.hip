@@ -39,11 +39,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DIGIT_BITS = 11;
 constexpr int NBINS = 1 << DIGIT_BITS;          // 2048
 constexpr size_t MAX_K = 16384;                 // 128 KiB of LDS for the in-block sort
-// sampling rate of the threshold estimate: one element in 64, or one in 256 for long marks (k >= 4096), whose
-// tail still holds >= 48 samples -- the sample pass pulls a cache line per 16-byte quad it reads, i.e. 1/8 of the
-// plane at rate 1/64 (98 us of a 1.07 ms selection on 32 8K frames with k = 10000)
-constexpr unsigned SAMPLE_STRIDE = 64, SAMPLE_STRIDE_LONG = 256;
-static inline unsigned sample_stride_for(size_t k) { return k >= 4096 ? SAMPLE_STRIDE_LONG : SAMPLE_STRIDE; }
+// sampling rate of the threshold estimate: one element in 64; for long marks one in 128 (k >= 4096) or 256
+// (k >= 8192) -- the sample pass pulls a cache line per 16-byte quad it reads, i.e. 1/8 of the plane at rate 1/64
+// (98 us of a 1.07 ms selection on 32 8K frames with k = 10000).  The four members of a quad are neighbouring
+// coefficients of a smooth spectrum, i.e. strongly correlated: count QUADS when judging the noise of the estimate
+// (ADVICE r3).  The tail of the sample holds 3k / stride >= 96 elements = 24 quads at both thresholds; the exact
+// whole-plane fallback needs that tail to overestimate the true density threefold: below 1e-5 per frame.
+constexpr unsigned SAMPLE_STRIDE = 64, SAMPLE_STRIDE_MID = 128, SAMPLE_STRIDE_LONG = 256;
+static inline unsigned sample_stride_for(size_t k) { return k >= 8192 ? SAMPLE_STRIDE_LONG : k >= 4096 ? SAMPLE_STRIDE_MID : SAMPLE_STRIDE; }
 constexpr unsigned FINISH_THREADS = 1024;
 
 size_t select_max_k() { return MAX_K; }

@@ -25,8 +25,20 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// DeviceGuard + "the context this thread is working for": dev_malloc() gives that context's pool of spare handle
+// planes (up to SSW_PLANE_POOL_MB) back to the device and retries once before it reports out of memory.
+struct CtxGuard {
+    DeviceGuard dg;
+    ssw_ctx* prev;
+    explicit CtxGuard(ssw_ctx* ctx);
+    ~CtxGuard();
+};
+// frees the spare planes of the context's pool; returns the bytes given back
+size_t plane_pool_flush(ssw_ctx* ctx);
+
 // Device allocation: a failing hipMalloc is reported as SSW_ERR_OUT_OF_MEMORY whatever code the runtime
-// chose for it, and the runtime's sticky error is cleared so that the next call starts clean.
+// chose for it, and the runtime's sticky error is cleared so that the next call starts clean.  Before that the
+// working context's plane pool is flushed and the allocation retried once.
 int dev_malloc(void** p, size_t bytes);
 #define SSW_ALLOC(pp, bytes) SSW_TRY(::ssw::host::dev_malloc((void**)(pp), (bytes)))
 int grow(ssw_ctx::Buf& b, size_t bytes);

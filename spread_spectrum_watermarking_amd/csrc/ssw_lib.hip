@@ -75,12 +75,7 @@ int pool_get(ssw_ctx* ctx, size_t bytes, void** p) {
         ctx->plane_pool_bytes -= bytes;
         return SSW_OK;
     }
-    int rc = dev_malloc(p, bytes);
-    if (rc == SSW_OK || ctx->plane_pool.empty()) return rc;
-    for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);        // out of memory: give the pool back first
-    ctx->plane_pool.clear();
-    ctx->plane_pool_bytes = 0;
-    return dev_malloc(p, bytes);
+    return dev_malloc(p, bytes);                                      // out of memory: flushes the pool and retries once
 }
 // Every use of a handle's plane was enqueued on the context's stream, and so is every later use by the next
 // owner: no synchronisation.  (ssw_ctx_set_stream synchronises the stream it leaves.)
@@ -236,7 +231,7 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
 
 int ssw_ctx_destroy(ssw_ctx* ctx) {
     if (!ctx) return SSW_OK;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
@@ -275,7 +270,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
 
 int ssw_ctx_synchronize(ssw_ctx* ctx) {
     if (!ctx) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SSW_OK;
 }
@@ -284,7 +279,7 @@ void* ssw_ctx_stream(ssw_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; 
 
 int ssw_ctx_set_stream(ssw_ctx* ctx, void* hip_stream) {
     if (!ctx) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_TRY(flush_timers(ctx));                                      // pending event pairs belong to the old stream
     SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));                // workspace in flight on the old stream
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
@@ -293,14 +288,14 @@ int ssw_ctx_set_stream(ssw_ctx* ctx, void* hip_stream) {
 
 int ssw_ctx_wait_event(ssw_ctx* ctx, void* hip_event) {
     if (!ctx || !hip_event) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, (hipEvent_t)hip_event, 0));
     return SSW_OK;
 }
 
 int ssw_ctx_record_event(ssw_ctx* ctx, void* hip_event) {
     if (!ctx || !hip_event) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_HIP_CHECK(hipEventRecord((hipEvent_t)hip_event, ctx->stream));
     return SSW_OK;
 }
@@ -325,7 +320,7 @@ int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int enable) {
 
 int ssw_ctx_enable_timing(ssw_ctx* ctx, int enable) {
     if (!ctx) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_TRY(flush_timers(ctx));
     ctx->timing = enable != 0;
     return SSW_OK;
@@ -333,7 +328,7 @@ int ssw_ctx_enable_timing(ssw_ctx* ctx, int enable) {
 
 int ssw_ctx_reset_timing(ssw_ctx* ctx) {
     if (!ctx) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_TRY(flush_timers(ctx));
     for (int s = 0; s < SSW_STAGE_COUNT; ++s) { ctx->stage_ms[s] = 0; ctx->stage_launches[s] = 0; ctx->stage_work[s] = 0; }
     ctx->pruned_chunks = ctx->redone_chunks = ctx->pruned_columns = 0;
@@ -342,7 +337,7 @@ int ssw_ctx_reset_timing(ssw_ctx* ctx) {
 
 int ssw_ctx_get_timing(ssw_ctx* ctx, double* ms, uint64_t* launches) {
     if (!ctx) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_TRY(flush_timers(ctx));
     for (int s = 0; s < SSW_STAGE_COUNT; ++s) {
         if (ms) ms[s] = ctx->stage_ms[s];
@@ -353,7 +348,7 @@ int ssw_ctx_get_timing(ssw_ctx* ctx, double* ms, uint64_t* launches) {
 
 int ssw_ctx_get_work(ssw_ctx* ctx, double* work) {
     if (!ctx || !work) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_TRY(flush_timers(ctx));
     for (int s = 0; s < SSW_STAGE_COUNT; ++s) work[s] = ctx->stage_work[s];
     return SSW_OK;
@@ -387,41 +382,41 @@ int ssw_ctx_get_prune_stats(ssw_ctx* ctx, uint64_t* stats) {
 
 int ssw_dev_mem_info(ssw_ctx* ctx, size_t* free_bytes, size_t* total_bytes) {
     if (!ctx || !free_bytes || !total_bytes) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes));
     return SSW_OK;
 }
 
 int ssw_dev_alloc(ssw_ctx* ctx, size_t bytes, void** dev_ptr) {
     if (!ctx || !dev_ptr) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_ALLOC(dev_ptr, bytes);
     return SSW_OK;
 }
 int ssw_dev_free(ssw_ctx* ctx, void* dev_ptr) {
     if (!ctx) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (dev_ptr) SSW_HIP_CHECK(hipFree(dev_ptr));
     return SSW_OK;
 }
 int ssw_copy_to_dev(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
     if (!ctx || (bytes && (!dev_dst || !host_src))) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_TRY(upload(ctx, dev_dst, host_src, bytes, ctx->stream));
     SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SSW_OK;
 }
 int ssw_copy_to_host(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
     if (!ctx || (bytes && (!host_dst || !dev_src))) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     return download(ctx, host_dst, dev_src, bytes, ctx->stream);
 }
 
 int ssw_host_alloc(ssw_ctx* ctx, size_t bytes, void** host_ptr) {
     if (!ctx || !host_ptr) return SSW_ERR_BAD_ARG;
     *host_ptr = nullptr;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const hipError_t e = hipHostMalloc(host_ptr, bytes ? bytes : 16, hipHostMallocDefault);
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -433,7 +428,7 @@ int ssw_host_alloc(ssw_ctx* ctx, size_t bytes, void** host_ptr) {
 }
 int ssw_host_free(ssw_ctx* ctx, void* host_ptr) {
     if (!ctx) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     if (host_ptr) SSW_HIP_CHECK(hipHostFree(host_ptr));
     return SSW_OK;
 }
@@ -450,7 +445,7 @@ int ssw_ctx_get_transfer_stats(ssw_ctx* ctx, double* stats, int reset) {
 int ssw_rgb_to_yiq(ssw_ctx* ctx, const float* dev_rgb, size_t n_frames, size_t w, size_t h,
                    float* dev_y, float* dev_i, float* dev_q) {
     if (!ctx || !dev_rgb || !dev_y || ((dev_i == nullptr) != (dev_q == nullptr))) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, ctx->stream);
     return launch_rgb_to_yiq(ctx->stream, dev_rgb, n_frames * w * h, dev_y, dev_i, dev_q);
 }
@@ -458,7 +453,7 @@ int ssw_rgb_to_yiq(ssw_ctx* ctx, const float* dev_rgb, size_t n_frames, size_t w
 int ssw_yiq_to_rgb(ssw_ctx* ctx, const float* dev_y, const float* dev_i, const float* dev_q,
                    size_t n_frames, size_t w, size_t h, float* dev_rgb) {
     if (!ctx || !dev_rgb || !dev_y || !dev_i || !dev_q) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     StageTimer t(ctx, SSW_STAGE_YIQ_TO_RGB, ctx->stream);
     return launch_yiq_to_rgb(ctx->stream, dev_y, dev_i, dev_q, n_frames * w * h, dev_rgb);
 }
@@ -468,7 +463,7 @@ int ssw_dct2d(ssw_ctx* ctx, int dct_type, int precision, size_t n_frames, size_t
     if (!ctx || !dev_planes) return SSW_ERR_BAD_ARG;
     if (dct_type < SSW_DCT2 || dct_type > SSW_DCT3 || !valid_precision(precision)) return SSW_ERR_BAD_ARG;
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const size_t chunk = effective_chunk(ctx, w, h, n_frames);
     SSW_TRY(grow(ctx->lane[0].plane[3], chunk * w * h * sizeof(float)));
     for (size_t f0 = 0; f0 < n_frames; f0 += chunk) {
@@ -485,7 +480,7 @@ int ssw_topk_indices(ssw_ctx* ctx, const float* dev_coef, size_t n_frames, size_
     if (!valid_ordering(ordering)) return SSW_ERR_BAD_ARG;
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
     if (k > w * h - 1) return SSW_ERR_K_TOO_LARGE;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     return topk0(ctx, dev_coef, n_frames, w, h, ordering, k, dev_indices);
 }
 
@@ -495,7 +490,7 @@ int ssw_embed_coefficients(ssw_ctx* ctx, float* dev_coef, size_t n_frames, size_
     if (!ctx || !dev_coef || !dev_indices || !dev_marks) return SSW_ERR_BAD_ARG;
     if (method == SSW_METHOD_CUSTOM) return SSW_ERR_UNSUPPORTED;
     if (!valid_method(method)) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     StageTimer t(ctx, SSW_STAGE_EMBED, ctx->stream);
     return launch_embed(ctx->stream, dev_coef, n_frames, plane_len, dev_indices, k, dev_marks, nullptr,
                         nullptr, n_marks, k, k, method, alpha);
@@ -508,7 +503,7 @@ int ssw_extract_coefficients(ssw_ctx* ctx, const float* dev_base, const float* d
     if (method == SSW_METHOD_CUSTOM) return SSW_ERR_UNSUPPORTED;
     if (!valid_method(method)) return SSW_ERR_BAD_ARG;
     if (k >= plane_len) return SSW_ERR_K_TOO_LARGE;                   // src/algorithm.rs:553-555
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     StageTimer t(ctx, SSW_STAGE_EXTRACT, ctx->stream);
     return launch_extract(ctx->stream, dev_base, dev_derived, n_frames, plane_len, dev_indices, k, method,
                           alpha, dev_out);
@@ -517,7 +512,7 @@ int ssw_extract_coefficients(ssw_ctx* ctx, const float* dev_base, const float* d
 int ssw_similarity_batch(ssw_ctx* ctx, const float* dev_extracted, const float* dev_marks,
                          size_t n_pairs, size_t k, float* dev_sims) {
     if (!ctx || !dev_extracted || !dev_marks || !dev_sims) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     StageTimer t(ctx, SSW_STAGE_SIMILARITY, ctx->stream);
     return launch_similarity(ctx->stream, dev_extracted, dev_marks, n_pairs, k, dev_sims);
 }
@@ -526,7 +521,7 @@ int ssw_similarity_matrix(ssw_ctx* ctx, const float* dev_extracted, size_t n_ext
                           size_t n_marks, size_t k, float* dev_sims) {
     if (!ctx || !dev_extracted || !dev_marks || !dev_sims) return SSW_ERR_BAD_ARG;
     if (n_extracted == 0 || n_marks == 0) return SSW_OK;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_TRY(grow(ctx->small, n_extracted * sizeof(float)));
     StageTimer t(ctx, SSW_STAGE_SIMILARITY, ctx->stream);
     SSW_TRY(launch_sim_den(ctx->stream, dev_extracted, n_extracted, k, (float*)ctx->small.p));
@@ -607,14 +602,14 @@ int ssw_batch_extract_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* d
 // ---- 8-bit boundary and the resize attack ---------------------------------------------------------
 int ssw_convert_rgb8_to_f32(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_values, float* dev_out) {
     if (!ctx || (n_values && (!dev_in || !dev_out))) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     StageTimer t(ctx, SSW_STAGE_CONVERT, ctx->stream);
     return launch_u8_to_f32(ctx->stream, dev_in, n_values, dev_out);
 }
 
 int ssw_convert_f32_to_rgb8(ssw_ctx* ctx, const float* dev_in, size_t n_values, uint8_t* dev_out) {
     if (!ctx || (n_values && (!dev_in || !dev_out))) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     StageTimer t(ctx, SSW_STAGE_CONVERT, ctx->stream);
     return launch_f32_to_u8(ctx->stream, dev_in, n_values, dev_out);
 }
@@ -623,7 +618,7 @@ int ssw_resize_rgb8(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_frames, size_t
                     size_t nh, uint8_t* dev_out) {
     if (!ctx || !dev_in || !dev_out) return SSW_ERR_BAD_ARG;
     if (w == 0 || h == 0 || nw == 0 || nh == 0) return SSW_ERR_BAD_DIMS;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     if (nw == w && nh == h) {                         // the crate copies when the size is unchanged
         SSW_HIP_CHECK(hipMemcpyAsync(dev_out, dev_in, n_frames * w * h * 3, hipMemcpyDeviceToDevice, ctx->stream));
         return SSW_OK;
@@ -650,7 +645,7 @@ static int writer_create_impl(ssw_ctx* ctx, const void* rgb_hwc, bool u8, size_t
     *out = nullptr;
     SSW_TRY(check_config(cfg));
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const size_t plane = w * h;
     ssw_writer* wr = new (std::nothrow) ssw_writer();
     if (!wr) return SSW_ERR_OUT_OF_MEMORY;
@@ -685,7 +680,7 @@ static int writer_embed_impl(ssw_writer* wr, const float* const* marks, const si
     if (!wr || (n_marks && (!marks || !lens))) return SSW_ERR_BAD_ARG;
     if (wr->consumed) return SSW_ERR_CONSUMED;
     ssw_ctx* ctx = wr->ctx;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const size_t plane = wr->w * wr->h;
     if (n_marks == 0) return SSW_OK;
     for (size_t m = 0; m < n_marks; ++m)
@@ -745,7 +740,7 @@ static int writer_result_impl(ssw_writer* wr, void* out_rgb_hwc, bool u8_out) {
     if (!wr || !out_rgb_hwc) return SSW_ERR_BAD_ARG;
     if (wr->consumed) return SSW_ERR_CONSUMED;
     ssw_ctx* ctx = wr->ctx;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const size_t plane = wr->w * wr->h;
     const size_t out_bytes = plane * 3 * (u8_out ? 1 : sizeof(float));
     SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
@@ -791,7 +786,7 @@ int ssw_writer_mark_rgb8(ssw_writer* wr, const float* const* marks, const size_t
 int ssw_writer_destroy(ssw_writer* wr) {
     if (!wr) return SSW_OK;
     ssw_ctx* ctx = wr->ctx;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     if (wr->staging_in_flight) (void)hipStreamSynchronize(ctx->stream);     // host vectors of embed() die with the handle
     const size_t plane = wr->w * wr->h;
     pool_put(ctx, wr->y, plane * 4);
@@ -814,7 +809,7 @@ static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, bool u8, size_t
     else if (is_base) return SSW_ERR_BAD_ARG;                         // config.unwrap(), :482
     SSW_TRY(check_config(&c));
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const size_t plane = w * h;
     ssw_reader* rd = new (std::nothrow) ssw_reader();
     if (!rd) return SSW_ERR_OUT_OF_MEMORY;
@@ -848,12 +843,20 @@ static int reader_ensure_coefficients(ssw_reader* rd) {
     if (rd->y) return SSW_OK;
     ssw_ctx* ctx = rd->ctx;
     const size_t plane = rd->w * rd->h;
-    SSW_TRY(pool_get(ctx, plane * 4, (void**)&rd->y));
-    SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
-    Chain ch;
-    SSW_TRY(build_forward_from_rgb(ctx, ctx->lane[0], rd->cfg.precision, rd->rgb, rd->rgb_u8, 1, rd->w, rd->h, rd->y,
-                                   nullptr, nullptr, (float*)ctx->lane[0].plane[3].p, ch));
-    SSW_TRY(run_serial(ch, ctx->stream));
+    // rd->y is set only once the whole chain is enqueued: a failure below (out of memory in grow() is the realistic
+    // one) leaves the reader as it was -- still RGB, a retry works -- instead of pointing at a recycled plane
+    float* y = nullptr;
+    SSW_TRY(pool_get(ctx, plane * 4, (void**)&y));
+    auto run = [&]() -> int {
+        SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
+        Chain ch;
+        SSW_TRY(build_forward_from_rgb(ctx, ctx->lane[0], rd->cfg.precision, rd->rgb, rd->rgb_u8, 1, rd->w, rd->h, y,
+                                       nullptr, nullptr, (float*)ctx->lane[0].plane[3].p, ch));
+        return run_serial(ch, ctx->stream);
+    };
+    const int rc = run();
+    if (rc != SSW_OK) { pool_put(ctx, y, plane * 4); return rc; }
+    rd->y = y;
     pool_put(ctx, rd->rgb, plane * 3 * (rd->rgb_u8 ? 1 : sizeof(float)));      // reuse is ordered on the stream
     rd->rgb = nullptr;
     return SSW_OK;
@@ -871,7 +874,7 @@ int ssw_reader_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_
 
 int ssw_reader_coefficients(ssw_reader* rd, float* out_plane) {
     if (!rd || !out_plane) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(rd->ctx->device);
+    CtxGuard g(rd->ctx);
     SSW_TRY(reader_ensure_coefficients(rd));
     return ssw_copy_to_host(rd->ctx, out_plane, rd->y, rd->w * rd->h * sizeof(float));
 }
@@ -883,15 +886,18 @@ static int reader_ensure_indices(ssw_reader* rd, size_t k) {
     ssw_ctx* ctx = rd->ctx;
     pool_put(ctx, rd->idx, rd->idx_k * sizeof(uint32_t));
     rd->idx = nullptr; rd->idx_k = 0;
-    SSW_TRY(pool_get(ctx, k * sizeof(uint32_t), (void**)&rd->idx));
-    SSW_TRY(topk0(ctx, rd->y, 1, rd->w, rd->h, rd->cfg.ordering, k, rd->idx));           // :493
+    uint32_t* idx = nullptr;
+    SSW_TRY(pool_get(ctx, k * sizeof(uint32_t), (void**)&idx));
+    const int rc = topk0(ctx, rd->y, 1, rd->w, rd->h, rd->cfg.ordering, k, idx);           // :493
+    if (rc != SSW_OK) { pool_put(ctx, idx, k * sizeof(uint32_t)); return rc; }          // back under the size it was taken with
+    rd->idx = idx;
     rd->idx_k = k;
     return SSW_OK;
 }
 
 int ssw_reader_indices(ssw_reader* rd, size_t k, uint64_t* out) {
     if (!rd || (k && !out)) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(rd->ctx->device);
+    CtxGuard g(rd->ctx);
     if (k == 0) return rd->is_base ? SSW_OK : SSW_ERR_NOT_BASE;
     SSW_TRY(reader_ensure_indices(rd, k));
     ssw_ctx* ctx = rd->ctx;
@@ -909,7 +915,7 @@ int ssw_reader_extract(ssw_reader* base, ssw_reader* derived, float* out, size_t
     if (k >= plane) return SSW_ERR_K_TOO_LARGE;                                           // :553-555
     if (k == 0) return SSW_OK;
     ssw_ctx* ctx = base->ctx;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     SSW_TRY(reader_ensure_indices(base, k));
     SSW_TRY(grow(ctx->small, k * sizeof(float)));
     if (!derived->y && derived->w == base->w && derived->h == base->h) {
@@ -938,7 +944,7 @@ int ssw_reader_extract(ssw_reader* base, ssw_reader* derived, float* out, size_t
 int ssw_reader_destroy(ssw_reader* rd) {
     if (!rd) return SSW_OK;
     ssw_ctx* ctx = rd->ctx;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     pool_put(ctx, rd->y, rd->w * rd->h * 4);
     pool_put(ctx, rd->idx, rd->idx_k * sizeof(uint32_t));
     pool_put(ctx, rd->rgb, rd->w * rd->h * 3 * (rd->rgb_u8 ? 1 : sizeof(float)));
@@ -952,7 +958,7 @@ int ssw_similarity(ssw_ctx* ctx, const float* extracted, size_t n_extracted, con
                    size_t n_mark, float* out_similarity) {
     if (!ctx || !out_similarity || (n_extracted && !extracted) || (n_mark && !mark)) return SSW_ERR_BAD_ARG;
     if (n_extracted != n_mark) return SSW_ERR_LENGTH_MISMATCH;                            // :697-700
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const size_t k = n_extracted;
     const size_t bytes = (k * 4 + 15) / 16 * 16;
     SSW_TRY(grow(ctx->small, 2 * bytes + 16));
@@ -973,7 +979,7 @@ int ssw_similarity(ssw_ctx* ctx, const float* extracted, size_t n_extracted, con
 int ssw_synth_frames(ssw_ctx* ctx, uint32_t seed, uint32_t first_frame, size_t n_frames, size_t w,
                      size_t h, float* dev_rgb) {
     if (!ctx || !dev_rgb) return SSW_ERR_BAD_ARG;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     return launch_synth(ctx->stream, seed, first_frame, n_frames, w, h, dev_rgb);
 }
 

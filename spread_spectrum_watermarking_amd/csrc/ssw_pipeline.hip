@@ -21,11 +21,29 @@ namespace ssw {
 namespace host {
 
 // ---- small helpers ------------------------------------------------------------------------------------
+namespace { thread_local ssw_ctx* tl_ctx = nullptr; }
+CtxGuard::CtxGuard(ssw_ctx* ctx) : dg(ctx->device), prev(tl_ctx) { tl_ctx = ctx; }
+CtxGuard::~CtxGuard() { tl_ctx = prev; }
+
+size_t plane_pool_flush(ssw_ctx* ctx) {
+    const size_t bytes = ctx->plane_pool_bytes;
+    for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);
+    ctx->plane_pool.clear();
+    ctx->plane_pool_bytes = 0;
+    return bytes;
+}
+
 int dev_malloc(void** p, size_t bytes) {
     *p = nullptr;
-    const hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
     if (e == hipSuccess) return SSW_OK;
     (void)hipGetLastError();
+    if (tl_ctx && !tl_ctx->plane_pool.empty()) {                   // spare planes of destroyed handles: give them back first
+        (void)plane_pool_flush(tl_ctx);
+        e = hipMalloc(p, bytes ? bytes : 16);
+        if (e == hipSuccess) return SSW_OK;
+        (void)hipGetLastError();
+    }
     *p = nullptr;
     set_last_error(std::string("hipMalloc(") + std::to_string(bytes) + " bytes): " + hipGetErrorString(e));
     return SSW_ERR_OUT_OF_MEMORY;
@@ -171,9 +189,13 @@ size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames) 
         size_t free_b = 0, total_b = 0;
         DeviceGuard g(ctx->device);
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t lanes = (ctx->overlap && n_frames > c) ? 2 : 1;
-            const size_t budget = (free_b + lane_bytes_held(ctx)) / 2;
-            c = std::max<size_t>(1, std::min(c, budget / (lanes * 36 * px)));
+            // half of what the device can give: free memory, what the lanes already hold, and the spare handle planes
+            // (dev_malloc gives those back before it fails).  A clamp can turn a one-pass call into several passes,
+            // i.e. into two lanes: budget for one lane first, then for the lane count the clamped pass size implies.
+            const size_t budget = (free_b + lane_bytes_held(ctx) + ctx->plane_pool_bytes) / 2;
+            size_t c1 = std::max<size_t>(1, std::min(c, budget / (36 * px)));
+            if (ctx->overlap && n_frames > c1) c1 = std::max<size_t>(1, std::min(c1, budget / (2 * 36 * px)));
+            c = c1;
         } else {
             (void)hipGetLastError();
         }
@@ -964,7 +986,7 @@ int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, b
     if (w == 0 || h == 0) return SSW_ERR_BAD_DIMS;
     const size_t plane = w * h;
     const size_t k_eff = std::min(k, plane - 1);                       // zip() truncation, :396: a longer mark is cut silently
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const size_t chunk = effective_chunk(ctx, w, h, n_frames);
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     const ssw_config c = *cfg;
@@ -1018,7 +1040,7 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
     const size_t plane = w * h;
     if (k >= plane) return SSW_ERR_K_TOO_LARGE;                        // :553-555
     if (n_frames == 0) return SSW_OK;
-    DeviceGuard g(ctx->device);
+    CtxGuard g(ctx);
     const size_t chunk = effective_chunk(ctx, w, h, n_frames);
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     const ssw_config c = *cfg;

@@ -272,7 +272,7 @@ int download(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hi
     const size_t SLICES = PIECE / SUB;                 // event slots per staging buffer (>= slices of a piece)
     while (t->slice_ev.size() < SLICES * RING) {
         hipEvent_t e = nullptr;
-        SSW_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        SSW_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
         t->slice_ev.push_back(e);
     }
     // In rounds of RING pieces (one staging buffer each): all DMAs of a round are enqueued first, slice by
@@ -299,6 +299,18 @@ int download(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hi
             j.n_sub = (pb + SUB - 1) / SUB;
             j.ready_sub.store(0);
             for (size_t s = 0; s < n_slices; ++s) j.done[s].store(0);
+            // Sleep (blocking event) until the piece's first slice has landed: whatever the stream still has to run ahead
+            // of the DMA -- a whole batch call, possibly -- is waited for here by one sleeping thread; the caller and the
+            // copy threads used to spin through all of it.  On an error the stream is drained before the
+            // staging buffers go back to the ring.
+            {
+                const hipError_t e0 = hipEventSynchronize(ev[0]);
+                if (e0 != hipSuccess) {
+                    (void)hipStreamSynchronize(st);
+                    (void)hipGetLastError();
+                    SSW_HIP_CHECK(e0);
+                }
+            }
             t->post(j);
             size_t synced = 0;
             constexpr size_t NONE = ~(size_t)0;
@@ -312,7 +324,8 @@ int download(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hi
                         ++synced;
                         j.ready_sub.store(std::min(synced * SUBS_PER_SLICE, j.n_sub), std::memory_order_release);
                     } else if (q != hipErrorNotReady) {
-                        err = q;                            // let the helpers run out, then report
+                        err = q;                            // drain the stream (no DMA may still be writing the staging
+                        (void)hipStreamSynchronize(st);     // buffer), let the helpers run out, then report
                         synced = n_slices;
                         j.ready_sub.store(j.n_sub, std::memory_order_release);
                     }

@@ -8,7 +8,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
     for row in csv.DictReader(open(f)):
         name = row.get("Kernel_Name", "")
         if filt and filt not in name: continue
-        short = name.split("(")[0].replace("void ", "").replace("ssw::", "")
+        short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("ssw::", "")
         acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     print(k, {c: round(sum(v) / len(v), 1) for c, v in sorted(acc[k].items())}, "n=%d" % len(next(iter(acc[k].values()))))

@@ -5,12 +5,16 @@
 HBM-side bytes per launch = 2 * FETCH_SIZE[KB] * 1024 + WRITE_SIZE[KB] * 1024: on gfx950 FETCH_SIZE reports half
 the bytes of 16-byte-per-lane streaming reads (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are
 included (memory-side L2 requests), so this is an upper bound on DRAM traffic.
-usage: pmc_traffic_json.py <dir> <tag> <width> <height> <chunk_frames> <commit>"""
+Besides the per-instance entries the file carries two FAMILY sums per 128-frame (chunk_frames) step -- what bench.py's
+`roofline` (every pair_gemm_f64_kernel launch) and `roofline_hbm` (every *prep16* launch) blocks quote: bytes summed over
+all launches of the family in one step of the profiled run (`steps_profiled` steps of one pass each).
+usage: pmc_traffic_json.py <dir> <tag> <width> <height> <chunk_frames> <commit> [steps_profiled = 2]"""
 import ast
 import json
 import sys
 
 d, tag, W, H, chunk, commit = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+steps_profiled = int(sys.argv[7]) if len(sys.argv) > 7 else 2          # collect_profiles.sh: --steps 1 --warmup 1
 
 
 def load(path):
@@ -66,9 +70,18 @@ names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESI
     "pair_prep16_rows_kernel<double, 1, true>": ("pair_prep16_rows_kernel<double, rgb, with I/Q>", lines_r * W * (12 + 8 + esz),
         "writer: RGB f32 in, operand planes + I, Q planes out"),
     "pair_prep16_cols_kernel<double>": ("pair_prep16_cols_kernel<double>", lines_r * W * (4 + esz),
-        "f32 plane in, transposed deep f64 operand planes out (mean over launches incl. the narrow pruned ones)"),
-    "pair_prep16_inv_rows_kernel<double>": ("pair_prep16_inv_rows_kernel<double>", lines_r * W * (4 + esz), "coefficient plane in, deep inverse operand planes out"),
-    "pair_prep16_inv_cols_kernel<double>": ("pair_prep16_inv_cols_kernel<double>", lines_r * W * (4 + esz), "the same, transposed"),
+        "r3 kernel (SSW_PREP_STAGED=0): f32 plane in, transposed deep f64 operand planes out (mean over launches incl. the narrow pruned ones)"),
+    "pair_prep16_inv_rows_kernel<double>": ("pair_prep16_inv_rows_kernel<double>", lines_r * W * (4 + esz), "r3 kernel: coefficient plane in, deep inverse operand planes out"),
+    "pair_prep16_inv_cols_kernel<double>": ("pair_prep16_inv_cols_kernel<double>", lines_r * W * (4 + esz), "r3 kernel: the same, transposed"),
+    # r4: the LDS-staged forms (csrc/dct_pair_prep_staged.hip); <1 | 2, true> = class-major tiles, deep
+    "prep16_cols_staged_kernel<1, true>": ("prep16_cols_staged_kernel<class-major tile, deep>", lines_r * W * (4 + esz),
+        "forward column pre-pass: f32 plane (class-major tiles of 128 columns) in, the ten transposed f64 operand planes out"),
+    "prep16_cols_staged_kernel<0, true>": ("prep16_cols_staged_kernel<natural, deep>", lines_r * W * (4 + esz), "the same from a natural-order plane (the compact planes of the pruned transform: mean over launches)"),
+    "prep16_cols_staged_kernel<0, false>": ("prep16_cols_staged_kernel<natural, semi-deep>", lines_r * W * (4 + esz), "H % 16 != 0 (1080 rows)"),
+    "prep16_inv_rows_staged_kernel": ("prep16_inv_rows_staged_kernel", lines_r * W * (4 + esz), "inverse row pre-pass: coefficient plane in, deep inverse operand planes out"),
+    "prep16_inv_cols_staged_kernel<2, true>": ("prep16_inv_cols_staged_kernel<class-major tile, deep>", lines_r * W * (4 + esz), "inverse column pre-pass (transposing)"),
+    "prep16_inv_cols_staged_kernel<0, true>": ("prep16_inv_cols_staged_kernel<natural, deep>", lines_r * W * (4 + esz), "the same from a natural-order plane"),
+    "prep16_inv_cols_staged_kernel<0, false>": ("prep16_inv_cols_staged_kernel<natural, semi-deep>", lines_r * W * (4 + esz), "H % 16 != 0 (1080 rows)"),
     "select_compact_kernel<true>": ("select_compact_kernel<energy>", lines_r * W * 4, "the one full pass of the top-k selection"),
 }
 out = {"_how": __doc__.strip().split("usage:")[0].strip(), "commit": commit,
@@ -86,5 +99,32 @@ for inst, (label, alg, note) in names.items():
     m = mfma.get(inst, ({}, 0))[0]
     if m.get("GRBM_GUI_ACTIVE") and m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
         out["kernels"][label]["mfma_busy_over_active_cycles"] = round((m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (m["GRBM_GUI_ACTIVE"] / 8.0), 4)
+# family sums per step: every launch of every instance whose name matches, bytes = mean x launches (pmc_summary.py prints both)
+def family(match):
+    tot_f = tot_w = 0.0
+    n = 0
+    members = {}
+    for inst in fetch:
+        if match not in inst or inst not in write:
+            continue
+        f, nf = fetch[inst][0]["FETCH_SIZE"], fetch[inst][1]
+        w, nw = write[inst][0]["WRITE_SIZE"], write[inst][1]
+        tot_f += f * nf
+        tot_w += w * nw
+        n += nf
+        members[inst] = nf // steps_profiled if steps_profiled else nf
+    return {"match": match, "launches_per_step": n // steps_profiled if steps_profiled else n, "members_launches_per_step": members,
+            "hbm_bytes_per_step": int((2 * tot_f + tot_w) * 1024 / max(steps_profiled, 1)),
+            "fetch_bytes_per_step_x2": int(2 * tot_f * 1024 / max(steps_profiled, 1)), "write_bytes_per_step": int(tot_w * 1024 / max(steps_profiled, 1))}
+
+
+px_step = chunk * W * H
+out["families"] = {"_unit": f"one step = embed + extract of one {chunk}-frame pass ({steps_profiled} steps profiled, sums divided by that)",
+                   "gemm": family("pair_gemm_f64_kernel"), "prepass": family("prep16")}
+# algorithmic bytes of the pre-pass family per step: writer frame RGB f32 -> operands + I, Q (28 B/px),
+# base and derived frames (20 B/px each), forward columns x 2, inverse rows, inverse columns (12 B/px each); the
+# column pre-passes of the pruned derived transform work on compact planes (a few percent of a frame, not counted)
+out["families"]["prepass"]["algorithmic_bytes_per_step"] = int(px_step * (28 + 20 + 20 + 4 * 12))
+out["families"]["prepass"]["traffic_over_algorithmic"] = round(out["families"]["prepass"]["hbm_bytes_per_step"] / (px_step * (28 + 20 + 20 + 4 * 12)), 3)
 json.dump(out, sys.stdout, indent=1)
 print()
