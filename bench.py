@@ -523,7 +523,10 @@ def main():
                     help="frames per internal pass (0 = the library's automatic choice, ~2^30 pixels; bounds the workspace)")
     ap.add_argument("--precision", choices=["f32", "f64"], default="f64",
                     help="headline precision: f64 = canonical (bit-parity with the CPU path), f32 = fast")
-    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other precision")
+    ap.add_argument("--alt", action="store_true",
+                    help="also time the OTHER precision (f32 MFMA chains for the default f64): a non-parity path -- its extracted "
+                         "marks miss the 1e-5 bar (max <= 2e-3) and since r3 it is also the slower one; off by default")
+    ap.add_argument("--no-alt", action="store_true", help="(default since r4; kept for old command lines)")
     ap.add_argument("--attack-resize", action="store_true",
                     help="configs[4] flow on 8-bit frames: embed -> into_rgb8 -> CatmullRom 1/8 down + up -> extract")
     ap.add_argument("--embed-only", action="store_true", help="configs[1] flow: Writer::new + mark only (DCT2 -> embed -> DCT3)")
@@ -761,7 +764,7 @@ def main():
         args.steps = keep
 
     alt = None
-    if not args.no_alt:
+    if args.alt and not args.no_alt:
         alt_name = "f32" if args.precision == "f64" else "f64"
         _, alt_elapsed, alt_stage, _, alt_sims, _ = measure(alt_name)
         alt_kernels, (alt_roofline, _), _ = kernel_report(alt_name, alt_stage, steps)
@@ -769,7 +772,8 @@ def main():
                "ms_per_step": round(alt_elapsed / steps * 1e3, 3), "roofline": alt_roofline,
                "kernels": {k: alt_kernels[k] for k in ("dct_rows", "dct_cols")},
                "sim_mean": round(float(alt_sims.mean()), 4),
-               "max_abs_sim_diff_vs_headline": float(np.abs(alt_sims - sims_host).max())}
+               "max_abs_sim_diff_vs_headline": float(np.abs(alt_sims - sims_host).max()),
+               "parity": "NOT a parity path: extracted marks within median 1e-5 / max 2e-3 of the oracle only (DESIGN.md 5)"}
 
     result = None
     if rank == 0:
@@ -906,7 +910,12 @@ def main():
                            "marked_frame_bit_identical_fraction": float(np.mean(marked_f == ref_marked)),
                            "extracted_max_abs_diff_vs_cpu_exact": float(np.abs(gpu_ext[f] - ref_ext).max())})
         result["parity"] = {"precision": args.precision, "sim_cpu_f32fft": float(cpu_sim),
-                            "sim_delta_vs_cpu_f32fft": abs(float(sims_now[0]) - float(cpu_sim)), "frames": checks}
+                            "sim_delta_vs_cpu_f32fft": abs(float(sims_now[0]) - float(cpu_sim)),
+                            # frame 0, each side extracting from its own marked frame: the f32-FFT backend (the stand-in for
+                            # rustdct) is itself 3e-5 .. 1.6e-4 away from the exact transform in the worst element
+                            "extracted_max_abs_diff_vs_cpu_f32fft": float(np.abs(gpu_ext[0] - cpu_ext).max()),
+                            "extracted_median_abs_diff_vs_cpu_f32fft": float(np.median(np.abs(gpu_ext[0] - cpu_ext))),
+                            "frames": checks}
 
     if rank == 0:
         print(json.dumps(result))

@@ -69,8 +69,9 @@ typedef enum ssw_dct_type {
 /* Arithmetic of the DCT basis GEMMs (no counterpart in the reference, which
    delegates to rustdct's f32 FFT kernels). */
 typedef enum ssw_precision {
-    SSW_PRECISION_F32 = 0,        /* v_mfma_f32_32x32x2_f32: f32 fma chains; ~1.8x faster, extracted
-                                     marks within 1e-5 in the median, ~1e-3 worst case      */
+    SSW_PRECISION_F32 = 0,        /* v_mfma_f32_32x32x2_f32: f32 fma chains.  NOT a parity path: extracted
+                                     marks within 1e-5 in the median, ~1e-3 worst case; since r3 (split
+                                     odd halves in f64) it is also the slower precision at 4K */
     SSW_PRECISION_F64 = 1         /* DEFAULT.  v_mfma_f64_16x16x4_f64, f64 basis, result rounded
                                      once to f32: the correctly rounded ("canonical") transform,
                                      bit-identical extraction against the CPU restatement   */
