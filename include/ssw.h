@@ -331,6 +331,21 @@ int ssw_batch_extract_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* d
                            const uint8_t* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
                            float* dev_extracted, const float* dev_marks, float* dev_sims);
 
+/* ---- 16-bit frames (device-resident, batched) ----------------------------------- */
+/* `DynamicImage::into_rgb32f()` for 16-bit input (ImageRgb16; call sites src/algorithm.rs:308, :476): v / 65535,
+   and `into_rgb16()` from Rgb32F: round(clamp(v,0,1) * 65535) (`image 0.24.3`, like the 8-bit forms). */
+int ssw_convert_rgb16_to_f32(ssw_ctx* ctx, const uint16_t* dev_in, size_t n_values, float* dev_out);
+int ssw_convert_f32_to_rgb16(ssw_ctx* ctx, const float* dev_in, size_t n_values, uint16_t* dev_out);
+/* ssw_batch_embed / ssw_batch_extract on 16-bit frames: v / 65535 fused into the first operand pre-pass (6 instead of
+   12 B/px read at the boundary).  The marked frames come back as f32 -- what Writer::mark returns
+   (src/algorithm.rs:355-379: Rgb32F); quantise with ssw_convert_f32_to_rgb16 / _rgb8 as the caller would.  Bit-identical
+   to the f32 entry points on host-converted frames.  Same reference lines as the f32 forms. */
+int ssw_batch_embed_rgb16(ssw_ctx* ctx, const ssw_config* cfg, const uint16_t* dev_rgb, size_t n_frames,
+                          size_t w, size_t h, const float* dev_marks, size_t k, float* dev_rgb_out);
+int ssw_batch_extract_rgb16(ssw_ctx* ctx, const ssw_config* cfg, const uint16_t* dev_base_rgb,
+                            const uint16_t* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
+                            float* dev_extracted, const float* dev_marks, float* dev_sims);
+
 /* ---- single-image handles mirroring the crate's types (host buffers) ------- */
 /* Writer::new(image, config), src/algorithm.rs:295-316.  rgb_hwc: host [h][w][3]
    f32 (what `into_rgb32f()` yields, :308).  The ordering is computed lazily at
@@ -343,6 +358,11 @@ int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
    host [h][w][3] u8.  Bit-identical to ssw_writer_create on the host-converted frame. */
 int ssw_writer_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_t h,
                            const ssw_config* cfg, ssw_writer** out);
+/* Writer::new on a 16-bit image (ImageRgb16): `into_rgb32f()` (src/algorithm.rs:308; v / 65535) on the device, 6 instead
+   of 12 bytes per pixel cross PCIe.  rgb_hwc: host [h][w][3] u16.  Bit-identical to ssw_writer_create on the
+   host-converted frame. */
+int ssw_writer_create_rgb16(ssw_ctx* ctx, const uint16_t* rgb_hwc, size_t w, size_t h,
+                            const ssw_config* cfg, ssw_writer** out);
 /* Writer::coefficient_image(), src/algorithm.rs:319-321 -> host [h][w]. */
 int ssw_writer_coefficients(ssw_writer* wr, float* out_plane);
 /* Writer::embed(&mut self, marks), src/algorithm.rs:348-352.  marks[m] has lens[m] floats (host).
@@ -369,6 +389,9 @@ int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, in
 /* The same on an 8-bit image (`into_rgb32f()`, src/algorithm.rs:476, on the device); host [h][w][3] u8. */
 int ssw_reader_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_t h, int is_base,
                            const ssw_config* cfg, ssw_reader** out);
+/* ... and on a 16-bit image (v / 65535; src/algorithm.rs:476); host [h][w][3] u16. */
+int ssw_reader_create_rgb16(ssw_ctx* ctx, const uint16_t* rgb_hwc, size_t w, size_t h, int is_base,
+                            const ssw_config* cfg, ssw_reader** out);
 /* Reader::coefficients(), src/algorithm.rs:502-504 -> host [h*w]. */
 int ssw_reader_coefficients(ssw_reader* rd, float* out_plane);
 /* Reader::indices(), src/algorithm.rs:506-508: first k entries (k <= w*h-1) as u64 (`usize`). */

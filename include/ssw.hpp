@@ -142,6 +142,14 @@ struct ImageRgb8 {
     ImageRgb8(size_t w, size_t h) : width(w), height(h), data(w * h * 3) {}
 };
 
+// A 16-bit RGB image [h][w][3] (16-bit PNG / TIFF): `into_rgb32f()` = v / 65535 on the device, half the bytes cross PCIe.
+struct ImageRgb16 {
+    size_t width = 0, height = 0;
+    std::vector<uint16_t> data;
+    ImageRgb16() = default;
+    ImageRgb16(size_t w, size_t h) : width(w), height(h), data(w * h * 3) {}
+};
+
 class MarkBuf {                                        // algorithm.rs:607-645
 public:
     MarkBuf() = default;
@@ -176,6 +184,12 @@ public:
         if (image.data.size() != w_ * h_ * 3) throw Error(SSW_ERR_BAD_DIMS, "Writer::new");
         ssw_config c = config.c();
         check(ssw_writer_create_rgb8(ctx.get(), image.data.data(), w_, h_, &c, &wr_), "Writer::new");
+    }
+    Writer(Context& ctx, const ImageRgb16& image, const WriteConfig& config = WriteConfig())
+        : w_(image.width), h_(image.height) {
+        if (image.data.size() != w_ * h_ * 3) throw Error(SSW_ERR_BAD_DIMS, "Writer::new");
+        ssw_config c = config.c();
+        check(ssw_writer_create_rgb16(ctx.get(), image.data.data(), w_, h_, &c, &wr_), "Writer::new");
     }
     ~Writer() { ssw_writer_destroy(wr_); }
     Writer(const Writer&) = delete;
@@ -253,6 +267,12 @@ private:
         if (image.data.size() != w_ * h_ * 3) throw Error(SSW_ERR_BAD_DIMS, "Reader::new_impl");
         ssw_config c = config.c();
         check(ssw_reader_create_rgb8(ctx.get(), image.data.data(), w_, h_, is_base ? 1 : 0, &c, &rd_), "Reader::new_impl");
+    }
+    Reader(Context& ctx, const ImageRgb16& image, bool is_base, const ReadConfig& config)
+        : w_(image.width), h_(image.height) {
+        if (image.data.size() != w_ * h_ * 3) throw Error(SSW_ERR_BAD_DIMS, "Reader::new_impl");
+        ssw_config c = config.c();
+        check(ssw_reader_create_rgb16(ctx.get(), image.data.data(), w_, h_, is_base ? 1 : 0, &c, &rd_), "Reader::new_impl");
     }
     size_t w_, h_;
     ssw_reader* rd_ = nullptr;

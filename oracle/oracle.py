@@ -64,6 +64,11 @@ def _load() -> C.CDLL:
     lib.sswo_u8_to_f32.restype = None
     lib.sswo_f32_to_u8.argtypes = [_f32p, C.c_size_t, _u8p]
     lib.sswo_f32_to_u8.restype = None
+    _u16p = C.POINTER(C.c_uint16)
+    lib.sswo_u16_to_f32.argtypes = [_u16p, C.c_size_t, _f32p]
+    lib.sswo_u16_to_f32.restype = None
+    lib.sswo_f32_to_u16.argtypes = [_f32p, C.c_size_t, _u16p]
+    lib.sswo_f32_to_u16.restype = None
     lib.sswo_resize_rgb8.argtypes = [_u8p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, _u8p]
     lib.sswo_resize_rgb8.restype = None
     lib.sswo_resize_taps.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32), _f32p, C.c_size_t]
@@ -237,6 +242,22 @@ def f32_to_u8(img_f32):
     a = _f32(img_f32)
     out = np.empty(a.shape, np.uint8)
     lib().sswo_f32_to_u8(_p(a), a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
+def u16_to_f32(img_u16):
+    """`into_rgb32f` for 16-bit input: v / 65535."""
+    a = np.ascontiguousarray(img_u16, dtype=np.uint16)
+    out = np.empty(a.shape, np.float32)
+    lib().sswo_u16_to_f32(a.ctypes.data_as(C.POINTER(C.c_uint16)), a.size, _p(out))
+    return out
+
+
+def f32_to_u16(img_f32):
+    """`into_rgb16` from Rgb32F: round(clamp(v, 0, 1) * 65535)."""
+    a = _f32(img_f32)
+    out = np.empty(a.shape, np.uint16)
+    lib().sswo_f32_to_u16(_p(a), a.size, out.ctypes.data_as(C.POINTER(C.c_uint16)))
     return out
 
 

@@ -448,6 +448,19 @@ void sswo_f32_to_u8(const float* in, size_t n, uint8_t* out) {
     }
 }
 
+/* 16-bit boundary (`image 0.24.3`, like the 8-bit forms):
+ *   into_rgb32f for 16-bit input : v / 65535                      (call sites src/algorithm.rs:308, :476)
+ *   into_rgb16 from Rgb32F       : round(clamp(v, 0, 1) * 65535)                                       */
+void sswo_u16_to_f32(const uint16_t* in, size_t n, float* out) {
+    for (size_t i = 0; i < n; ++i) out[i] = (float)in[i] / 65535.0f;
+}
+void sswo_f32_to_u16(const float* in, size_t n, uint16_t* out) {
+    for (size_t i = 0; i < n; ++i) {
+        const float v = clampf(in[i], 0.0f, 1.0f) * 65535.0f;
+        out[i] = (uint16_t)roundf(v);
+    }
+}
+
 static float catmullrom_kernel(float x) {          /* bc_cubic_spline(x, b = 0, c = 0.5) */
     const float b = 0.0f, c = 0.5f;
     const float a = fabsf(x);

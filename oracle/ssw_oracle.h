@@ -81,6 +81,8 @@ void sswo_synth_frame(uint32_t seed, uint32_t frame, size_t w, size_t h, float* 
    parity unpinned; see the .c file). */
 void sswo_u8_to_f32(const uint8_t* in, size_t n, float* out);
 void sswo_f32_to_u8(const float* in, size_t n, uint8_t* out);
+void sswo_u16_to_f32(const uint16_t* in, size_t n, float* out);      /* into_rgb32f of ImageRgb16: v / 65535 */
+void sswo_f32_to_u16(const float* in, size_t n, uint16_t* out);      /* into_rgb16: round(clamp(v,0,1) * 65535) */
 size_t sswo_resize_taps(size_t in_len, size_t out_len, size_t out_idx, uint32_t* left_out, float* ws, size_t max_taps);
 void sswo_resize_rgb8(const uint8_t* in, size_t w, size_t h, size_t nw, size_t nh, uint8_t* out);
 

@@ -85,9 +85,14 @@ SIGNATURES = {
     "ssw_convert_f32_to_rgb8": (C.c_int, [_vp, _f32p, _sz, _vp]),
     "ssw_resize_rgb8": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "ssw_batch_embed_rgb8": (C.c_int, [_vp, _cfgp, _vp, _sz, _sz, _sz, _f32p, _sz, _vp]),
+    "ssw_convert_rgb16_to_f32": (C.c_int, [_vp, _vp, _sz, _f32p]),
+    "ssw_convert_f32_to_rgb16": (C.c_int, [_vp, _f32p, _sz, _vp]),
+    "ssw_batch_embed_rgb16": (C.c_int, [_vp, _cfgp, _vp, _sz, _sz, _sz, _f32p, _sz, _f32p]),
+    "ssw_batch_extract_rgb16": (C.c_int, [_vp, _cfgp, _vp, _vp, _sz, _sz, _sz, _sz, _f32p, _f32p, _f32p]),
     "ssw_batch_extract_rgb8": (C.c_int, [_vp, _cfgp, _vp, _vp, _sz, _sz, _sz, _sz, _f32p, _f32p, _f32p]),
     "ssw_writer_create": (C.c_int, [_vp, _vp, _sz, _sz, _cfgp, C.POINTER(_vp)]),
     "ssw_writer_create_rgb8": (C.c_int, [_vp, _vp, _sz, _sz, _cfgp, C.POINTER(_vp)]),
+    "ssw_writer_create_rgb16": (C.c_int, [_vp, _vp, _sz, _sz, _cfgp, C.POINTER(_vp)]),
     "ssw_writer_coefficients": (C.c_int, [_vp, _vp]),
     "ssw_writer_embed": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_sz), _sz]),
     "ssw_writer_result": (C.c_int, [_vp, _vp]),
@@ -97,6 +102,7 @@ SIGNATURES = {
     "ssw_writer_destroy": (C.c_int, [_vp]),
     "ssw_reader_create": (C.c_int, [_vp, _vp, _sz, _sz, C.c_int, _cfgp, C.POINTER(_vp)]),
     "ssw_reader_create_rgb8": (C.c_int, [_vp, _vp, _sz, _sz, C.c_int, _cfgp, C.POINTER(_vp)]),
+    "ssw_reader_create_rgb16": (C.c_int, [_vp, _vp, _sz, _sz, C.c_int, _cfgp, C.POINTER(_vp)]),
     "ssw_reader_coefficients": (C.c_int, [_vp, _vp]),
     "ssw_reader_indices": (C.c_int, [_vp, _sz, _vp]),
     "ssw_reader_extract": (C.c_int, [_vp, _vp, _vp, _sz]),

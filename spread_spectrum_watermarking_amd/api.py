@@ -269,16 +269,14 @@ class ReadConfig:
 
 
 def _as_rgb(image) -> np.ndarray:
-    """What crosses the C ABI for a `DynamicImage`: 8-bit images as they are (`into_rgb32f()`, algorithm.rs:308,
-    :476, then runs on the device: v / 255), everything else as f32 (u16 -> v / 65535 on the host)."""
+    """What crosses the C ABI for a `DynamicImage`: 8- and 16-bit images as they are (`into_rgb32f()`, algorithm.rs:308,
+    :476, then runs on the device: v / 255, v / 65535), everything else as f32."""
     a = np.asarray(image)
     if a.ndim != 3 or a.shape[2] not in (3, 4):
         raise ValueError("image must be [H, W, 3] (or RGBA [H, W, 4])")
     a = a[:, :, :3]
-    if a.dtype == np.uint8:
+    if a.dtype in (np.uint8, np.uint16):
         return np.ascontiguousarray(a)
-    if a.dtype == np.uint16:
-        a = a.astype(np.float32) / np.float32(65535)
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
@@ -335,7 +333,8 @@ class Writer:
         self.height, self.width = rgb.shape[:2]
         h = C.c_void_p()
         cfg = config._c()
-        create = self._lib.ssw_writer_create_rgb8 if rgb.dtype == np.uint8 else self._lib.ssw_writer_create
+        create = {np.dtype(np.uint8): self._lib.ssw_writer_create_rgb8,
+                  np.dtype(np.uint16): self._lib.ssw_writer_create_rgb16}.get(rgb.dtype, self._lib.ssw_writer_create)
         check(create(self._ctx.handle, rgb.ctypes.data, self.width, self.height, C.byref(cfg), C.byref(h)), "Writer::new")
         self._h = h
 
@@ -402,7 +401,8 @@ class Reader:
         self.is_base = is_base
         h = C.c_void_p()
         cfg = config._c() if config is not None else None
-        create = self._lib.ssw_reader_create_rgb8 if rgb.dtype == np.uint8 else self._lib.ssw_reader_create
+        create = {np.dtype(np.uint8): self._lib.ssw_reader_create_rgb8,
+                  np.dtype(np.uint16): self._lib.ssw_reader_create_rgb16}.get(rgb.dtype, self._lib.ssw_reader_create)
         check(create(self._ctx.handle, rgb.ctypes.data, self.width, self.height, int(is_base),
                      C.byref(cfg) if cfg is not None else None, C.byref(h)), "Reader::new_impl")
         self._h = h

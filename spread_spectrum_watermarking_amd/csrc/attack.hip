@@ -73,6 +73,31 @@ static inline unsigned sgrid(size_t items) {
     return (unsigned)b;
 }
 
+// 16-bit boundary: into_rgb32f of an Rgb16 image (v / 65535, src/algorithm.rs:308, :476) and into_rgb16 of an Rgb32F one
+// (round(clamp(v, 0, 1) * 65535), `image 0.24.3` like the 8-bit forms)
+__global__ void u16_to_f32_kernel(const uint16_t* __restrict__ in, size_t n, float* __restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (float)in[i] / 65535.0f;
+}
+__global__ void f32_to_u16_kernel(const float* __restrict__ in, size_t n, uint16_t* __restrict__ out) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = in[i];
+        v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);                // f32::clamp: NaN passes through and saturates to 0 below
+        out[i] = (uint16_t)roundf(v * 65535.0f);
+    }
+}
+template <bool WITH_IQ>
+__global__ __launch_bounds__(256) void rgb16_to_yiq_kernel(const uint16_t* __restrict__ rgb, size_t npix,
+                                                           float* __restrict__ y, float* __restrict__ ip, float* __restrict__ qp) {
+    for (size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x; p < npix; p += (size_t)gridDim.x * blockDim.x) {
+        const float r = (float)rgb[3 * p] / 65535.0f, g = (float)rgb[3 * p + 1] / 65535.0f, b = (float)rgb[3 * p + 2] / 65535.0f;
+        y[p] = dot3a(0.30f, 0.59f, 0.11f, r, g, b);                 // yiq.rs:131-136, :177-186
+        if (WITH_IQ) {
+            ip[p] = dot3a(0.60f, -0.28f, -0.32f, r, g, b);
+            qp[p] = dot3a(0.21f, -0.52f, 0.31f, r, g, b);
+        }
+    }
+}
+
 int launch_u8_to_f32(hipStream_t st, const uint8_t* in, size_t n, float* out) {
     if (!n) return SSW_OK;
     u8_to_f32_kernel<<<sgrid(n), 256, 0, st>>>(in, n, out);
@@ -89,6 +114,25 @@ int launch_rgb8_to_yiq(hipStream_t st, const uint8_t* rgb, size_t npix, float* y
     if (!npix) return SSW_OK;
     if (i && q) rgb8_to_yiq_kernel<true><<<sgrid(npix), 256, 0, st>>>(rgb, npix, y, i, q);
     else        rgb8_to_yiq_kernel<false><<<sgrid(npix), 256, 0, st>>>(rgb, npix, y, nullptr, nullptr);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+int launch_u16_to_f32(hipStream_t st, const uint16_t* in, size_t n, float* out) {
+    if (n == 0) return SSW_OK;
+    u16_to_f32_kernel<<<sgrid(n), 256, 0, st>>>(in, n, out);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+int launch_f32_to_u16(hipStream_t st, const float* in, size_t n, uint16_t* out) {
+    if (n == 0) return SSW_OK;
+    f32_to_u16_kernel<<<sgrid(n), 256, 0, st>>>(in, n, out);
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+int launch_rgb16_to_yiq(hipStream_t st, const uint16_t* rgb, size_t npix, float* y, float* i, float* q) {
+    if (npix == 0) return SSW_OK;
+    if (i && q) rgb16_to_yiq_kernel<true><<<sgrid(npix), 256, 0, st>>>(rgb, npix, y, i, q);
+    else        rgb16_to_yiq_kernel<false><<<sgrid(npix), 256, 0, st>>>(rgb, npix, y, nullptr, nullptr);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -417,10 +417,23 @@ __global__ __launch_bounds__(256) void pair_prep4_cols_kernel(const float* __res
 __device__ inline float prep_dot3(float m0, float m1, float m2, float a, float b, float c) { return m0 * a + m1 * b + m2 * c; }
 
 // 4 consecutive pixels starting at pixel x of a row (x % 4 == 0): Y (and I, Q)
-template <bool U8, bool WITH_IQ>
+// FMT: SSW_PIX_F32 / U8 / U16 (into_rgb32f: as it is, v / 255, v / 65535)
+template <int FMT, bool WITH_IQ>
 __device__ inline void load_yiq4(const void* row_base, unsigned x, f32x4& y, f32x4& iv, f32x4& qv) {
     float r[4], g[4], b[4];
-    if (!U8) {
+    if (FMT == SSW_PIX_U16) {
+        const u32x2* src = reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(row_base) + 3 * (size_t)x);
+        const u32x2 w0 = src[0], w1 = src[1], w2 = src[2];
+        const uint32_t wd[6] = {w0[0], w0[1], w1[0], w1[1], w2[0], w2[1]};
+        float v[12];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {                               // into_rgb32f: v / 65535
+            v[2 * e] = (float)(wd[e] & 0xFFFFu) / 65535.0f;
+            v[2 * e + 1] = (float)(wd[e] >> 16) / 65535.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r[e] = v[3 * e]; g[e] = v[3 * e + 1]; b[e] = v[3 * e + 2]; }
+    } else if (FMT == SSW_PIX_F32) {
         const f32x4* src = reinterpret_cast<const f32x4*>(static_cast<const float*>(row_base) + 3 * (size_t)x);
         const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
         r[0] = v0[0]; g[0] = v0[1]; b[0] = v0[2];
@@ -448,7 +461,7 @@ __device__ inline void load_yiq4(const void* row_base, unsigned x, f32x4& y, f32
     }
 }
 
-template <typename T, bool U8, bool WITH_IQ>
+template <typename T, int FMT, bool WITH_IQ>
 __global__ __launch_bounds__(256) void pair_prep4_rows_rgb_kernel(const void* __restrict__ RGB, T* __restrict__ Q1,
                                                                  T* __restrict__ Q2, T* __restrict__ P,
                                                                  float* __restrict__ IP, float* __restrict__ QP,
@@ -460,13 +473,12 @@ __global__ __launch_bounds__(256) void pair_prep4_rows_rgb_kernel(const void* __
     if (row >= rows || q >= Kq) return;
     vec4_t<T> a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
     if (q < Nq) {                                                 // Nq % 4 == 0
-        const void* base = U8 ? static_cast<const void*>(static_cast<const uint8_t*>(RGB) + (size_t)row * W * 3)
-                              : static_cast<const void*>(static_cast<const float*>(RGB) + (size_t)row * W * 3);
+        const void* base = static_cast<const char*>(RGB) + (size_t)row * W * 3 * (FMT == SSW_PIX_U8 ? 1 : FMT == SSW_PIX_U16 ? 2 : 4);
         const unsigned pos[4] = {q, Nh - 4 - q, Nh + q, W - 4 - q};
         f32x4 y[4], iv, qv;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            load_yiq4<U8, WITH_IQ>(base, pos[u], y[u], iv, qv);
+            load_yiq4<FMT, WITH_IQ>(base, pos[u], y[u], iv, qv);
             if (WITH_IQ) {
                 *reinterpret_cast<f32x4*>(IP + (size_t)row * W + pos[u]) = iv;
                 *reinterpret_cast<f32x4*>(QP + (size_t)row * W + pos[u]) = qv;
@@ -520,12 +532,13 @@ __global__ __launch_bounds__(256) void pair_prep8_rows_kernel(const void* __rest
 #pragma unroll
             for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(xr + pos[u]);
         } else {
-            const void* base = SRC == 2 ? static_cast<const void*>(static_cast<const uint8_t*>(SRCP) + (size_t)row * W * 3)
+            const void* base = SRC == 3 ? static_cast<const void*>(static_cast<const uint16_t*>(SRCP) + (size_t)row * W * 3)
+                           : SRC == 2 ? static_cast<const void*>(static_cast<const uint8_t*>(SRCP) + (size_t)row * W * 3)
                                         : static_cast<const void*>(static_cast<const float*>(SRCP) + (size_t)row * W * 3);
             f32x4 iv, qv;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                load_yiq4<SRC == 2, WITH_IQ>(base, pos[u], x[u], iv, qv);
+                load_yiq4<SRC - 1, WITH_IQ>(base, pos[u], x[u], iv, qv);
                 if (WITH_IQ) {
                     *reinterpret_cast<f32x4*>(IP + (size_t)row * W + pos[u]) = iv;
                     *reinterpret_cast<f32x4*>(QP + (size_t)row * W + pos[u]) = qv;
@@ -609,13 +622,14 @@ __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __res
             x[15 - u] = *reinterpret_cast<const f32x4*>(xr + (W - 4 - pos[u]));
         }
     } else {
-        const void* base = SRC == 2 ? static_cast<const void*>(static_cast<const uint8_t*>(SRCP) + (size_t)row * W * 3)
+        const void* base = SRC == 3 ? static_cast<const void*>(static_cast<const uint16_t*>(SRCP) + (size_t)row * W * 3)
+                           : SRC == 2 ? static_cast<const void*>(static_cast<const uint8_t*>(SRCP) + (size_t)row * W * 3)
                                     : static_cast<const void*>(static_cast<const float*>(SRCP) + (size_t)row * W * 3);
         f32x4 iv, qv;
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
             const unsigned p = u < 8 ? pos[u] : W - 4 - pos[15 - u];
-            load_yiq4<SRC == 2, WITH_IQ>(base, p, x[u], iv, qv);
+            load_yiq4<SRC - 1, WITH_IQ>(base, p, x[u], iv, qv);
             if (WITH_IQ) {
                 *reinterpret_cast<f32x4*>(IP + (size_t)row * W + p) = iv;
                 *reinterpret_cast<f32x4*>(QP + (size_t)row * W + p) = qv;
@@ -1150,7 +1164,7 @@ int launch_dct_pair_prep4(hipStream_t st, bool f64, bool is_row, bool inverse, c
 }
 
 template <typename T>
-static int prep4_rgb_impl(hipStream_t st, bool u8, const void* rgb, size_t n_frames, size_t w, size_t h,
+static int prep4_rgb_impl(hipStream_t st, int u8, const void* rgb, size_t n_frames, size_t w, size_t h,
                           T* q1, T* q2, T* p, float* ip, float* qp) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
@@ -1161,8 +1175,9 @@ static int prep4_rgb_impl(hipStream_t st, bool u8, const void* rgb, size_t n_fra
     const bool iq = ip && qp;
 #define SSW_PREP_RGB(U8V, IQV) pair_prep4_rows_rgb_kernel<T, U8V, IQV><<<(unsigned)nblk, 256, 0, st>>>( \
         rgb, q1, q2, p, ip, qp, (unsigned)rows, (unsigned)w, Kq, Kp, tiles_q)
-    if (u8) { if (iq) SSW_PREP_RGB(true, true); else SSW_PREP_RGB(true, false); }
-    else    { if (iq) SSW_PREP_RGB(false, true); else SSW_PREP_RGB(false, false); }
+    if (u8 == SSW_PIX_U8)       { if (iq) SSW_PREP_RGB(SSW_PIX_U8, true); else SSW_PREP_RGB(SSW_PIX_U8, false); }
+    else if (u8 == SSW_PIX_U16) { if (iq) SSW_PREP_RGB(SSW_PIX_U16, true); else SSW_PREP_RGB(SSW_PIX_U16, false); }
+    else                        { if (iq) SSW_PREP_RGB(SSW_PIX_F32, true); else SSW_PREP_RGB(SSW_PIX_F32, false); }
 #undef SSW_PREP_RGB
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
@@ -1170,10 +1185,10 @@ static int prep4_rgb_impl(hipStream_t st, bool u8, const void* rgb, size_t n_fra
 
 // rows-first forward transform with two folding levels on the row axis: the first pre-pass straight
 // from the interleaved RGB frames (u8 or f32); ip / qp (both or neither) receive the I and Q planes.
-bool dct_pair_can_prep_from_rgb(size_t w, size_t h, const void* rgb, bool u8) {
-    return w >= h && dct_pair_can_fold2(w) && (reinterpret_cast<uintptr_t>(rgb) & (u8 ? 3 : 15)) == 0;
+bool dct_pair_can_prep_from_rgb(size_t w, size_t h, const void* rgb, int u8) {
+    return w >= h && dct_pair_can_fold2(w) && (reinterpret_cast<uintptr_t>(rgb) & pix_align_mask(u8)) == 0;
 }
-int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, bool u8, const void* rgb, size_t n_frames, size_t w, size_t h,
+int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, int u8, const void* rgb, size_t n_frames, size_t w, size_t h,
                                    void* q1, void* q2, void* p, float* ip, float* qp) {
     return f64 ? prep4_rgb_impl<double>(st, u8, rgb, n_frames, w, h, (double*)q1, (double*)q2, (double*)p, ip, qp)
                : prep4_rgb_impl<float>(st, u8, rgb, n_frames, w, h, (float*)q1, (float*)q2, (float*)p, ip, qp);
@@ -1194,7 +1209,8 @@ static int prep8_impl(hipStream_t st, int src_kind, const void* src, size_t n_fr
         src, r1, r2, m, p, ip, qp, (unsigned)rows, (unsigned)w, K8, Kq, Kp, tiles_e)
     if (src_kind == 0) SSW_PREP8(0, false);
     else if (src_kind == 1) { if (iq) SSW_PREP8(1, true); else SSW_PREP8(1, false); }
-    else                    { if (iq) SSW_PREP8(2, true); else SSW_PREP8(2, false); }
+    else if (src_kind == 2) { if (iq) SSW_PREP8(2, true); else SSW_PREP8(2, false); }
+    else                    { if (iq) SSW_PREP8(3, true); else SSW_PREP8(3, false); }
 #undef SSW_PREP8
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
@@ -1253,7 +1269,8 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
         src, dp, rot1, rot2, ip, qp, (unsigned)rows, (unsigned)w, K8, K16, tiles_e)
     if (src_kind == 0) SSW_PREP16(0, false);
     else if (src_kind == 1) { if (iq) SSW_PREP16(1, true); else SSW_PREP16(1, false); }
-    else                    { if (iq) SSW_PREP16(2, true); else SSW_PREP16(2, false); }
+    else if (src_kind == 2) { if (iq) SSW_PREP16(2, true); else SSW_PREP16(2, false); }
+    else                    { if (iq) SSW_PREP16(3, true); else SSW_PREP16(3, false); }
 #undef SSW_PREP16
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;

@@ -97,7 +97,7 @@ struct Xform {
     float* data;
     float* tmp;
     const void* rgb = nullptr;
-    bool rgb_u8 = false;
+    int rgb_u8 = 0;                 // SSW_PIX_* of `rgb`
     float* iq_i = nullptr;
     float* iq_q = nullptr;
     // inverse transforms (Writer::result): where the last pass may deliver RGB pixels instead of the Y plane
@@ -111,13 +111,13 @@ struct Xform {
     bool natural_order = false;
 };
 int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch, bool* fused_rgb = nullptr);
-bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8);
+bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, int u8);
 // rgb -> Y (+ I, Q) -> forward transform of Y into `y` (Writer::new / Reader::new_impl), fused where possible
-int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t n, size_t w,
+int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, int u8, size_t n, size_t w,
                            size_t h, float* y, float* i, float* q, float* tmp, Chain& ch);
 // the same transform as two chains: the row pass of a band of image rows, and the column pass of the whole frame
-bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8);
-int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t w, size_t rows,
+bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, int u8);
+int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, int u8, size_t w, size_t rows,
                             size_t frame_h, float* tmp, float* i, float* q, Chain& ch);
 int build_forward_cols_after_rows(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, size_t w, size_t h, float* tmp, float* y, Chain& ch);
 int run_serial(Chain& ch, hipStream_t st);
@@ -128,16 +128,16 @@ int dct2d_planes(ssw_ctx* ctx, int type, int precision, size_t n, size_t w, size
 int topk(ssw_ctx* ctx, hipStream_t st, SelectWorkspace& sel, const float* coef, size_t n, size_t w, size_t h, int ordering,
          size_t k, uint32_t* idx);
 
-int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, bool u8_in, size_t n_frames, size_t w,
+int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, int u8_in, size_t n_frames, size_t w,
                      size_t h, const float* dev_marks, size_t k, void* dev_rgb_out, bool u8_out, float* dev_coef_out,
                      uint32_t* dev_indices_out);
-int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base_rgb, const void* dev_derived_rgb, bool u8,
+int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base_rgb, const void* dev_derived_rgb, int u8,
                        size_t n_frames, size_t w, size_t h, size_t k, float* dev_extracted, const float* dev_marks,
                        float* dev_sims);
 
 // Reader::extract with a derived frame that is still RGB on the device (single-image handles): pruned transform +
 // extraction enqueued on the context's stream; see ssw_pipeline.hip
-int extract_single_pruned(ssw_ctx* ctx, int precision, const void* derived_rgb, bool u8, size_t w, size_t h, const float* base_y,
+int extract_single_pruned(ssw_ctx* ctx, int precision, const void* derived_rgb, int u8, size_t w, size_t h, const float* base_y,
                           const uint32_t* idx, size_t k, int method, float alpha, float* dev_out, uint32_t** dev_info,
                           bool* applicable);
 

@@ -96,8 +96,14 @@ int launch_dct_pair_prep4(hipStream_t st, bool f64, bool is_row, bool inverse, c
                           size_t h, void* q1, void* q2, void* p);
 // first pass of a rows-first forward transform straight from interleaved RGB (u8 or f32), two levels;
 // ip / qp: I and Q planes out (both or neither)
-bool dct_pair_can_prep_from_rgb(size_t w, size_t h, const void* rgb, bool u8);
-int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, bool u8, const void* rgb, size_t n_frames, size_t w, size_t h,
+// Sample format of an interleaved RGB frame at the boundary (`u8` parameters below): what `into_rgb32f()` accepts
+// (src/algorithm.rs:308, :476): f32 as it is, 8-bit v / 255, 16-bit v / 65535
+enum { SSW_PIX_F32 = 0, SSW_PIX_U8 = 1, SSW_PIX_U16 = 2 };
+inline size_t pix_bytes(int fmt) { return fmt == SSW_PIX_U8 ? 1 : fmt == SSW_PIX_U16 ? 2 : 4; }          // per sample
+inline unsigned pix_align_mask(int fmt) { return fmt == SSW_PIX_U8 ? 3u : fmt == SSW_PIX_U16 ? 7u : 15u; }   // of a 4-pixel load
+inline int pix_src_kind(int fmt) { return fmt + 1; }                     // SRC of the row pre-passes: 1 f32, 2 u8, 3 u16
+bool dct_pair_can_prep_from_rgb(size_t w, size_t h, const void* rgb, int u8);
+int launch_dct_pair_prep4_rows_rgb(hipStream_t st, bool f64, int u8, const void* rgb, size_t n_frames, size_t w, size_t h,
                                    void* q1, void* q2, void* p, float* ip, float* qp);
 // three levels on a forward row pass: (SSS, SS-) [kpad(w/4) wide], S- [kpad(w/2)], x- [kpad(w)] from an f32
 // plane (src_kind 0) or interleaved RGB f32 / u8 (1 / 2; ip / qp: I, Q planes out or null)
@@ -218,6 +224,9 @@ void build_resize_taps(size_t in_len, size_t out_len, ResizeTaps& t);
 int launch_u8_to_f32(hipStream_t st, const uint8_t* in, size_t n, float* out);
 int launch_f32_to_u8(hipStream_t st, const float* in, size_t n, uint8_t* out);
 int launch_rgb8_to_yiq(hipStream_t st, const uint8_t* rgb, size_t npix, float* y, float* i, float* q);
+int launch_u16_to_f32(hipStream_t st, const uint16_t* in, size_t n, float* out);
+int launch_f32_to_u16(hipStream_t st, const float* in, size_t n, uint16_t* out);
+int launch_rgb16_to_yiq(hipStream_t st, const uint16_t* rgb, size_t npix, float* y, float* i, float* q);
 int launch_yiq_to_rgb8(hipStream_t st, const float* y, const float* i, const float* q, size_t npix, uint8_t* rgb);
 size_t resize_tmp_bytes(const uint8_t* in, size_t n_frames, size_t w, size_t h, size_t nw, size_t nh, const DeviceTaps& vt,
                         const DeviceTaps& ht, const uint8_t* out);

@@ -48,7 +48,7 @@ struct ssw_reader {
     // frequency columns those need (the pruned transform of the batch path, bit-identical values); fully when
     // coefficients() is called or the pruned path does not apply.
     void* rgb = nullptr;
-    bool rgb_u8 = false;
+    int rgb_u8 = 0;                 // SSW_PIX_* of `rgb`
     hipEvent_t rgb_uploaded = nullptr;
 };
 
@@ -115,10 +115,10 @@ int stage_consumed(ssw_ctx* ctx, ssw_ctx::FrameStage& fs) {
 
 // Writer::new / Reader::new_impl up to the coefficients (:308-313, :476-480): host frame (f32 or 8-bit) -> Y
 // (+ I, Q) -> forward transform, through the same fused chain as the batch entry points (n = 1).  Enqueues only.
-int forward_from_host(ssw_ctx* ctx, const void* host_rgb, bool u8, size_t w, size_t h, int precision, float* y, float* i,
+int forward_from_host(ssw_ctx* ctx, const void* host_rgb, int u8, size_t w, size_t h, int precision, float* y, float* i,
                       float* q) {
     const size_t plane = w * h;
-    const size_t bytes = plane * 3 * (u8 ? 1 : sizeof(float));
+    const size_t bytes = plane * 3 * pix_bytes(u8);
     SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
     float* tmp = (float*)ctx->lane[0].plane[3].p;
     {
@@ -589,14 +589,42 @@ int ssw_batch_extract(ssw_ctx* ctx, const ssw_config* cfg, const float* dev_base
 
 int ssw_batch_embed_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* dev_rgb, size_t n_frames,
                          size_t w, size_t h, const float* dev_marks, size_t k, uint8_t* dev_rgb_out) {
-    return batch_embed_impl(ctx, cfg, dev_rgb, true, n_frames, w, h, dev_marks, k, dev_rgb_out, true, nullptr, nullptr);
+    return batch_embed_impl(ctx, cfg, dev_rgb, SSW_PIX_U8, n_frames, w, h, dev_marks, k, dev_rgb_out, true, nullptr, nullptr);
 }
 
 int ssw_batch_extract_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* dev_base_rgb,
                            const uint8_t* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
                            float* dev_extracted, const float* dev_marks, float* dev_sims) {
-    return batch_extract_impl(ctx, cfg, dev_base_rgb, dev_derived_rgb, true, n_frames, w, h, k, dev_extracted,
+    return batch_extract_impl(ctx, cfg, dev_base_rgb, dev_derived_rgb, SSW_PIX_U8, n_frames, w, h, k, dev_extracted,
                               dev_marks, dev_sims);
+}
+
+// ---- 16-bit boundary (`into_rgb32f()` of an Rgb16 image, v / 65535, fused into the first operand
+// pre-pass like the 8-bit form; Writer::mark returns Rgb32F, src/algorithm.rs:355-379, so the marked frames leave as f32) ----
+int ssw_batch_embed_rgb16(ssw_ctx* ctx, const ssw_config* cfg, const uint16_t* dev_rgb, size_t n_frames,
+                          size_t w, size_t h, const float* dev_marks, size_t k, float* dev_rgb_out) {
+    return batch_embed_impl(ctx, cfg, dev_rgb, SSW_PIX_U16, n_frames, w, h, dev_marks, k, dev_rgb_out, false, nullptr, nullptr);
+}
+
+int ssw_batch_extract_rgb16(ssw_ctx* ctx, const ssw_config* cfg, const uint16_t* dev_base_rgb,
+                            const uint16_t* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
+                            float* dev_extracted, const float* dev_marks, float* dev_sims) {
+    return batch_extract_impl(ctx, cfg, dev_base_rgb, dev_derived_rgb, SSW_PIX_U16, n_frames, w, h, k, dev_extracted,
+                              dev_marks, dev_sims);
+}
+
+int ssw_convert_rgb16_to_f32(ssw_ctx* ctx, const uint16_t* dev_in, size_t n_values, float* dev_out) {
+    if (!ctx || (n_values && (!dev_in || !dev_out))) return SSW_ERR_BAD_ARG;
+    CtxGuard g(ctx);
+    StageTimer t(ctx, SSW_STAGE_CONVERT, ctx->stream);
+    return launch_u16_to_f32(ctx->stream, dev_in, n_values, dev_out);
+}
+
+int ssw_convert_f32_to_rgb16(ssw_ctx* ctx, const float* dev_in, size_t n_values, uint16_t* dev_out) {
+    if (!ctx || (n_values && (!dev_in || !dev_out))) return SSW_ERR_BAD_ARG;
+    CtxGuard g(ctx);
+    StageTimer t(ctx, SSW_STAGE_CONVERT, ctx->stream);
+    return launch_f32_to_u16(ctx->stream, dev_in, n_values, dev_out);
 }
 
 // ---- 8-bit boundary and the resize attack ---------------------------------------------------------
@@ -639,7 +667,7 @@ int ssw_resize_rgb8(ssw_ctx* ctx, const uint8_t* dev_in, size_t n_frames, size_t
 }
 
 // ---- Writer ---------------------------------------------------------------------------------
-static int writer_create_impl(ssw_ctx* ctx, const void* rgb_hwc, bool u8, size_t w, size_t h, const ssw_config* cfg,
+static int writer_create_impl(ssw_ctx* ctx, const void* rgb_hwc, int u8, size_t w, size_t h, const ssw_config* cfg,
                               ssw_writer** out) {
     if (!ctx || !rgb_hwc || !out) return SSW_ERR_BAD_ARG;
     *out = nullptr;
@@ -667,7 +695,12 @@ int ssw_writer_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h,
 
 int ssw_writer_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_t h,
                            const ssw_config* cfg, ssw_writer** out) {
-    return writer_create_impl(ctx, rgb_hwc, true, w, h, cfg, out);
+    return writer_create_impl(ctx, rgb_hwc, SSW_PIX_U8, w, h, cfg, out);
+}
+
+int ssw_writer_create_rgb16(ssw_ctx* ctx, const uint16_t* rgb_hwc, size_t w, size_t h,
+                            const ssw_config* cfg, ssw_writer** out) {
+    return writer_create_impl(ctx, rgb_hwc, SSW_PIX_U16, w, h, cfg, out);
 }
 
 int ssw_writer_coefficients(ssw_writer* wr, float* out_plane) {
@@ -799,7 +832,7 @@ int ssw_writer_destroy(ssw_writer* wr) {
 }
 
 // ---- Reader ---------------------------------------------------------------------------------
-static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, bool u8, size_t w, size_t h, int is_base,
+static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, int u8, size_t w, size_t h, int is_base,
                               const ssw_config* cfg, ssw_reader** out) {
     if (!ctx || !rgb_hwc || !out) return SSW_ERR_BAD_ARG;
     *out = nullptr;
@@ -817,7 +850,7 @@ static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, bool u8, size_t
     auto fail = [&](int rc) { ssw_reader_destroy(rd); return rc; };
     if (!is_base && ctx->prune) {
         // upload only; transformed on first use (see ssw_reader)
-        const size_t bytes = plane * 3 * (u8 ? 1 : sizeof(float));
+        const size_t bytes = plane * 3 * pix_bytes(u8);
         rd->rgb_u8 = u8;
         if (pool_get(ctx, bytes, &rd->rgb) != SSW_OK) return fail(SSW_ERR_OUT_OF_MEMORY);
         if (hipEventCreateWithFlags(&rd->rgb_uploaded, hipEventDisableTiming) != hipSuccess) return fail(SSW_ERR_HIP);
@@ -857,7 +890,7 @@ static int reader_ensure_coefficients(ssw_reader* rd) {
     const int rc = run();
     if (rc != SSW_OK) { pool_put(ctx, y, plane * 4); return rc; }
     rd->y = y;
-    pool_put(ctx, rd->rgb, plane * 3 * (rd->rgb_u8 ? 1 : sizeof(float)));      // reuse is ordered on the stream
+    pool_put(ctx, rd->rgb, plane * 3 * pix_bytes(rd->rgb_u8));      // reuse is ordered on the stream
     rd->rgb = nullptr;
     return SSW_OK;
 }
@@ -869,7 +902,12 @@ int ssw_reader_create(ssw_ctx* ctx, const float* rgb_hwc, size_t w, size_t h, in
 
 int ssw_reader_create_rgb8(ssw_ctx* ctx, const uint8_t* rgb_hwc, size_t w, size_t h, int is_base,
                            const ssw_config* cfg, ssw_reader** out) {
-    return reader_create_impl(ctx, rgb_hwc, true, w, h, is_base, cfg, out);
+    return reader_create_impl(ctx, rgb_hwc, SSW_PIX_U8, w, h, is_base, cfg, out);
+}
+
+int ssw_reader_create_rgb16(ssw_ctx* ctx, const uint16_t* rgb_hwc, size_t w, size_t h, int is_base,
+                            const ssw_config* cfg, ssw_reader** out) {
+    return reader_create_impl(ctx, rgb_hwc, SSW_PIX_U16, w, h, is_base, cfg, out);
 }
 
 int ssw_reader_coefficients(ssw_reader* rd, float* out_plane) {
@@ -947,7 +985,7 @@ int ssw_reader_destroy(ssw_reader* rd) {
     CtxGuard g(ctx);
     pool_put(ctx, rd->y, rd->w * rd->h * 4);
     pool_put(ctx, rd->idx, rd->idx_k * sizeof(uint32_t));
-    pool_put(ctx, rd->rgb, rd->w * rd->h * 3 * (rd->rgb_u8 ? 1 : sizeof(float)));
+    pool_put(ctx, rd->rgb, rd->w * rd->h * 3 * pix_bytes(rd->rgb_u8));
     if (rd->rgb_uploaded) (void)hipEventDestroy(rd->rgb_uploaded);
     delete rd;
     return SSW_OK;

@@ -251,11 +251,11 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
     const int st_pass = is_row ? SSW_STAGE_DCT_ROW : SSW_STAGE_DCT_COL;
     const int st_main = is_row ? SSW_STAGE_DCT_ROW_MAIN : SSW_STAGE_DCT_COL_MAIN;
     const void* rgb = x.rgb;
-    const bool rgb_u8 = x.rgb_u8;
+    const int rgb_u8 = x.rgb_u8;
     float *iq_i = x.iq_i, *iq_q = x.iq_q;
     // algorithmic bytes of the pre-pass: the f32 plane (or the RGB frame) in, the operand planes (one
     // element per pixel in the GEMM's precision, whatever the number of folding levels) and I / Q out
-    const double prep_bytes = from_rgb ? px * ((rgb_u8 ? 3.0 : 12.0) + (iq_i ? 8.0 : 0.0) + esz) : px * (4.0 + esz);
+    const double prep_bytes = from_rgb ? px * (3.0 * (double)pix_bytes(rgb_u8) + (iq_i ? 8.0 : 0.0) + esz) : px * (4.0 + esz);
     const int st_prep = from_rgb ? SSW_STAGE_RGB_TO_YIQ : SSW_STAGE_DCT_PREP;
     if (operand) {
         const size_t bytes = dct_pair_operand_elems(f64, n, w, h) * (size_t)esz;
@@ -298,7 +298,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
                 if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm);
-                return launch_dct_pair_prep16_rows(st, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
+                return launch_dct_pair_prep16_rows(st, from_rgb ? pix_src_kind(rgb_u8) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
                                                    (const double*)rot, (const double*)rot2, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
             }});
             // the "main" timer brackets ONE launch: class E of the full-length split (the largest launch of the pass)
@@ -484,7 +484,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
                 if (!is_row) SSW_TRY(launch_dct_pair_prep8_cols(st, f64, src, n, w, h, r1, r2, d2, d1));
-                else SSW_TRY(launch_dct_pair_prep8_rows(st, f64, from_rgb ? (rgb_u8 ? 2 : 1) : 0, from_rgb ? rgb : (const void*)src, n, w, h,
+                else SSW_TRY(launch_dct_pair_prep8_rows(st, f64, from_rgb ? pix_src_kind(rgb_u8) : 0, from_rgb ? rgb : (const void*)src, n, w, h,
                                                         r1, r2, d2, d1, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr));
                 return odd_rotate(st, d1);
             }});
@@ -596,7 +596,7 @@ int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch, 
             s.n = std::min(max_frames, n - f0);
             s.data = x.data + f0 * w * h;
             s.tmp = x.tmp + f0 * w * h;
-            if (x.rgb) s.rgb = static_cast<const char*>(x.rgb) + f0 * w * h * 3 * (x.rgb_u8 ? 1 : sizeof(float));
+            if (x.rgb) s.rgb = static_cast<const char*>(x.rgb) + f0 * w * h * 3 * pix_bytes(x.rgb_u8);
             if (x.iq_i) s.iq_i = x.iq_i + f0 * w * h;
             if (x.iq_q) s.iq_q = x.iq_q + f0 * w * h;
             if (x.rgb_out) s.rgb_out = static_cast<char*>(x.rgb_out) + f0 * w * h * 3 * (x.rgb_out_u8 ? 1 : sizeof(float));
@@ -622,14 +622,14 @@ int build_transform(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, Chain& ch, 
     return SSW_OK;
 }
 
-bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8) {
+bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, int u8) {
     return ctx->fold && ctx->fold_level >= 4 && dct_pair_can_run(f64, 1, w, h, y, tmp) && dct_pair_can_prep_from_rgb(w, h, rgb, u8);
 }
 
 // Writer::new / Reader::base / Reader::derived: rgb -> Y (+ I, Q) -> forward 2-D DCT of Y into `y`.
 // Where the default GEMM strategy applies (rows first, two folding levels on the row axis) the colour
 // conversion is fused into the first operand pre-pass and the f32 Y plane is never materialised.
-int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t n, size_t w,
+int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, int u8, size_t n, size_t w,
                            size_t h, float* y, float* i, float* q, float* tmp, Chain& ch) {
     const bool f64 = precision == SSW_PRECISION_F64;
     Xform x{SSW_DCT2, precision, n, w, h, y, tmp};
@@ -638,10 +638,11 @@ int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const
         return build_transform(ctx, ws, x, ch);
     }
     const size_t npix = n * w * h;
-    const double bytes = (double)npix * ((u8 ? 3.0 : 12.0) + (i ? 12.0 : 4.0));
+    const double bytes = (double)npix * (3.0 * (double)pix_bytes(u8) + (i ? 12.0 : 4.0));
     ch.push_back({true, [=](hipStream_t st) -> int {
         StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, bytes);
-        if (u8) return launch_rgb8_to_yiq(st, static_cast<const uint8_t*>(rgb), npix, y, i, q);
+        if (u8 == SSW_PIX_U8) return launch_rgb8_to_yiq(st, static_cast<const uint8_t*>(rgb), npix, y, i, q);
+        if (u8 == SSW_PIX_U16) return launch_rgb16_to_yiq(st, static_cast<const uint16_t*>(rgb), npix, y, i, q);
         return launch_rgb_to_yiq(st, static_cast<const float*>(rgb), npix, y, i, q);
     }});
     return build_transform(ctx, ws, x, ch);
@@ -651,10 +652,10 @@ int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const
 // of the top half of a frame runs while the bottom half is still crossing PCIe -- image rows are independent lines
 // of a row pass, so any band of rows gives the values the whole frame gives).  `rows` consecutive image rows starting
 // at `rgb` -> the same rows of the intermediate plane `tmp` (+ I, Q); then the column pass tmp -> y on the whole frame.
-bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, bool u8) {
+bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, int u8) {
     return w >= h && h % 16 == 0 && can_fuse_rgb(ctx, f64, w, h, y, tmp, rgb, u8) && can_fuse_rgb(ctx, f64, w, h / 2, y, tmp, rgb, u8);
 }
-int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t w, size_t rows,
+int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, int u8, size_t w, size_t rows,
                             size_t frame_h, float* tmp, float* i, float* q, Chain& ch) {
     Xform x{SSW_DCT2, precision, 1, w, rows, tmp /* never read or written by this pass */, tmp};
     x.rgb = rgb; x.rgb_u8 = u8; x.iq_i = i; x.iq_q = q;
@@ -815,7 +816,7 @@ size_t prune_capacity(size_t k) {
 }
 
 PruneSetup make_prune_setup(const ssw_ctx* ctx, bool f64, size_t n, size_t w, size_t h, size_t k, const float* y, const float* tmp,
-                            const void* rgb, bool u8) {
+                            const void* rgb, int u8) {
     PruneSetup ps;
     if (!ctx->prune || k == 0) return ps;
     if (!can_fuse_rgb(ctx, f64, w, h, y, tmp, rgb, u8)) return ps;       // rows first, >= two folding levels on the rows
@@ -862,7 +863,7 @@ PruneSetup make_prune_setup(const ssw_ctx* ctx, bool f64, size_t n, size_t w, si
 
 // derived rgb frames -> compact coefficient plane ws.compact[1] [n][h][cap_total] holding, for every
 // frequency column the chunk's index lists use, the column the full transform would produce
-int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, bool u8, size_t n, size_t w,
+int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, int u8, size_t n, size_t w,
                          size_t h, size_t k, const uint32_t* idx, const PruneSetup& ps, uint32_t* info, Chain& ch) {
     const bool f64 = precision == SSW_PRECISION_F64;
     const size_t esz = f64 ? 8 : 4;
@@ -938,13 +939,13 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     const int levels = ps.levels;
     const bool deep = ps.deep;
     const double px = (double)n * (double)w * (double)h;
-    const double prep_bytes = px * ((u8 ? 3.0 : 12.0) + (double)esz);
+    const double prep_bytes = px * (3.0 * (double)pix_bytes(u8) + (double)esz);
     // the set of columns, then Reader::derived's colour conversion + operand pre-pass (same kernels as the full path)
     ch.push_back({true, [=](hipStream_t st) -> int {
         SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
         StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, prep_bytes);
-        if (deep) return launch_dct_pair_prep16_rows(st, u8 ? 2 : 1, rgb, n, w, h, sp, (const double*)rot, (const double*)rot2, nullptr, nullptr);
-        if (levels == 3) SSW_TRY(launch_dct_pair_prep8_rows(st, f64, u8 ? 2 : 1, rgb, n, w, h, o2, o3, o0, o1, nullptr, nullptr));
+        if (deep) return launch_dct_pair_prep16_rows(st, pix_src_kind(u8), rgb, n, w, h, sp, (const double*)rot, (const double*)rot2, nullptr, nullptr);
+        if (levels == 3) SSW_TRY(launch_dct_pair_prep8_rows(st, f64, pix_src_kind(u8), rgb, n, w, h, o2, o3, o0, o1, nullptr, nullptr));
         else SSW_TRY(launch_dct_pair_prep4_rows_rgb(st, f64, u8, rgb, n, w, h, o2, o3, o1, nullptr, nullptr));
         return sp ? launch_dct_pair_rotate(st, (const double*)o1, (const double*)rot, sp, lines, w) : SSW_OK;
     }});
@@ -978,7 +979,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
 }  // namespace
 
 // ---- Writer::new + Writer::mark, batched ------------------------------------------------------------------
-int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, bool u8_in, size_t n_frames, size_t w,
+int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, int u8_in, size_t n_frames, size_t w,
                      size_t h, const float* dev_marks, size_t k, void* dev_rgb_out, bool u8_out, float* dev_coef_out,
                      uint32_t* dev_indices_out) {
     if (!ctx || !dev_rgb || !dev_marks || !dev_rgb_out) return SSW_ERR_BAD_ARG;
@@ -990,7 +991,7 @@ int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, b
     const size_t chunk = effective_chunk(ctx, w, h, n_frames);
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     const ssw_config c = *cfg;
-    const size_t in_px = u8_in ? 3 : 3 * sizeof(float), out_px = u8_out ? 3 : 3 * sizeof(float);
+    const size_t in_px = 3 * pix_bytes(u8_in), out_px = u8_out ? 3 : 3 * sizeof(float);
     auto build = [&](size_t ci, ssw_ctx::Lane& ws, Chain& ch) -> int {
         const size_t f0 = ci * chunk, n = std::min(chunk, n_frames - f0);
         for (int p = 0; p < 4; ++p) SSW_TRY(grow(ws.plane[p], chunk * plane * sizeof(float)));
@@ -1030,7 +1031,7 @@ int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, b
 }
 
 // ---- Reader::base + Reader::derived + extract (+ Tester::similarity), batched --------------------------------
-int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base_rgb, const void* dev_derived_rgb, bool u8,
+int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base_rgb, const void* dev_derived_rgb, int u8,
                        size_t n_frames, size_t w, size_t h, size_t k, float* dev_extracted, const float* dev_marks,
                        float* dev_sims) {
     if (!ctx || !dev_base_rgb || !dev_derived_rgb || !dev_extracted) return SSW_ERR_BAD_ARG;
@@ -1045,7 +1046,7 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
     const size_t n_chunks = (n_frames + chunk - 1) / chunk;
     const ssw_config c = *cfg;
     const bool f64 = c.precision == SSW_PRECISION_F64;
-    const size_t px_bytes = u8 ? 3 : 3 * sizeof(float);
+    const size_t px_bytes = 3 * pix_bytes(u8);
     // planes of lane 0 decide the (alignment-dependent) strategy for all lanes: hipMalloc'd, always 256-byte aligned
     // (lane 1 only when the call will run two lanes: three chunks or more)
     for (int l = 0; l < (pipeline_uses_two_lanes(ctx, n_chunks) ? 2 : 1); ++l)
@@ -1143,7 +1144,7 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
 // values).  Enqueues on the context's stream: the k extracted values into dev_out, the overflow flag into
 // dev_info[0] (non-zero: the columns did not fit, the caller must transform fully).  *applicable = false (nothing
 // enqueued) when the shape or the settings do not take the pruned path.
-int extract_single_pruned(ssw_ctx* ctx, int precision, const void* derived_rgb, bool u8, size_t w, size_t h, const float* base_y,
+int extract_single_pruned(ssw_ctx* ctx, int precision, const void* derived_rgb, int u8, size_t w, size_t h, const float* base_y,
                           const uint32_t* idx, size_t k, int method, float alpha, float* dev_out, uint32_t** dev_info,
                           bool* applicable) {
     *applicable = false;

@@ -240,6 +240,52 @@ def batch_extract_rgb8(base_u8, derived_u8, k, marks, cfg=None):
     return e, s
 
 
+def batch_embed_rgb16(rgb_u16, marks, cfg=None):
+    """ssw_batch_embed_rgb16: u16 frames in, f32 marked frames out (what Writer::mark returns)."""
+    a = np.ascontiguousarray(rgb_u16, dtype=np.uint16)
+    m = np.ascontiguousarray(marks, dtype=np.float32)
+    n, h, w, _ = a.shape
+    c = cfg or default_config()
+    d, dm = ctx().to_device(a), ctx().to_device(m)
+    out = ctx().alloc(a.size * 4)
+    check(lib().ssw_batch_embed_rgb16(ctx().handle, C.byref(c), d.ptr, n, w, h, dm.ptr, m.shape[1], out.ptr), "ssw_batch_embed_rgb16")
+    r = out.to_host(np.float32, a.shape)
+    for b in (d, dm, out):
+        b.free()
+    return r
+
+
+def batch_extract_rgb16(base_u16, derived_u16, k, marks, cfg=None):
+    b, dv = np.ascontiguousarray(base_u16, dtype=np.uint16), np.ascontiguousarray(derived_u16, dtype=np.uint16)
+    n, h, w, _ = b.shape
+    c = cfg or default_config()
+    db, dd = ctx().to_device(b), ctx().to_device(dv)
+    dm = ctx().to_device(np.ascontiguousarray(marks, dtype=np.float32))
+    ext, sims = ctx().alloc(n * k * 4), ctx().alloc(n * 4)
+    check(lib().ssw_batch_extract_rgb16(ctx().handle, C.byref(c), db.ptr, dd.ptr, n, w, h, k, ext.ptr, dm.ptr, sims.ptr),
+          "ssw_batch_extract_rgb16")
+    e, s = ext.to_host(np.float32, (n, k)), sims.to_host(np.float32, (n,))
+    for x in (db, dd, dm, ext, sims):
+        x.free()
+    return e, s
+
+
+def convert_rgb16(values_u16=None, values_f32=None):
+    """ssw_convert_rgb16_to_f32 (u16 in) or ssw_convert_f32_to_rgb16 (f32 in) on a flat array."""
+    if values_u16 is not None:
+        a = np.ascontiguousarray(values_u16, dtype=np.uint16)
+        d, out = ctx().to_device(a), ctx().alloc(a.size * 4)
+        check(lib().ssw_convert_rgb16_to_f32(ctx().handle, d.ptr, a.size, out.ptr), "ssw_convert_rgb16_to_f32")
+        r = out.to_host(np.float32, a.shape)
+    else:
+        a = np.ascontiguousarray(values_f32, dtype=np.float32)
+        d, out = ctx().to_device(a), ctx().alloc(a.size * 2)
+        check(lib().ssw_convert_f32_to_rgb16(ctx().handle, d.ptr, a.size, out.ptr), "ssw_convert_f32_to_rgb16")
+        r = out.to_host(np.uint16, a.shape)
+    d.free(); out.free()
+    return r
+
+
 def similarity_matrix(extracted, marks_db):
     e, m = np.ascontiguousarray(extracted, dtype=np.float32), np.ascontiguousarray(marks_db, dtype=np.float32)
     b, k = e.shape

@@ -20,6 +20,18 @@ def test_u8_boundary_matches_numpy_restatement(cat_images):
     assert np.array_equal(O.f32_to_u8(O.u8_to_f32(cat)), cat)          # exact round trip
 
 
+def test_u16_boundary_matches_numpy_restatement():
+    """into_rgb32f of an ImageRgb16 (src/algorithm.rs:308, :476): v / 65535; into_rgb16: round(clamp * 65535)."""
+    v = np.arange(65536, dtype=np.uint16)
+    f = O.u16_to_f32(v)
+    assert np.array_equal(f, v.astype(np.float32) / np.float32(65535))
+    assert f[0] == 0.0 and f[-1] == 1.0
+    assert np.array_equal(O.f32_to_u16(f), v)                            # exact round trip of every 16-bit value
+    x = np.random.default_rng(0).random((50, 60, 3)).astype(np.float32) * 1.2 - 0.1
+    ref = np.floor(np.clip(x, np.float32(0), np.float32(1)) * np.float32(65535) + np.float32(0.5)).astype(np.uint16)
+    assert np.array_equal(O.f32_to_u16(x), ref)
+
+
 def test_resize_against_independent_bicubic(cat_images):
     Image = pytest.importorskip("PIL.Image")
     cat = cat_images["cat"]

@@ -73,6 +73,55 @@ def test_rgb8_handles_equal_batch_entry_points_and_f32_handles(shape, precision)
             assert abs(sim - o_sim) < 1e-4 * max(1.0, abs(o_sim))
 
 
+@pytest.mark.parametrize("shape", [(256, 144), (1024, 272), (208, 80), (100, 75), (37, 64)])
+@pytest.mark.parametrize("precision", [F32, F64])
+def test_rgb16_entry_points_equal_the_f32_ones_on_host_converted_frames(shape, precision):
+    """SURVEY 8(f) rank 2, the 16-bit half: `into_rgb32f()` of an ImageRgb16 (src/algorithm.rs:308, :476: v / 65535) runs
+    on the device -- ssw_writer_create_rgb16 / ssw_reader_create_rgb16 / ssw_batch_*_rgb16 are bit-identical to the f32
+    entry points fed with the oracle-converted frame (deep, two-level and unfused shapes), and agree with the oracle's
+    own pipeline on that frame."""
+    w, h = shape
+    k = 150
+    ctx = G.ctx()
+    img32 = O.synth_frame(13, 0, w, h)
+    img16 = O.f32_to_u16(img32)
+    conv = O.u16_to_f32(img16)
+    assert np.array_equal(conv, (img16.astype(np.float32) / np.float32(65535)))
+    assert np.array_equal(G.convert_rgb16(values_u16=img16), conv)                       # ssw_convert_rgb16_to_f32
+    assert np.array_equal(G.convert_rgb16(values_f32=img32 * 1.5 - 0.2), O.f32_to_u16(img32 * 1.5 - 0.2))   # clamp + round
+    mark = np.random.default_rng(6).standard_normal(k).astype(np.float32)
+    cfg_w, cfg_r = wm.WriteConfig(precision=precision), wm.ReadConfig(precision=precision)
+
+    w16, w32 = wm.Writer(img16, cfg_w, ctx), wm.Writer(conv, cfg_w, ctx)
+    coef = w16.coefficient_image()
+    assert np.array_equal(coef, w32.coefficient_image())
+    marked = w16.mark([mark])
+    assert np.array_equal(marked, w32.mark([mark]))
+    cfg = G.default_config(precision)
+    assert np.array_equal(G.batch_embed_rgb16(img16[None], mark[None], cfg)[0], marked)
+    assert np.array_equal(G.batch_embed(conv[None], mark[None], cfg)["rgb"][0], marked)
+    # the marked frame saved as a 16-bit image and read back: Reader::base / derived on u16 frames
+    marked16 = G.convert_rgb16(values_f32=marked)
+    assert np.array_equal(marked16, O.f32_to_u16(marked))
+    base, derived = wm.Reader.base(img16, cfg_r, ctx), wm.Reader.derived(marked16, ctx, precision)
+    assert np.array_equal(base.coefficients().reshape(h, w), coef)
+    ext = base.extract(derived, k)
+    sim = wm.Tester(ext, ctx).similarity(mark).similarity
+    e_b, s_b = G.batch_extract_rgb16(img16[None], marked16[None], k, mark[None], cfg)
+    assert np.array_equal(ext, e_b[0]) and np.float32(sim) == s_b[0]
+    e32 = wm.Reader.base(conv, cfg_r, ctx).extract(wm.Reader.derived(O.u16_to_f32(marked16), ctx, precision), k)
+    assert np.array_equal(ext, e32)
+    if precision == F64:
+        o_marked = O.embed_frame(conv, mark)
+        assert np.abs(marked - o_marked).max() <= 2e-7
+        o_marked16 = O.f32_to_u16(o_marked)
+        assert np.mean(marked16 == o_marked16) >= 0.999
+        if np.array_equal(marked16, o_marked16):
+            o_ext, o_sim = O.extract_frame(conv, O.u16_to_f32(o_marked16), mark)
+            assert np.abs(ext - o_ext).max() <= 1e-5 * max(1.0, float(np.abs(o_ext).max()))
+            assert abs(sim - o_sim) < 1e-4 * max(1.0, abs(o_sim))
+
+
 def test_rgb8_handles_4k_against_the_oracle():
     """configs[1]-sized frame through the 8-bit handles (25 MB each way: the staged path with its copy threads):
     `Writer::new(img).mark(&[&mark]).into_rgb8()` then `Reader::base / derived / extract` and `Tester::similarity`
