@@ -1,0 +1,37 @@
+"""A bounded, fixed-seed leg of the builder's fuzzers (tools/fuzz_dct.py, tools/fuzz_batch.py) inside `pytest -m gpu`, so
+that the driver's GPU test run covers every strategy branch of the transform (deep / semi-deep / first-level split /
+exact-operand folding / in-kernel folding / dense; rows or columns first; class-major tiles or natural planes; staged or
+r3 pre-passes by shape) and of the batch pipelines (pruned + two lanes against full + one lane) -- not only the
+hand-picked shapes of test_gpu_parity.py.  Reference: src/dct2d.rs:83-219 (the transform the oracle restates),
+src/algorithm.rs:295-316, :355-379, :529-593 (the batch flows).  Everything goes through the C ABI; the oracle checks."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import fuzz_batch  # noqa: E402
+import fuzz_dct  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+# 20 random shapes + two that pin layouts the draw missed: class-major in ONE tile (W % 64 == 0, not % 128: the r3 column
+# pre-passes) and a semi-deep column pass behind a deep row pass
+DCT_CASES = fuzz_dct.shapes(20, 20261002) + [(272, 320, 2, 77), (1048, 2048, 1, 78)]
+BATCH_CASES = fuzz_batch.shapes(6, 20261002)
+
+
+@pytest.mark.parametrize("kind", ["fwd", "ortho", "inv"])
+@pytest.mark.parametrize("case", DCT_CASES, ids=[f"{h}x{w}x{n}" for (h, w, n, _) in DCT_CASES])
+def test_random_shapes_through_ssw_dct2d_match_the_oracle(case, kind):
+    h, w, n, data_seed = case
+    same, err = fuzz_dct.check(h, w, n, data_seed, kind)
+    assert same >= fuzz_dct.BAR_IDENTICAL and err <= fuzz_dct.BAR_ERR, (h, w, n, kind, same, err)
+
+
+@pytest.mark.parametrize("case", BATCH_CASES, ids=[f"{c[0]}x{c[1]}x{c[2]}k{c[3]}" for c in BATCH_CASES])
+def test_random_shapes_through_the_batch_pipelines(case):
+    r = fuzz_batch.check(*case)
+    assert r["same"], "pruned + two lanes differs from full transforms + one lane"
+    assert fuzz_batch.passes(r), r
