@@ -424,6 +424,39 @@ def handle_api_leg(wm, L, lib, ctx, check, rgb0_dev, W, H, K, precision, reps=5)
     if len(times) == n_thr:
         out["rgb8_pinned_two_threads"] = {"threads": n_thr, "embed_extract_mpix_s": round(px * reps * n_thr / max(times), 1),
                                           "note": "one context per host thread, same GPU; aggregate over both threads"}
+    # the same caller with a QUEUE of images: the streaming entry points (ssw_batch_embed_host_rgb8 / _extract_host_rgb8,
+    # csrc/ssw_stream.hip) -- n host images in one call, groups of >= 8 frames share the GEMM launches, uploads / kernels /
+    # downloads of consecutive groups overlap.  Pinned and pageable frames; PCIe included; bit-identical to the handles.
+    n_stream = 64
+    smarks = np.random.default_rng(777).standard_normal((n_stream, K)).astype(np.float32)
+    smarks[0] = mark
+
+    def stream(frames, outs):
+        n_s, mk = len(frames), smarks[:len(frames)]
+        wm.mark_many(frames[:8], smarks[:8], wcfg, ctx, out=outs[:8])                    # warm-up (buffers, bases)
+        wm.extract_many(frames[:8], outs[:8], K, smarks[:8], rcfg, ctx)
+        ctx.transfer_stats(reset=True)
+        t0 = time.perf_counter()
+        wm.mark_many(frames, mk, wcfg, ctx, out=outs)
+        t1 = time.perf_counter()
+        ext, sims = wm.extract_many(frames, outs, K, mk, rcfg, ctx)
+        t2 = time.perf_counter()
+        st = ctx.transfer_stats()
+        return {"frames": n_s, "embed_ms_per_frame": round((t1 - t0) / n_s * 1e3, 3), "extract_ms_per_frame": round((t2 - t1) / n_s * 1e3, 3),
+                "embed_mpix_s": round(px * n_s / (t1 - t0), 1), "extract_mpix_s": round(px * n_s / (t2 - t1), 1),
+                "embed_extract_mpix_s": round(px * n_s / (t2 - t0), 1),
+                "pcie_bytes_per_frame": int((st["h2d_bytes"] + st["d2h_bytes"]) / n_s),
+                "staged_fraction": round(st["staged_bytes"] / max(st["h2d_bytes"] + st["d2h_bytes"], 1.0), 3),
+                "sim_mean": round(float(sims.mean()), 4)}, ext
+    s_in = [ctx.pinned_empty(img8.shape, np.uint8) for _ in range(n_stream)]
+    s_out = [ctx.pinned_empty(img8.shape, np.uint8) for _ in range(n_stream)]
+    for i, b in enumerate(s_in):
+        b[...] = np.roll(img8, 16 * i, axis=1)            # distinct frames, same statistics
+    out["rgb8_pinned_stream"], s_ext = stream(s_in, s_out)
+    out["rgb8_pinned_stream"]["frame0_bit_identical_to_handles"] = bool(np.array_equal(s_out[0], marked8p) and np.array_equal(s_ext[0], ext8p))
+    pg_in = [np.array(b) for b in s_in[:16]]
+    out["rgb8_pageable_stream"], _ = stream(pg_in, [np.empty_like(img8) for _ in range(16)])
+    del s_in, s_out, pg_in
     # the handles against the batch entry points on the same bytes (n = 1): bit for bit
     cfg = L.Config(L.ORDER_ENERGY, L.OPTION2, 0.1, prec)
     marks_dev = torch.from_numpy(mark[None]).to(rgb0_dev.device)

@@ -346,6 +346,21 @@ int ssw_batch_extract_rgb16(ssw_ctx* ctx, const ssw_config* cfg, const uint16_t*
                             const uint16_t* dev_derived_rgb, size_t n_frames, size_t w, size_t h, size_t k,
                             float* dev_extracted, const float* dev_marks, float* dev_sims);
 
+/* ---- host-image streaming (n frames that live on the host, one call) ------------- */
+/* The loops of the reference's callers -- examples/main.rs:271-278 (`watermark`: per image Writer::new -> mark ->
+   into_rgb8) and :383-415 (`test`: per image Reader::base / derived -> extract -> Tester::similarity) -- as ONE call over
+   n 8-bit host images [h][w][3] (frames[i]: one pointer per image; pinned buffers -- ssw_host_alloc, hipHostRegister --
+   are the DMA source / target themselves, any other buffer goes through the context's staging ring): the images go
+   through ssw_batch_embed_rgb8 / ssw_batch_extract_rgb8 in groups of >= 8 frames, the upload of group g + 1, the
+   kernels of group g and the download of group g - 1 in flight together (csrc/ssw_stream.hip).  Bit-identical to the
+   single-image handles.  Host-buffer entry points: they return when every buffer is the caller's again.
+   host_marks: [n][k] f32 (mark i for frame i); extract: host_marks and host_sims both or neither (NULL). */
+int ssw_batch_embed_host_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* const* host_frames, size_t n_frames,
+                              size_t w, size_t h, const float* host_marks, size_t k, uint8_t* const* host_out);
+int ssw_batch_extract_host_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* const* host_base,
+                                const uint8_t* const* host_derived, size_t n_frames, size_t w, size_t h, size_t k,
+                                float* host_extracted, const float* host_marks, float* host_sims);
+
 /* ---- single-image handles mirroring the crate's types (host buffers) ------- */
 /* Writer::new(image, config), src/algorithm.rs:295-316.  rgb_hwc: host [h][w][3]
    f32 (what `into_rgb32f()` yields, :308).  The ordering is computed lazily at

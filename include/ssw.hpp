@@ -315,4 +315,50 @@ private:
     const std::vector<float>& e_;
 };
 
+// The callers' loops over host images (examples/main.rs:271-278, :383-415) as one streaming call each: uploads,
+// kernels and downloads of consecutive groups of images overlap (ssw_batch_embed_host_rgb8 / ssw_batch_extract_host_rgb8).
+// marks[i] is embedded into images[i]; all marks have one length.  Bit-identical to a loop over Writer / Reader.
+inline std::vector<ImageRgb8> mark_many(Context& ctx, const std::vector<const ImageRgb8*>& images, const std::vector<const MarkBuf*>& marks,
+                                        const WriteConfig& config = WriteConfig()) {
+    if (images.empty() || images.size() != marks.size()) throw Error(SSW_ERR_BAD_ARG, "mark_many");
+    const size_t w = images[0]->width, h = images[0]->height, k = marks[0]->data().size();
+    std::vector<const uint8_t*> in(images.size());
+    std::vector<float> m(images.size() * k);
+    std::vector<ImageRgb8> out(images.size(), ImageRgb8(w, h));
+    std::vector<uint8_t*> op(images.size());
+    for (size_t i = 0; i < images.size(); ++i) {
+        if (images[i]->width != w || images[i]->height != h || images[i]->data.size() != w * h * 3 || marks[i]->data().size() != k)
+            throw Error(SSW_ERR_BAD_DIMS, "mark_many");
+        in[i] = images[i]->data.data();
+        std::copy(marks[i]->data().begin(), marks[i]->data().end(), m.begin() + i * k);
+        op[i] = out[i].data.data();
+    }
+    ssw_config c = config.c();
+    check(ssw_batch_embed_host_rgb8(ctx.get(), &c, in.data(), in.size(), w, h, m.data(), k, op.data()), "mark_many");
+    return out;
+}
+struct ExtractedMany { std::vector<std::vector<float>> extracted; std::vector<float> similarity; };
+inline ExtractedMany extract_many(Context& ctx, const std::vector<const ImageRgb8*>& base, const std::vector<const ImageRgb8*>& derived,
+                                  size_t k, const std::vector<const MarkBuf*>& marks, const ReadConfig& config = ReadConfig()) {
+    if (base.empty() || base.size() != derived.size() || (!marks.empty() && marks.size() != base.size())) throw Error(SSW_ERR_BAD_ARG, "extract_many");
+    const size_t n = base.size(), w = base[0]->width, h = base[0]->height;
+    std::vector<const uint8_t*> bp(n), dp(n);
+    std::vector<float> m(marks.empty() ? 0 : n * k), ext(n * k), sims(marks.empty() ? 0 : n);
+    for (size_t i = 0; i < n; ++i) {
+        if (base[i]->width != w || base[i]->height != h || derived[i]->width != w || derived[i]->height != h) throw Error(SSW_ERR_BAD_DIMS, "extract_many");
+        bp[i] = base[i]->data.data(); dp[i] = derived[i]->data.data();
+        if (!marks.empty()) {
+            if (marks[i]->data().size() != k) throw Error(SSW_ERR_LENGTH_MISMATCH, "extract_many");
+            std::copy(marks[i]->data().begin(), marks[i]->data().end(), m.begin() + i * k);
+        }
+    }
+    ssw_config c = config.c();
+    check(ssw_batch_extract_host_rgb8(ctx.get(), &c, bp.data(), dp.data(), n, w, h, k, ext.data(), marks.empty() ? nullptr : m.data(),
+                                      marks.empty() ? nullptr : sims.data()), "extract_many");
+    ExtractedMany r;
+    for (size_t i = 0; i < n; ++i) r.extracted.emplace_back(ext.begin() + i * k, ext.begin() + (i + 1) * k);
+    r.similarity = sims;
+    return r;
+}
+
 }  // namespace wm

@@ -85,6 +85,8 @@ SIGNATURES = {
     "ssw_convert_f32_to_rgb8": (C.c_int, [_vp, _f32p, _sz, _vp]),
     "ssw_resize_rgb8": (C.c_int, [_vp, _vp, _sz, _sz, _sz, _sz, _sz, _vp]),
     "ssw_batch_embed_rgb8": (C.c_int, [_vp, _cfgp, _vp, _sz, _sz, _sz, _f32p, _sz, _vp]),
+    "ssw_batch_embed_host_rgb8": (C.c_int, [_vp, _cfgp, C.POINTER(_vp), _sz, _sz, _sz, _f32p, _sz, C.POINTER(_vp)]),
+    "ssw_batch_extract_host_rgb8": (C.c_int, [_vp, _cfgp, C.POINTER(_vp), C.POINTER(_vp), _sz, _sz, _sz, _sz, _f32p, _f32p, _f32p]),
     "ssw_convert_rgb16_to_f32": (C.c_int, [_vp, _vp, _sz, _f32p]),
     "ssw_convert_f32_to_rgb16": (C.c_int, [_vp, _f32p, _sz, _vp]),
     "ssw_batch_embed_rgb16": (C.c_int, [_vp, _cfgp, _vp, _sz, _sz, _sz, _f32p, _sz, _f32p]),

@@ -462,6 +462,67 @@ class ReaderDerived:
         return self._reader.coefficients()
 
 
+# ---- the callers' loops over host images as one streaming call (examples/main.rs:271-278, :383-415) ----------------
+def _frame_ptrs(images, w=None, h=None):
+    """n 8-bit [H, W, 3] host images (a list, or one [n, H, W, 3] array) -> (kept-alive arrays, void* array, w, h)."""
+    arrs = [np.ascontiguousarray(np.asarray(im)[:, :, :3]) for im in images]
+    if not arrs:
+        raise ValueError("no images")
+    for a in arrs:
+        if a.dtype != np.uint8 or a.ndim != 3 or a.shape != arrs[0].shape:
+            raise ValueError("images must be 8-bit [H, W, 3] arrays of one size")
+    hh, ww = arrs[0].shape[:2]
+    if (w, h) != (None, None) and (ww, hh) != (w, h):
+        raise ValueError("image sizes differ")
+    return arrs, (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs]), ww, hh
+
+
+def mark_many(images, marks, config: Optional[WriteConfig] = None, ctx: Optional[Context] = None, out=None):
+    """`for (image, mark) in ..: Writer::new(image, config).mark(&[&mark]).into_rgb8()` (examples/main.rs:271-278) as ONE
+    streaming call over n 8-bit host images: ssw_batch_embed_host_rgb8.  marks: [n][k].  Returns / fills `out`, a list
+    of n u8 [H, W, 3] arrays (pinned arrays from Context.pinned_empty are the DMA source / target themselves)."""
+    ctx = ctx or default_context()
+    config = config or WriteConfig.default()
+    arrs, ptrs, w, h = _frame_ptrs(images)
+    m = np.ascontiguousarray(np.stack([_mark_data(x) for x in marks]), dtype=np.float32)
+    if m.ndim != 2 or m.shape[0] != len(arrs):
+        raise ValueError("one mark of equal length per image")
+    if out is None:
+        out = [np.empty((h, w, 3), np.uint8) for _ in arrs]
+    for o in out:
+        if o.dtype != np.uint8 or o.shape != (h, w, 3) or not o.flags.c_contiguous:
+            raise ValueError("out: contiguous u8 [H, W, 3] arrays")
+    optrs = (C.c_void_p * len(out))(*[o.ctypes.data for o in out])
+    cfg = config._c()
+    check(ctx._lib.ssw_batch_embed_host_rgb8(ctx.handle, C.byref(cfg), ptrs, len(arrs), w, h, m.ctypes.data, m.shape[1], optrs),
+          "ssw_batch_embed_host_rgb8")
+    return out
+
+
+def extract_many(base_images, derived_images, k: int, marks=None, config: Optional[ReadConfig] = None, ctx: Optional[Context] = None):
+    """`Reader::base(b, config).extract(&Reader::derived(d), ..)` (+ `Tester::similarity` against marks[i]) per image pair
+    (examples/main.rs:383-415) as ONE streaming call: ssw_batch_extract_host_rgb8.  Returns (extracted [n][k], sims [n] or None)."""
+    ctx = ctx or default_context()
+    config = config or ReadConfig.default()
+    ba, bp, w, h = _frame_ptrs(base_images)
+    da, dp, _, _ = _frame_ptrs(derived_images, w, h)
+    if len(ba) != len(da):
+        raise ValueError("one derived image per base image")
+    n = len(ba)
+    ext = np.empty((n, k), np.float32)
+    m = sims = None
+    if marks is not None:
+        m = np.ascontiguousarray(np.stack([_mark_data(x) for x in marks]), dtype=np.float32)
+        if m.shape != (n, k):
+            raise ValueError("marks must be [n][k]")
+        sims = np.empty(n, np.float32)
+    cfg = config._c()
+    check(ctx._lib.ssw_batch_extract_host_rgb8(ctx.handle, C.byref(cfg), bp, dp, n, w, h, k, ext.ctypes.data,
+                                               m.ctypes.data if m is not None else None, sims.ctypes.data if sims is not None else None),
+          "ssw_batch_extract_host_rgb8")
+    return ext, sims
+
+
 # ---- Tester (algorithm.rs:668-715) -------------------------------------------------------------
 @dataclass
 class Similarity:

@@ -50,6 +50,11 @@ void release_select(SelectWorkspace& s);
 // (the data reaches the device in stream order), download() once the caller's buffer is complete.
 int upload(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes, hipStream_t st);
 int download(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hipStream_t st);
+// The same for callers that keep every host buffer until they synchronise `st` themselves (the streaming entry
+// points): a pinned buffer is only ENQUEUED (no wait); any other buffer takes the staged path above (upload: returns
+// when staged; download: returns when complete).  *async_out: whether the transfer is still in flight on return.
+int upload_nowait(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes, hipStream_t st, bool* async_out);
+int download_nowait(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hipStream_t st, bool* async_out);
 void transfer_destroy(ssw_ctx* ctx);
 int transfer_set_threads(ssw_ctx* ctx, int threads);
 int transfer_stats(ssw_ctx* ctx, double* out, bool reset);

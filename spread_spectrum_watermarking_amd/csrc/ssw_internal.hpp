@@ -317,6 +317,16 @@ struct ssw_ctx {
     std::multimap<size_t, void*> plane_pool;
     size_t plane_pool_bytes = 0;
     ssw::host::Transfer* xfer = nullptr;  // pinned staging ring + copy threads (transfer.hip)
+    // host-image streaming entry points (ssw_stream.hip): groups of frames cross PCIe on `copy_stream` (up) and
+    // `down_stream` into / out of two alternating device buffers while the group between them is being computed
+    hipStream_t down_stream = nullptr;
+    struct HostStream {
+        static constexpr int NB = 3;      // ring depth
+        Buf in[NB], in2[NB], out[NB];     // frames of a group: input (base), second input (derived), output
+        Buf marks, ext, sims;             // the whole call's marks / extracted marks / similarities
+        hipEvent_t up_done[NB] = {}, k_done[NB] = {}, down_done[NB] = {};
+    };
+    HostStream hs;
     Buf small;                    // misc (mark offsets, sims, ...)
     Buf sort_scratch;             // full-order sort (lazy, Reader::indices beyond the top-k limit)
     Buf resize_tmp;               // f32 intermediate of the resize's vertical pass

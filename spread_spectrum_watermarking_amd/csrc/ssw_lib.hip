@@ -235,7 +235,13 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_stream) (void)hipStreamSynchronize(ctx->aux_stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    if (ctx->down_stream) (void)hipStreamSynchronize(ctx->down_stream);
     transfer_destroy(ctx);
+    for (int s = 0; s < ssw_ctx::HostStream::NB; ++s) {
+        release(ctx->hs.in[s]); release(ctx->hs.in2[s]); release(ctx->hs.out[s]);
+        for (hipEvent_t e : {ctx->hs.up_done[s], ctx->hs.k_done[s], ctx->hs.down_done[s]}) if (e) (void)hipEventDestroy(e);
+    }
+    release(ctx->hs.marks); release(ctx->hs.ext); release(ctx->hs.sims);
     for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);
     for (auto& fs : ctx->frame_stage) {
         release(fs.buf);
@@ -263,6 +269,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     for (auto& e : ctx->free_events) (void)hipEventDestroy(e);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    if (ctx->down_stream) (void)hipStreamDestroy(ctx->down_stream);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SSW_OK;

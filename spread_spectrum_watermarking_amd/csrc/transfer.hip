@@ -255,6 +255,32 @@ int upload(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes, hipS
     return SSW_OK;
 }
 
+int upload_nowait(ssw_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes, hipStream_t st, bool* async_out) {
+    *async_out = false;
+    if (bytes == 0) return SSW_OK;
+    if (!is_pinned(host_src)) return upload(ctx, dev_dst, host_src, bytes, st);
+    Transfer* t = nullptr;
+    SSW_TRY(get_transfer(ctx, &t));
+    t->stats[SSW_TRANSFER_H2D_BYTES] += (double)bytes;
+    t->stats[SSW_TRANSFER_DIRECT_BYTES] += (double)bytes;
+    SSW_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, st));
+    *async_out = true;
+    return SSW_OK;
+}
+
+int download_nowait(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hipStream_t st, bool* async_out) {
+    *async_out = false;
+    if (bytes == 0) return SSW_OK;
+    if (!is_pinned(host_dst)) return download(ctx, host_dst, dev_src, bytes, st);
+    Transfer* t = nullptr;
+    SSW_TRY(get_transfer(ctx, &t));
+    t->stats[SSW_TRANSFER_D2H_BYTES] += (double)bytes;
+    t->stats[SSW_TRANSFER_DIRECT_BYTES] += (double)bytes;
+    SSW_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, st));
+    *async_out = true;
+    return SSW_OK;
+}
+
 // device -> host on `st`.  Returns when `host_dst` holds the data.
 int download(ssw_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes, hipStream_t st) {
     if (bytes == 0) return SSW_OK;
