@@ -246,6 +246,78 @@ struct PlaneSource {                    // item i = coefficient i + 1 (DC skippe
     __device__ uint64_t operator()(size_t i) const { return composite_key(kp, (uint32_t)(i + 1), c[i + 1]); }
 };
 
+// Stable LSD radix sort, descending, of lbuf[0 .. rows * blockDim.x) in place: 8 passes of 8 bits.  (r4: the finish of
+// marks longer than 1024 entries.  The bitonic network it replaces moves every key through LDS ~105 times -- 16384
+// 64-bit keys: 55 MB of LDS traffic, 176 us on one CU, LDS-bandwidth bound; a counting pass reads and writes each key
+// once: 8 x 0.26 MB.)  Wave w owns the keys [w rows 64, (w + 1) rows 64), lane l of row r the key (w rows + r) 64 + l, all
+// of a thread's keys in registers between the load and the scatter of a pass, so one buffer suffices.  Per row the lanes
+// of equal digit find each other with eight ballots; the lowest of them adds their number to the wave's counter of that
+// digit (lcount[wave][digit], 16-bit: <= 1024 keys per wave), the others take their place behind the running count.
+// blockDim.x == 1024 (16 waves), rows <= 16.
+__device__ void block_radix_sort_desc(uint64_t* lbuf, unsigned rows, uint16_t* lcount, uint32_t* lscan, int first_pass) {
+    constexpr int MAXR = 16, NW = FINISH_THREADS / 64;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint64_t* mine = lbuf + (size_t)w * rows * 64 + lane;         // + 64 r
+    uint16_t* mycount = lcount + w * 256;
+#pragma unroll 1
+    for (int pass = first_pass; pass < 8; ++pass) {
+        const int shift = 8 * pass;
+        unsigned loc[MAXR];                                             // digit << 16 | place behind the wave's running count
+        for (unsigned i = tid; i < NW * 256; i += FINISH_THREADS) lcount[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if ((unsigned)r >= rows) continue;                          // block-uniform
+            const unsigned d = 255u - (unsigned)((mine[64 * r] >> shift) & 255ull);
+            unsigned long long mask = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const unsigned long long bal = __ballot((d >> b) & 1u);
+                mask &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            const unsigned rank = (unsigned)__popcll(mask & below);
+            const unsigned base = mycount[d];                           // read by every lane of the group, then the leader adds
+            if (rank == 0) mycount[d] = (uint16_t)(base + (unsigned)__popcll(mask));
+            loc[r] = (d << 16) | (base + rank);
+        }
+        __syncthreads();
+        // per digit: exclusive offsets of the waves, the digit's total
+        if (tid < 256) {
+            unsigned sum = 0;
+            for (int w2 = 0; w2 < NW; ++w2) { const unsigned c = lcount[w2 * 256 + tid]; lcount[w2 * 256 + tid] = (uint16_t)sum; sum += c; }
+            lscan[tid] = sum;
+        }
+        __syncthreads();
+        // exclusive scan of the 256 totals: one wave, four digits per lane
+        if (tid < 64) {
+            unsigned s4[4], run = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s4[e] = lscan[4 * tid + e]; run += s4[e]; }
+            unsigned incl = run;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o, 64); if ((int)lane >= o) incl += up; }
+            unsigned ex = incl - run;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lscan[4 * tid + e] = ex; ex += s4[e]; }
+        }
+        __syncthreads();
+        uint64_t key[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if ((unsigned)r >= rows) continue;
+            const unsigned d = loc[r] >> 16;
+            loc[r] = (loc[r] & 0xFFFFu) + lscan[d] + mycount[d];
+            key[r] = mine[64 * r];
+        }
+        __syncthreads();                                               // every key of the pass is in a register
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r)
+            if ((unsigned)r < rows) lbuf[loc[r]] = key[r];
+        __syncthreads();
+    }
+}
+
 template <class Src>
 __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n_pow2, uint32_t* lhist,
                                   uint32_t* lpart, uint64_t* lbuf, uint64_t* lstate,
@@ -253,6 +325,23 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
     // lstate: [0] prefix, [1] bits decided, [2] need, [3] resolved, [4] gather counter, [5..6] scan scratch
     const unsigned tid = threadIdx.x;
     if (tid == 0) { lstate[0] = 0; lstate[1] = 0; lstate[2] = k; lstate[3] = (n == k) ? 1 : 0; lstate[4] = 0; }
+    // r4: the walks over the items (select rounds, gather) keep UN loads per thread in flight -- a loop of one dependent
+    // load per iteration took ~30 us per walk over the 30000 candidates of a k = 10000 mark (1 us per trip to L2 / HBM).
+    // f(valid, key) is called for whole waves (the gather ballots).
+    constexpr int UN = 8;
+    auto walk = [&](auto&& f) {
+        const size_t step = (size_t)UN * blockDim.x;
+        for (size_t i0 = 0; i0 < n; i0 += step) {
+            uint64_t v[UN];
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const size_t i = i0 + tid + (size_t)j * blockDim.x;
+                v[j] = i < n ? src(i) : 0ull;
+            }
+#pragma unroll
+            for (int j = 0; j < UN; ++j) f(i0 + tid + (size_t)j * blockDim.x < n, v[j]);
+        }
+    };
     __syncthreads();
     while (!lstate[3]) {
         const uint64_t prefix = lstate[0];
@@ -263,11 +352,26 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
         const uint32_t mask = (1u << width) - 1u;
         for (unsigned i = tid; i < NBINS; i += blockDim.x) lhist[i] = 0;
         __syncthreads();
-        for (size_t i = tid; i < n; i += blockDim.x) {
-            const uint64_t comp = src(i);
-            if (bits_done == 0 || (comp >> (64 - bits_done)) == prefix)
-                atomicAdd(&lhist[(uint32_t)(comp >> shift) & mask], 1u);
-        }
+        // The first round sees every candidate in two or three bins (the top bits of keys above one threshold): lanes of
+        // equal bin are counted with one atomic -- up to three distinct bins per wave step, the rest one by one -- instead of
+        // 64 updates of one LDS word in a row
+        walk([&](bool valid, uint64_t comp) {
+            bool mine = valid && (bits_done == 0 || (comp >> (64 - bits_done)) == prefix);
+            const uint32_t bin = (uint32_t)(comp >> shift) & mask;
+            const unsigned lane = tid & 63u;
+#pragma unroll
+            for (int it = 0; it < 3; ++it) {
+                if (bits_done != 0) break;                              // later rounds spread over the bins: plain updates
+                const unsigned long long todo = __ballot(mine);
+                if (todo == 0) break;
+                const int leader = __builtin_ctzll(todo);
+                const uint32_t b = (uint32_t)__shfl((int)bin, leader, 64);
+                const unsigned long long same = __ballot(mine && bin == b);
+                if ((int)lane == leader) atomicAdd(&lhist[b], (uint32_t)__popcll(same));
+                if (bin == b) mine = false;
+            }
+            if (mine) atomicAdd(&lhist[bin], 1u);
+        });
         __syncthreads();
         // digit holding the need-th largest key: 256 threads own 8 digits each (counted from the
         // top), thread 0 scans the 256 partial sums, the owner resolves inside its 8 digits
@@ -311,14 +415,20 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
     {
         const uint64_t prefix = lstate[0];
         const int bits_done = (int)lstate[1];
-        for (size_t i = tid; i < n; i += blockDim.x) {
-            const uint64_t comp = src(i);
+        // one counter update per wave and step (the survivors of a wave take consecutive places), not one per survivor
+        auto take = [&](bool in_range, uint64_t comp) {
             const uint64_t top = (bits_done == 0) ? 1 : (bits_done >= 64 ? comp : (comp >> (64 - bits_done)));
-            if (bits_done == 0 || top >= prefix) {
-                const unsigned pos = (unsigned)atomicAdd((unsigned long long*)&lstate[4], 1ull);
-                if (pos < n_pow2) lbuf[pos] = comp;
-            }
-        }
+            const bool keep = in_range && (bits_done == 0 || top >= prefix);
+            const unsigned long long m = __ballot(keep);
+            if (m == 0) return;
+            const unsigned lane = tid & 63u;
+            unsigned base = 0;
+            if (lane == (unsigned)__builtin_ctzll(m)) base = (unsigned)atomicAdd((unsigned long long*)&lstate[4], (unsigned long long)__popcll(m));
+            base = __shfl(base, __builtin_ctzll(m), 64);
+            const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (keep && pos < n_pow2) lbuf[pos] = comp;
+        };
+        walk(take);
         __syncthreads();
         const unsigned gathered = (unsigned)lstate[4];            // k <= gathered <= n_pow2
         for (unsigned i = tid; i < n_pow2; i += blockDim.x)
@@ -354,9 +464,16 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
         if (tid < k) indices[tid] = ~(uint32_t)(v & 0xFFFFFFFFull);
         return;
     }
-    // more keys than threads: compare-exchanges through LDS.  (A variant with 1024 * R keys in registers -- own keys
-    // in registers, wave partners by shuffle, LDS only from stride 64 R up -- measured SLOWER: 220 vs 176 us for the
-    // k = 10000 finish of an 8K frame; one CU sorting 16384 64-bit keys is bound by its VALU / LDS-crossbar issue.)
+    // more keys than threads: a counting sort of the gathered keys (zero padded to whole rows of the block), the
+    // histogram / partial-sum areas of the select rounds serving as its counters.  (r3: compare-exchanges through LDS,
+    // 176 us for the k = 10000 finish of an 8K frame, kept below for blocks of another size.)
+    if (blockDim.x == FINISH_THREADS && n_pow2 <= 16 * FINISH_THREADS) {
+        const unsigned gathered = (unsigned)lstate[4] < n_pow2 ? (unsigned)lstate[4] : n_pow2;
+        const unsigned rows = (gathered + FINISH_THREADS - 1) / FINISH_THREADS;
+        block_radix_sort_desc(lbuf, rows, reinterpret_cast<uint16_t*>(lhist), lpart, 0);
+        for (unsigned i = tid; i < k; i += blockDim.x) indices[i] = ~(uint32_t)(lbuf[i] & 0xFFFFFFFFull);
+        return;
+    }
     for (unsigned size = 2; size <= n_pow2; size <<= 1) {
         for (unsigned stride = size >> 1; stride > 0; stride >>= 1) {
             for (unsigned i = tid; i < n_pow2 / 2; i += blockDim.x) {

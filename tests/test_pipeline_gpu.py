@@ -453,6 +453,8 @@ def test_bench_line_carries_every_leg():
                 "--no-alt", "--no-serial-leg", "--no-timers-off-leg"])
     h = j["handle_api"]
     assert h["bit_identical_to_batch_rgb8"] is True
+    assert h["rgb8_pinned_stream"]["frame0_bit_identical_to_handles"] is True and h["rgb8_pinned_stream"]["staged_fraction"] == 0.0
+    assert h["rgb8_pageable_stream"]["embed_extract_mpix_s"] > 0
     for leg in ("rgb8_pageable", "rgb8_pinned", "f32_pageable"):
         assert h[leg]["embed_extract_mpix_s"] > 0 and h[leg]["pcie_bytes_per_frame"] > 0
     assert h["rgb8_pinned"]["staged_fraction"] == 0.0 and h["rgb8_pageable"]["pcie_bytes_per_frame"] * 3 < h["f32_pageable"]["pcie_bytes_per_frame"]
@@ -462,6 +464,10 @@ def test_bench_line_carries_every_leg():
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["value"] > 0
     assert j["parity"]["frames"][0]["sim_delta_vs_cpu_exact"] < 1e-4
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] <= 1.0
+    # the two blocks describe the step: the GEMM kernel family and the pre-pass family (verdict r3 #2)
+    assert j["roofline"]["name_match"].startswith("ssw::pair_gemm_") and 0 < j["roofline"]["share_of_step"] <= 1.0
+    assert j["roofline_hbm"]["bound"] == "hbm" and j["roofline_hbm"]["name_match"] == "prep16" and 0 < j["roofline_hbm"]["frac"] <= 1.0
+    assert 0 < j["roofline"]["best_launch"]["frac"] <= 1.0
 
 
 def test_bench_attack_line_checks_itself_against_the_oracle():
@@ -474,7 +480,9 @@ def test_bench_attack_line_checks_itself_against_the_oracle():
     assert p["resize_down_bit_exact"] is True and p["resize_up_bit_exact"] is True
     assert p["marked_rgb8_identical_fraction_vs_cpu_exact"] >= 0.9999
     assert p["extracted_max_abs_diff_vs_cpu_exact"] <= 1e-5 * 10 and p["sim_delta_vs_cpu_exact"] < 1e-4 * max(1.0, abs(p["sim_cpu_exact"]))
-    assert j["roofline"]["flop_per_launch"] > 0 and j["config"]["chunk_frames"] == 3
+    assert j["roofline"]["best_launch"]["flop_per_launch"] > 0 and j["roofline"]["executed_flop_per_step"] > 0
+    assert j["roofline_hbm"]["bound"] == "hbm" and 0 < j["roofline_hbm"]["frac"] <= 1.0
+    assert j["config"]["chunk_frames"] == 3
 
 
 def test_bench_under_torchrun_two_ranks(tmp_path):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times ssw_topk_indices (sample + threshold + compaction + finish) for several mark lengths on coefficient planes
-of synthetic frames.  usage: python tools/select_bench.py [W H FRAMES]"""
+of synthetic frames.  usage: python tools/select_bench.py [W H FRAMES [K ...]]"""
 import os
 import sys
 
@@ -12,6 +12,7 @@ from spread_spectrum_watermarking_amd import _lib as L
 from spread_spectrum_watermarking_amd.api import check
 
 W, H, N = (int(a) for a in (sys.argv[1:4] + ["7680", "4320", "8"][len(sys.argv) - 1:]))
+KS = [int(a) for a in sys.argv[4:]] or [500, 1000, 1024, 1025, 2000, 4000, 8000, 10000, 16384]
 ctx = wm.Context(0)
 lib = ctx._lib
 rgb = ctx.alloc(N * H * W * 12)
@@ -21,7 +22,7 @@ check(lib.ssw_rgb_to_yiq(ctx.handle, rgb.ptr, N, W, H, y.ptr, None, None), "yiq"
 rgb.free()
 check(lib.ssw_dct2d(ctx.handle, L.DCT2, L.PRECISION_F64, N, W, H, y.ptr), "dct")
 idx = ctx.alloc(N * 16384 * 4)
-for k in (500, 1000, 1024, 1025, 2000, 4000, 8000, 10000, 16384):
+for k in KS:
     check(lib.ssw_topk_indices(ctx.handle, y.ptr, N, W, H, L.ORDER_ENERGY, k, idx.ptr), "topk")
     ctx.enable_timing(True); ctx.reset_timing()
     for _ in range(5):
