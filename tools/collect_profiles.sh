@@ -3,9 +3,9 @@
 #   bench JSON lines of the four BASELINE configs, rocprofv3 kernel-trace stats of the same commands, and the
 #   PMC passes (HBM traffic, VALU / LDS activity) of a short 4K run -- separate --pmc passes, never combined with
 #   trace domains other than the kernel trace (MI355X_MICROARCH.md, rocprofv3 section).
-# usage: bash tools/collect_profiles.sh r3
+# usage (in the container, so that the commit is recorded): git rev-parse --short HEAD > .commit_stamp; gpurun -- bash tools/collect_profiles.sh r4
 set -u
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
@@ -52,13 +52,13 @@ pmc fetch FETCH_SIZE -- $PM
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $PM
 pmc valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $PM
 pmc mfma SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- $PM
-python3 "$R/tools/pmc_traffic_json.py" "$OUT" "$TAG" 3840 2160 128 "$COMMIT" > "$OUT/${TAG}_pmc_traffic.json"
+python3 "$R/tools/pmc_traffic_json.py" "$OUT" "$TAG" 3840 2160 128 "$COMMIT" 2 > "$OUT/${TAG}_pmc_traffic.json"
 # the same two traffic passes on one 32-frame pass of configs[4] (8K, 8-bit): roofline.traffic of `--config 4`
 PA="--config 4 --batch 32 --steps 1 --warmup 1 --no-overlap $SHORT"
 mv "$OUT/${TAG}_pmc_fetch.txt" "$OUT/${TAG}_pmc_fetch_4k.txt"; mv "$OUT/${TAG}_pmc_write.txt" "$OUT/${TAG}_pmc_write_4k.txt"
 pmc fetch FETCH_SIZE -- $PA
 pmc write WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $PA
-python3 "$R/tools/pmc_traffic_json.py" "$OUT" "$TAG" 7680 4320 32 "$COMMIT" > "$OUT/${TAG}_pmc_traffic_8k.json"
+python3 "$R/tools/pmc_traffic_json.py" "$OUT" "$TAG" 7680 4320 32 "$COMMIT" 2 > "$OUT/${TAG}_pmc_traffic_8k.json"
 mv "$OUT/${TAG}_pmc_fetch.txt" "$OUT/${TAG}_pmc_fetch_8k.txt"; mv "$OUT/${TAG}_pmc_write.txt" "$OUT/${TAG}_pmc_write_8k.txt"
 mv "$OUT/${TAG}_pmc_fetch_4k.txt" "$OUT/${TAG}_pmc_fetch.txt"; mv "$OUT/${TAG}_pmc_write_4k.txt" "$OUT/${TAG}_pmc_write.txt"
 python3 "$R/tools/handle_bench.py" > "$OUT/${TAG}_handle_api.txt" 2>&1
