@@ -158,6 +158,11 @@ int ssw_ctx_set_prune(ssw_ctx* ctx, int enable);
 /* stats[0] chunks that took the pruned path, [1] of those redone with the full transform, [2] frequency
    columns actually needed (sum over chunks); since the last ssw_ctx_reset_timing. */
 int ssw_ctx_get_prune_stats(ssw_ctx* ctx, uint64_t* stats);
+/* Top-k selection (the first k entries of the ordering of src/algorithm.rs:200-280): stats[0] frames selected, [1] of
+   those whose sampled threshold left fewer than k or more than the candidate buffer's survivors, so that the finish ran
+   the exact select over the whole plane (same result, one CU sorting the plane: a latency cliff; massive ties and
+   constant planes take it by design, images should not); since the last ssw_ctx_reset_timing.  Synchronises. */
+int ssw_ctx_get_select_stats(ssw_ctx* ctx, uint64_t* stats);
 
 /* Even/odd folding of the basis GEMMs (fewer multiply-adds for the same transform; exact in f64,
    one extra rounding per input pair in f32) where the frame shape allows (W % 8 == 0 / H % 8 == 0).

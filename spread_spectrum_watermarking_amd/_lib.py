@@ -62,6 +62,7 @@ SIGNATURES = {
     "ssw_ctx_set_prune": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_set_odd_split": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_get_prune_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
+    "ssw_ctx_get_select_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ssw_dev_mem_info": (C.c_int, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "ssw_dev_alloc": (C.c_int, [_vp, _sz, C.POINTER(_vp)]),
     "ssw_dev_free": (C.c_int, [_vp, _vp]),

@@ -111,6 +111,11 @@ class Context:
         check(self._lib.ssw_ctx_get_prune_stats(self.handle, st), "ssw_ctx_get_prune_stats")
         return {"pruned_chunks": int(st[0]), "redone_chunks": int(st[1]), "columns_needed": int(st[2])}
 
+    def select_stats(self) -> dict:
+        st = (C.c_uint64 * 2)()
+        check(self._lib.ssw_ctx_get_select_stats(self.handle, st), "ssw_ctx_get_select_stats")
+        return {"frames": int(st[0]), "exact_fallback_frames": int(st[1])}
+
     def set_copy_threads(self, n: int = 0):
         """Host threads that move pageable buffers through the pinned staging ring (0 = automatic)."""
         check(self._lib.ssw_ctx_set_copy_threads(self.handle, int(n)), "ssw_ctx_set_copy_threads")

@@ -492,7 +492,7 @@ __device__ void block_select_sort(const Src& src, size_t n, size_t k, unsigned n
 __global__ __launch_bounds__(FINISH_THREADS) void select_finish_kernel(
     const float* __restrict__ coef, size_t plane_len, KeyParams kp, uint32_t* __restrict__ ctrl,
     uint32_t* __restrict__ hist, const uint64_t* __restrict__ cand, size_t cap, size_t k, unsigned n_pow2,
-    uint32_t* __restrict__ indices) {
+    uint32_t* __restrict__ indices, uint32_t* __restrict__ fallbacks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* lbuf = reinterpret_cast<uint64_t*>(smem_raw);                      // max(n_pow2, blockDim.x) entries
     uint64_t* lstate = lbuf + (n_pow2 > blockDim.x ? n_pow2 : blockDim.x);       // 8 entries
@@ -507,6 +507,7 @@ __global__ __launch_bounds__(FINISH_THREADS) void select_finish_kernel(
         CandSource src{cand + f * cap};
         block_select_sort(src, n, k, n_pow2, lhist, lpart, lbuf, lstate, indices + f * k);
     } else {                                     // degenerate data: exact select over the whole plane
+        if (threadIdx.x == 0 && fallbacks) atomicAdd(fallbacks, 1u);      // a latency cliff: visible in ssw_ctx_get_select_stats
         PlaneSource src{coef + f * plane_len, kp};
         block_select_sort(src, plane_len - 1, k, n_pow2, lhist, lpart, lbuf, lstate, indices + f * k);
     }
@@ -572,7 +573,7 @@ int launch_topk(hipStream_t st, const float* coef, size_t n_frames, size_t w, si
         }
     }
     select_finish_kernel<<<(unsigned)n_frames, FINISH_THREADS, smem, st>>>(coef, plane_len, kp, ws.ctrl, ws.hist,
-                                                                            ws.cand, ws.cap, k, n_pow2, indices);
+                                                                            ws.cand, ws.cap, k, n_pow2, indices, ws.fallbacks);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -201,6 +201,7 @@ struct SelectWorkspace {
     uint32_t* ctrl = nullptr;       // [n_frames][4]: threshold digit, candidate count, 2 spare
     uint64_t* cand = nullptr;       // [n_frames][cap] candidate composite keys
     size_t frames = 0, cap = 0;
+    uint32_t* fallbacks = nullptr;  // (the context's) counter of frames whose finish ran the exact whole-plane select
 };
 size_t select_cand_capacity(size_t k);   // candidate slots per frame needed for mark length k
 size_t select_max_k();
@@ -316,6 +317,8 @@ struct ssw_ctx {
     // three 4K planes cost more than the transform); all reuse is ordered on the context's stream
     std::multimap<size_t, void*> plane_pool;
     size_t plane_pool_bytes = 0;
+    uint32_t* select_fallbacks = nullptr; // device counter: frames whose candidate count fell outside [k, capacity]
+    uint64_t select_frames = 0;           // frames selected since the last ssw_ctx_reset_timing
     ssw::host::Transfer* xfer = nullptr;  // pinned staging ring + copy threads (transfer.hip)
     // host-image streaming entry points (ssw_stream.hip): groups of frames cross PCIe on `copy_stream` (up) and
     // `down_stream` into / out of two alternating device buffers while the group between them is being computed

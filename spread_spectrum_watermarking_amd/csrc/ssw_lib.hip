@@ -259,6 +259,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
         release(ln.prune_u32);
         release_select(ln.sel);
     }
+    if (ctx->select_fallbacks) (void)hipFree(ctx->select_fallbacks);
     release(ctx->overflow);
     release(ctx->small);
     release(ctx->sort_scratch);
@@ -339,6 +340,8 @@ int ssw_ctx_reset_timing(ssw_ctx* ctx) {
     SSW_TRY(flush_timers(ctx));
     for (int s = 0; s < SSW_STAGE_COUNT; ++s) { ctx->stage_ms[s] = 0; ctx->stage_launches[s] = 0; ctx->stage_work[s] = 0; }
     ctx->pruned_chunks = ctx->redone_chunks = ctx->pruned_columns = 0;
+    ctx->select_frames = 0;
+    if (ctx->select_fallbacks) SSW_HIP_CHECK(hipMemsetAsync(ctx->select_fallbacks, 0, sizeof(uint32_t), ctx->stream));
     return SSW_OK;
 }
 
@@ -384,6 +387,21 @@ int ssw_ctx_get_prune_stats(ssw_ctx* ctx, uint64_t* stats) {
     stats[0] = ctx->pruned_chunks;
     stats[1] = ctx->redone_chunks;
     stats[2] = ctx->pruned_columns;
+    return SSW_OK;
+}
+
+int ssw_ctx_get_select_stats(ssw_ctx* ctx, uint64_t* stats) {
+    if (!ctx || !stats) return SSW_ERR_BAD_ARG;
+    CtxGuard g(ctx);
+    stats[0] = ctx->select_frames;
+    stats[1] = 0;
+    if (ctx->select_fallbacks) {
+        uint32_t v = 0;
+        SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->aux_stream) SSW_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
+        SSW_HIP_CHECK(hipMemcpy(&v, ctx->select_fallbacks, sizeof(v), hipMemcpyDeviceToHost));
+        stats[1] = v;
+    }
     return SSW_OK;
 }
 

@@ -693,6 +693,12 @@ int topk(ssw_ctx* ctx, hipStream_t st, SelectWorkspace& sel, const float* coef, 
         return launch_full_sort(st, coef, n, w, h, ordering, ctx->sort_scratch.p, ctx->sort_scratch.bytes, idx, k);
     }
     SSW_TRY(grow_select(st, sel, n, k));
+    if (!ctx->select_fallbacks) {
+        SSW_ALLOC(&ctx->select_fallbacks, sizeof(uint32_t));
+        SSW_HIP_CHECK(hipMemsetAsync(ctx->select_fallbacks, 0, sizeof(uint32_t), st));
+    }
+    sel.fallbacks = ctx->select_fallbacks;
+    ctx->select_frames += n;
     StageTimer t(ctx, SSW_STAGE_SELECT, st, bytes);
     return launch_topk(st, coef, n, w, h, ordering, k, sel, idx);
 }

@@ -274,8 +274,34 @@ def test_topk_matches_oracle_with_ties(ordering):
 def test_topk_matches_oracle_on_real_coefficients(ordering, cat_images):
     y = O.rgb_to_yiq(u8_to_f32(cat_images["cat"]))[0]
     c = O.dct2d(y)
-    for k in (1000, 10000):
+    ctx = G.ctx()
+    ctx.reset_timing()
+    for k in (1000, 4096, 10000):          # 4096 / 10000: the coarser sample strides and the counting-sort finish
         assert np.array_equal(G.topk(c, k, ordering), O.indices(c, ordering, k=k))
+    st = ctx.select_stats()
+    assert st["frames"] == 3 and st["exact_fallback_frames"] == 0, st     # an image never takes the whole-plane fallback
+
+
+def test_exact_fallback_of_the_selection_is_counted():
+    """A constant plane larger than the candidate buffer (every key equal: the sampled threshold keeps everything) takes
+    the exact whole-plane select in the finish kernel -- same result as the oracle's stable sort -- and
+    ssw_ctx_get_select_stats counts it.  Own context: the candidate buffer of a fresh one holds 65 536 keys."""
+    import ctypes as C
+    import spread_spectrum_watermarking_amd as wm
+    from spread_spectrum_watermarking_amd.api import check
+    ctx = wm.Context(0)
+    c = np.full((2, 256, 320), 0.25, np.float32)       # 81 919 equal keys
+    c[1] = np.random.default_rng(3).standard_normal((256, 320)).astype(np.float32)
+    d, idx = ctx.to_device(c), ctx.alloc(2 * 300 * 4)
+    check(ctx._lib.ssw_topk_indices(ctx.handle, d.ptr, 2, 320, 256, L.ORDER_ENERGY, 300, idx.ptr), "ssw_topk_indices")
+    got = idx.to_host(np.uint32, (2, 300))
+    for f in range(2):
+        assert np.array_equal(got[f], O.indices(c[f], k=300))
+    st = ctx.select_stats()
+    assert st == {"frames": 2, "exact_fallback_frames": 1}, st
+    ctx.reset_timing()
+    assert ctx.select_stats() == {"frames": 0, "exact_fallback_frames": 0}
+    d.free(); idx.free(); ctx.close()
 
 
 @pytest.mark.parametrize("ordering", ORDERINGS)
