@@ -1247,7 +1247,11 @@ int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t
 
 // deep forward row pre-pass: src_kind 0 = f32 plane, 1 / 2 = interleaved RGB f32 / u8 (ip / qp: I, Q planes out or null);
 // base: 6 planes of lines * K8 doubles (AS BD AD BS R1 R2) followed by 4 planes of lines * K16 (AS2 BD2 AD2 BS2)
-bool dct_pair_can_deep_rows(size_t len) { return len % 64 == 0 && len >= 256; }
+static size_t deep_min(const char* name, size_t dflt) {           // experiment switch: minimum length for the deep split
+    const char* e = std::getenv(name);
+    return e ? (size_t)std::atoll(e) : dflt;
+}
+bool dct_pair_can_deep_rows(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_ROWS", 256); return len % 64 == 0 && len >= mn; }
 size_t dct_pair_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + 4 * dct_pair_split_kpad(len / 2)); }
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, float* ip, float* qp) {
@@ -1277,9 +1281,9 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
 }
 
 // deep forward column pre-pass (H % 16 == 0): same plane order as the row version, lines = n_frames * w
-bool dct_pair_can_deep_cols(size_t len) { return len % 16 == 0 && len >= 256; }
+bool dct_pair_can_deep_cols(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_COLS", 256); return len % 16 == 0 && len >= mn; }
 // semi-deep: H % 8 == 0 but not % 16 (1080 rows): D split, SS folded a third time, SD left whole
-bool dct_pair_can_semi_deep_cols(size_t len) { return len % 8 == 0 && len % 16 != 0 && len >= 256; }
+bool dct_pair_can_semi_deep_cols(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_COLS", 256); return len % 8 == 0 && len % 16 != 0 && len >= mn; }
 size_t dct_pair_semi_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + pair_kpad<double>(len / 2)); }
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, bool class_major) {
@@ -1311,7 +1315,7 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
 }
 
 // deep inverse pre-passes: same plane order (AS BD AD BS R1 R2 | AS2 BD2 AD2 BS2) with R1 = c[8q], R2 = c[8q+4]
-bool dct_pair_can_deep_inv_rows(size_t len) { return len % 128 == 0 && len >= 256 && len <= 128 * 256; }
+bool dct_pair_can_deep_inv_rows(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_ROWS", 256); return len % 128 == 0 && len >= mn && len <= 128 * 256; }
 static DeepPlanes deep_planes(double* base, size_t lines, size_t len) {
     const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
     DeepPlanes dp;
