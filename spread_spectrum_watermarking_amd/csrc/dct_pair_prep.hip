@@ -87,6 +87,13 @@ __global__ void make_rot_table_kernel(size_t n, double* out) {
 // first-level split through pair_rotate_kernel: any axis whose quarter length folds (rows and columns alike)
 // tile width of the class-major plane orders of a line of length len (dct_pair_common.hpp); SSW_CLASS_TILE=0: one tile
 // (the r3 order)
+// Row passes long enough fold class E of the full-length split once more (launches of K = len/16: 240 at 4K, where such
+// launches run at 71 % of peak against 84 % for K = len/8; at 1080p, K = 120, the same fold LOSES 10 % of the row pass).
+// SSW_EFOLD_MIN: A/B switch (minimum length).
+bool dct_pair_efold(size_t len) {
+    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_MIN"); return e ? (size_t)std::atoll(e) : (size_t)3072; }();
+    return dct_pair_can_deep_rows(len) && len >= mn;
+}
 unsigned dct_pair_class_tile(size_t len) {
     static const int one_tile = [] { const char* e = std::getenv("SSW_CLASS_TILE"); return (e && std::atoi(e) == 0) ? 1 : 0; }();
     return one_tile ? (unsigned)len : class_tile((unsigned)len);
@@ -597,18 +604,22 @@ template <typename T, int SRC /*0 plane, 1 rgb f32, 2 rgb u8*/, bool WITH_IQ>
 __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __restrict__ SRCP, DeepPlanes dp,
                                                               const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                               float* __restrict__ IP, float* __restrict__ QP,
-                                                              unsigned rows, unsigned W, unsigned K8, unsigned K16, unsigned tiles_e) {
+                                                              unsigned rows, unsigned W, unsigned K8, unsigned K16, unsigned tiles_e, unsigned efold) {
     const unsigned Nh = W / 2, Nq = W / 4, N8 = W / 8, N16 = W / 16;
     const unsigned e0 = (blockIdx.x % tiles_e) * 32 + (threadIdx.x & 7) * 4;
     const unsigned row = (blockIdx.x / tiles_e) * 32 + (threadIdx.x >> 3);
     if (row >= rows || e0 >= K16) return;
-    T* AS = static_cast<T*>(dp.as); T* BD = static_cast<T*>(dp.bd); T* AD = static_cast<T*>(dp.ad); T* BS = static_cast<T*>(dp.bs);
+    T* AD = static_cast<T*>(dp.ad); T* BS = static_cast<T*>(dp.bs);
     T* R1 = static_cast<T*>(dp.r1); T* R2 = static_cast<T*>(dp.r2);
     T* AS2 = static_cast<T*>(dp.as2); T* BD2 = static_cast<T*>(dp.bd2); T* AD2 = static_cast<T*>(dp.ad2); T* BS2 = static_cast<T*>(dp.bs2);
     auto put = [&](T* plane, unsigned k, const vec4_t<T>& v) { *reinterpret_cast<vec4_t<T>*>(plane + blk_index<T>(row, k, rows)) = v; };
     const vec4_t<T> zero = {0, 0, 0, 0};
     if (e0 >= N16) {                                              // padding of the n/16-wide planes
         put(AS2, e0, zero); put(BD2, e0, zero); put(AD2, e0, zero); put(BS2, e0, zero);
+        if (efold) {
+            put(static_cast<T*>(dp.asp), e0, zero); put(static_cast<T*>(dp.asm_), e0, zero);
+            put(static_cast<T*>(dp.bdp), e0, zero); put(static_cast<T*>(dp.bdm), e0, zero);
+        }
         return;
     }
     // quads of x, ascending positions inside a quad
@@ -645,13 +656,28 @@ __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __res
             S[u][i] = (T)x[u][i] + (T)x[15 - u][3 - i];
             D[u][i] = (T)x[u][i] - (T)x[15 - u][3 - i];
         }
-    // D (DCT-IV input of length n/2): the unit at e0 and its mirror unit at n/8 - 4 - e0
+    // D (DCT-IV input of length n/2): the unit at e0 and its mirror unit at n/8 - 4 - e0.  AS and BD (class E: a DCT-II
+    // and a DST-II of length n/8) fold once more with their mirrors -- element e0 + i meets element n/8 - 1 - (e0 + i), which
+    // is element 3 - i of the mirror unit: exact additions -- into AS+ AS- BD+ BD- of length n/16 (launches E even / odd)
     {
-        vec4_t<T> as, bd, ad, bs;
+        vec4_t<T> as, bd, ad, bs, asm_, bdm_;
         split_unit<T>(D[0], D[3], D[4], D[7], rot1, e0, Nq, as, bd, ad, bs);
-        put(AS, e0, as); put(BD, e0, bd); put(AD, e0, ad); put(BS, e0, bs);
-        split_unit<T>(D[1], D[2], D[5], D[6], rot1, N8 - 4 - e0, Nq, as, bd, ad, bs);
-        put(AS, N8 - 4 - e0, as); put(BD, N8 - 4 - e0, bd); put(AD, N8 - 4 - e0, ad); put(BS, N8 - 4 - e0, bs);
+        put(AD, e0, ad); put(BS, e0, bs);
+        split_unit<T>(D[1], D[2], D[5], D[6], rot1, N8 - 4 - e0, Nq, asm_, bdm_, ad, bs);
+        put(AD, N8 - 4 - e0, ad); put(BS, N8 - 4 - e0, bs);
+        if (efold) {
+            vec4_t<T> p, m, q, r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                p[i] = as[i] + asm_[3 - i]; m[i] = as[i] - asm_[3 - i];
+                q[i] = bd[i] + bdm_[3 - i]; r[i] = bd[i] - bdm_[3 - i];
+            }
+            put(static_cast<T*>(dp.asp), e0, p); put(static_cast<T*>(dp.asm_), e0, m);
+            put(static_cast<T*>(dp.bdp), e0, q); put(static_cast<T*>(dp.bdm), e0, r);
+        } else {
+            put(static_cast<T*>(dp.as), e0, as); put(static_cast<T*>(dp.bd), e0, bd);
+            put(static_cast<T*>(dp.as), N8 - 4 - e0, asm_); put(static_cast<T*>(dp.bd), N8 - 4 - e0, bdm_);
+        }
     }
     // level 2 on S (length n/2): quad u mirrors quad 7 - u
     vec4_t<T> SS[4], SD[4];
@@ -682,7 +708,8 @@ __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __res
     }
     if (e0 == 0)
         for (unsigned z = N8; z < K8; z += 4) {
-            put(AS, z, zero); put(BD, z, zero); put(AD, z, zero); put(BS, z, zero); put(R1, z, zero); put(R2, z, zero);
+            put(AD, z, zero); put(BS, z, zero); put(R1, z, zero); put(R2, z, zero);
+            if (!efold) { put(static_cast<T*>(dp.as), z, zero); put(static_cast<T*>(dp.bd), z, zero); }
         }
 }
 
@@ -796,7 +823,7 @@ template <typename T, bool SPLIT_SD>
 __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                               const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                               unsigned W, unsigned H, unsigned K8, unsigned K16,
-                                                              unsigned n_frames, unsigned tiles_e, unsigned tiles_c, unsigned class_major, unsigned ctile) {
+                                                              unsigned n_frames, unsigned tiles_e, unsigned tiles_c, unsigned class_major, unsigned ctile, unsigned efold) {
     __shared__ T s[4][32][33];
     const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = SPLIT_SD ? H / 16 : (H / 8 + 1) / 2;      // H16: units
     const unsigned z = blockIdx.x / (tiles_e * tiles_c);
@@ -809,16 +836,16 @@ __global__ __launch_bounds__(256) void pair_prep16_cols_kernel(const float* __re
     // class_major == 2 (W % 256 == 0, long lines): the block takes the ten runs of memory columns -- one per launch class,
     // 32 or 16 wide -- that hold the natural columns [256 tile, 256 tile + 256): its stores then fill whole runs of
     // operand lines (8K: both pre-passes of a forward transform 7.1 -> 6.5 ms per 32 frames; at 4K the plain mapping is faster)
-    const unsigned nsub = class_major == 2 ? 10u : 1u;
+    const unsigned nsub = 1u;
     for (unsigned sub = 0; sub < nsub; ++sub) {
     if (sub) __syncthreads();
-    const unsigned wd = (class_major == 2 && sub >= 2 && sub < 6) ? 16u : 32u;
-    const unsigned c0 = class_major == 2 ? ForwardClassLayout{W}.base((int)sub) + tile * wd : tile * 32;      // 2: one tile (ctile == W)
+    const unsigned wd = 32u;
+    const unsigned c0 = tile * 32;
     const bool col_ok = cl < wd && c0 + cl < W;
     const unsigned cw = c0 + cl, ew = e0 + kq;
     // memory column cw of the intermediate plane holds frequency natural(cw) of the row pass (class-major order): the
     // operand line -- and with it the output column of the column GEMMs -- is the natural one
-    const unsigned cn = (class_major && col_ok) ? ForwardClassLayout{W, ctile}.natural(cw) : cw;
+    const unsigned cn = (class_major && col_ok) ? ForwardClassLayout{W, ctile, efold != 0}.natural(cw) : cw;
     const size_t line = (size_t)z * W + cn, lines = (size_t)n_frames * W;
     T* planes8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs),
                      static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
@@ -1252,7 +1279,8 @@ static size_t deep_min(const char* name, size_t dflt) {           // experiment 
     return e ? (size_t)std::atoll(e) : dflt;
 }
 bool dct_pair_can_deep_rows(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_ROWS", 256); return len % 64 == 0 && len >= mn; }
-size_t dct_pair_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + 4 * dct_pair_split_kpad(len / 2)); }
+// 6 planes K8 wide + 4 K16 wide + (row passes) the 4 folded class-E planes, K16 wide
+size_t dct_pair_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + 8 * dct_pair_split_kpad(len / 2)); }
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, float* ip, float* qp) {
     if (n_frames == 0) return SSW_OK;
@@ -1268,9 +1296,12 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
     dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
     p += 6 * p8;
     dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
+    p += 4 * p16;
+    dp.asp = p; dp.asm_ = p + p16; dp.bdp = p + 2 * p16; dp.bdm = p + 3 * p16;
+    const unsigned efold = dct_pair_efold(w) ? 1u : 0u;
     const bool iq = ip && qp;
 #define SSW_PREP16(SRCV, IQV) pair_prep16_rows_kernel<double, SRCV, IQV><<<(unsigned)nblk, 256, 0, st>>>( \
-        src, dp, rot1, rot2, ip, qp, (unsigned)rows, (unsigned)w, K8, K16, tiles_e)
+        src, dp, rot1, rot2, ip, qp, (unsigned)rows, (unsigned)w, K8, K16, tiles_e, efold)
     if (src_kind == 0) SSW_PREP16(0, false);
     else if (src_kind == 1) { if (iq) SSW_PREP16(1, true); else SSW_PREP16(1, false); }
     else if (src_kind == 2) { if (iq) SSW_PREP16(2, true); else SSW_PREP16(2, false); }
@@ -1294,10 +1325,10 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
     const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the SD plane
     if (dct_pair_prep_staged_cols_ok(w, class_major))
-        return launch_prep16_cols_staged(st, in, n_frames, w, h, base, rot1, rot2, class_major, semi, K8, K16);
+        return launch_prep16_cols_staged(st, in, n_frames, w, h, base, rot1, rot2, class_major, semi, K8, K16, dct_pair_efold(w));
     const unsigned units = semi ? (unsigned)(((h / 8 + 1) / 2 + 3) & ~(size_t)3) : K16;
     const unsigned ctile = dct_pair_class_tile(w);
-    const unsigned cm = !class_major ? 0u : (ctile == w && w % 256 == 0 && w >= 6144) ? 2u : 1u;      // 8K: 7.1 -> 6.5 ms; 4K: 7.6 -> 7.8
+    const unsigned cm = !class_major ? 0u : 1u;      // (the r3 per-class-run mode, 2, knew the ten-class order; lines of such lengths take the staged kernels now)
     const unsigned tiles_e = (units + 31) / 32, tiles_c = cm == 2 ? (unsigned)(w / 256) : (unsigned)((w + 31) / 32);
     const unsigned long long nblk = (unsigned long long)tiles_e * tiles_c * n_frames;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
@@ -1308,8 +1339,8 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
     dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
     p += 6 * p8;
     dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;      // semi: as2 = the SD plane, the others unused
-    if (semi) pair_prep16_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, 0u, ctile);
-    else      pair_prep16_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, cm, ctile);
+    if (semi) pair_prep16_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, 0u, ctile, 0u);
+    else      pair_prep16_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tiles_e, tiles_c, cm, ctile, dct_pair_efold(w) ? 1u : 0u);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -33,8 +33,8 @@ __device__ inline unsigned slab_sw(unsigned l) {
 }
 // operand line (inside the tile) of memory column m of the tile
 template <int MODE>
-__device__ inline unsigned tile_line(unsigned m) {
-    if (MODE == 1) return ForwardClassLayout{CT, CT}.natural(m);
+__device__ inline unsigned tile_line(unsigned m, bool efold = true) {
+    if (MODE == 1) return ForwardClassLayout{CT, CT, efold}.natural(m);
     if (MODE == 2) return inverse_class_natural(m, CT, CT);
     return m;
 }
@@ -125,7 +125,7 @@ template <int MODE, bool SPLIT_SD>
 __global__ __launch_bounds__(256) void prep16_cols_staged_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                                  const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                                  unsigned W, unsigned H, unsigned K8, unsigned K16,
-                                                                 unsigned n_frames, unsigned groups, unsigned tiles_c, unsigned nwork) {
+                                                                 unsigned n_frames, unsigned groups, unsigned tiles_c, unsigned nwork, unsigned efold) {
     __shared__ __attribute__((aligned(16))) double lds[6 * SLABD];
     const unsigned id = xcd_contiguous_id(blockIdx.x, nwork);
     const unsigned g = id % groups, zt = id / groups, ct = zt % tiles_c, z = zt / tiles_c;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void prep16_cols_staged_kernel(const float* __
     unsigned off[4], sws[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned l = tile_line<MODE>(4 * mq + i);
+        const unsigned l = tile_line<MODE>(4 * mq + i, efold != 0);
         sws[i] = slab_sw<MODE>(l);
         off[i] = l * 8;
     }
@@ -556,7 +556,7 @@ bool dct_pair_prep_staged_cols_ok(size_t w, bool class_major) {
 bool dct_pair_prep_staged_rows_ok() { return staged_enabled(); }
 
 int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                              const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16) {
+                              const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16, bool efold) {
     const unsigned HU = semi ? (unsigned)((h / 8 + 1) / 2) : (unsigned)(h / 16);
     const unsigned sh = (8u - (unsigned)((h / 8) & 7)) & 7u;       // shift of the mirrored units (kernel comment, round B)
     const unsigned groups = (HU + sh + 7) / 8, tiles_c = (unsigned)((w + CT - 1) / CT);
@@ -564,7 +564,7 @@ int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, 
     if (nwork > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     const DeepPlanes dp = planes_of(base, n_frames * w, K8, K16);
 #define SSW_L(MODEV, SPLITV) prep16_cols_staged_kernel<MODEV, SPLITV><<<(unsigned)nwork, 256, 0, st>>>( \
-        in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, (unsigned)nwork)
+        in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, (unsigned)nwork, efold ? 1u : 0u)
     if (class_major) { if (semi) SSW_L(1, false); else SSW_L(1, true); }
     else             { if (semi) SSW_L(0, false); else SSW_L(0, true); }
 #undef SSW_L

@@ -42,6 +42,9 @@ struct DeepPlanes {        // device pointers of one pass's operand planes
     void *as, *bd, *ad, *bs;         // K8 wide
     void *r1, *r2;                   // K8 wide
     void *as2, *bd2, *ad2, *bs2;     // K16 wide
+    // forward ROW passes (r4b): class E's operands folded once more, AS +/- its mirror and BD +/- its mirror (K16 wide);
+    // `as` and `bd` are then not written
+    void *asp = nullptr, *asm_ = nullptr, *bdp = nullptr, *bdm = nullptr;
 };
 
 

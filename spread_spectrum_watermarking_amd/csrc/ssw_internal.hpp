@@ -142,11 +142,12 @@ int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1,
 bool dct_pair_can_split(size_t len, bool is_row);
 size_t dct_pair_split_kpad(size_t len);
 unsigned dct_pair_class_tile(size_t len);               // tile width of the class-major plane orders (dct_pair_common.hpp)
+bool dct_pair_efold(size_t len);                        // forward row passes of this length fold class E once more (r4b)
 // LDS-staged forms of the deep pre-passes (dct_pair_prep_staged.hip; SSW_PREP_STAGED=0 keeps the r3 kernels)
 bool dct_pair_prep_staged_cols_ok(size_t w, bool class_major);
 bool dct_pair_prep_staged_rows_ok();
 int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                              const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16);
+                              const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16, bool efold);
 int launch_prep16_inv_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                   const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16);
 int launch_prep16_inv_rows_staged(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
@@ -184,7 +185,7 @@ constexpr uint32_t PRUNE_NEG = 0x40000000u;              // rows[] flag: negate 
 struct PruneClass { unsigned mod, rem, cap, off, rem2 = PRUNE_NO_REM, radd = 0; };
 struct PrunePlan {
     unsigned n_classes = 0;
-    PruneClass c[6];
+    PruneClass c[7];        // info[] of launch_prune_build holds 1 + 7 words
     unsigned W = 0, cap_total = 0;
 };
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,

@@ -220,6 +220,7 @@ double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t
     const double lines = (double)(is_row ? n * h : n * w);
     const size_t leff = (is_row ? w : h) >> sub;
     if (kind == 3 || kind == 4) return 4.0 * lines * (double)(leff / 8) * (double)(leff / 8);      // class E: n/8 + 1 pairs in n/8 slots
+    if (kind == 5 || kind == 6) return 4.0 * lines * (double)(leff / 16) * (double)(leff / 16);    // class E folded once more: half the length
     const double np = (double)(kind == 0 ? leff / 2 : leff / 4), k = (double)(kind == 1 ? leff / 4 : leff / 2);
     return 4.0 * lines * np * k;
 }
@@ -301,9 +302,16 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 return launch_dct_pair_prep16_rows(st, from_rgb ? pix_src_kind(rgb_u8) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
                                                    (const double*)rot, (const double*)rot2, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
             }});
-            // the "main" timer brackets ONE launch: class E of the full-length split (the largest launch of the pass)
-            const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h);
-            const double f_all = f_main + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) +
+            // Row passes (r4b): class E of the full-length split -- a DCT-II of AS and a DST-II of BD, length len/8 -- folds
+            // once more with exact additions (the pre-pass writes AS+ AS- BD+ BD-, length len/16): two launches of half the
+            // sum length and half the pairs each (kinds 5 / 6) instead of one, half of its multiply-adds.  Class O (a
+            // DCT-IV / DST-IV pair: no reflection symmetry) and the column passes (K = len/16 launches run at 51 % there)
+            // stay.  The "main" timer brackets ONE launch: class O of the full-length split (now the largest of the pass).
+            const bool efold = is_row && dct_pair_efold(len);
+            double* ep_ = q + 4 * p16;                                 // AS+ AS- BD+ BD- (launch_dct_pair_prep16_rows)
+            const double f_main = pair_gemm_flop(is_row, 4, 0, n, w, h);
+            const double f_e = efold ? pair_gemm_flop(is_row, 5, 0, n, w, h) + pair_gemm_flop(is_row, 6, 0, n, w, h) : pair_gemm_flop(is_row, 3, 0, n, w, h);
+            const double f_all = f_main + f_e + pair_gemm_flop(is_row, 1, 1, n, w, h) +
                                  pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             // a single frame's launches are too small alone (class E of a 4K frame: 272 blocks for 512 slots): one launch
             // over the five classes instead
@@ -312,20 +320,28 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 StageTimer t(ctx, st_pass, st, f_all);
                 const bool rcm = cm && is_row;
                 if (merge) {
-                    const PairClassDesc d[5] = {{1, 1, sp + 4 * p8, sp + 5 * p8, (const double*)e0, (const double*)e1},
+                    // E even / odd: the bases are those of class E' / O' (the quarter-length cosine / sine bases of len/2)
+                    const PairClassDesc d[6] = {{1, 1, sp + 4 * p8, sp + 5 * p8, (const double*)e0, (const double*)e1},
                                                 {3, 1, q, q + p16, (const double*)t0, (const double*)t1},
                                                 {4, 1, q + 2 * p16, q + 3 * p16, (const double*)t2, (const double*)t3},
                                                 {4, 0, sp + 2 * p8, sp + 3 * p8, (const double*)sb2_, (const double*)sb3},
-                                                {3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1}};
+                                                efold ? PairClassDesc{5, 0, ep_, ep_ + 3 * p16, (const double*)t0, (const double*)t1}
+                                                      : PairClassDesc{3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1},
+                                                {6, 0, ep_ + p16, ep_ + 2 * p16, (const double*)t2, (const double*)t3}};
                     StageTimer tm(ctx, st_main, st, f_all);
-                    return launch_dct_pair_gemm_multi_f64(st, is_row, false, 5, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
+                    return launch_dct_pair_gemm_multi_f64(st, is_row, false, efold ? 6 : 5, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
                 }
                 SSW_TRY(pair_gemm(st, true, is_row, false, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
                 SSW_TRY(pair_gemm(st, true, is_row, false, 3, 1, q, q + p16, t0, t1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
                 SSW_TRY(pair_gemm(st, true, is_row, false, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
-                SSW_TRY(pair_gemm(st, true, is_row, false, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
+                if (efold) {
+                    SSW_TRY(pair_gemm(st, true, is_row, false, 5, 0, ep_, ep_ + 3 * p16, t0, t1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
+                    SSW_TRY(pair_gemm(st, true, is_row, false, 6, 0, ep_ + p16, ep_ + 2 * p16, t2, t3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
+                } else {
+                    SSW_TRY(pair_gemm(st, true, is_row, false, 3, 0, sp, sp + p8, sb0, sb1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
+                }
                 StageTimer tm(ctx, st_main, st, f_main);
-                return pair_gemm(st, true, is_row, false, 3, 0, sp, sp + p8, sb0, sb1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
+                return pair_gemm(st, true, is_row, false, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
             }});
             return SSW_OK;
         }
@@ -842,13 +858,18 @@ PruneSetup make_prune_setup(const ssw_ctx* ctx, bool f64, size_t n, size_t w, si
         off += cc;
         ++nc;
     };
+    ps.deep = ps.split && dct_pair_can_deep_rows(w);
     if (ps.split) {                       // odd v = 8i +/- 1 -> class E row i (= (v + 1) / 8), v = 8i + 5 | 8i + 3 -> class O row i
-        add(8, 1, c / 4, 7, 1);
+        if (ps.deep && dct_pair_efold(w)) {      // class E folded once more (r4b): v = 16i +/- 1 -> row i of E even, v = 16i + 9 | 16i + 7 -> E odd
+            add(16, 1, c / 8, 15, 1);
+            add(16, 9, c / 8, 7, 0);
+        } else {
+            add(8, 1, c / 4, 7, 1);
+        }
         add(8, 5, c / 4, 3, 0);
     } else {
         add(2, 1, c / 2);
     }
-    ps.deep = ps.split && dct_pair_can_deep_rows(w);
     if (ps.deep) {                        // v = 2 (8i +/- 1) -> class E' row i (= (v + 2) / 16), v = 2 (8i + 5) | 2 (8i + 3) -> class O' row i
         add(16, 2, c / 8, 14, 2);
         add(16, 10, c / 8, 6, 0);
@@ -884,7 +905,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     uint32_t* rows = pos + w;
     // class -> image operand plane(s), cached basis plane(s), padded / true sum length
     struct ClassSrc { const void* x; const void* basis; size_t src_rows, kp, ktrue; const void* x2 = nullptr; const void* basis2 = nullptr; };
-    ClassSrc cs[6];
+    ClassSrc cs[7];
     unsigned ci = 0;
     const size_t lines = n * h;
     const void *rot = nullptr, *rot2 = nullptr;
@@ -896,16 +917,22 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         const size_t kp8 = dct_pair_split_kpad(w), plane = lines * kp8;
         SSW_TRY(grow(ws.operand[5], split_scratch_elems(n, w, h) * sizeof(double)));
         sp = (double*)ws.operand[5].p;
-        cs[ci++] = {sp, sb[0], dct_pair_split_basis_rows(w, 0), kp8, w / 8, sp + plane, sb[1]};                  // AS x cosE, BD x sinE
+        const void *sb2[4] = {nullptr, nullptr, nullptr, nullptr}, *e0 = nullptr, *e1 = nullptr;
+        const size_t kp16 = dct_pair_split_kpad(w / 2), p16 = lines * kp16;
+        double* q = sp + 6 * plane;
+        if (ps.deep) for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w / 2, false, true, 5 + b, &sb2[b]));
+        if (ps.deep && dct_pair_efold(w)) {
+            double* ef = q + 4 * p16;                                   // AS+ AS- BD+ BD- (launch_dct_pair_prep16_rows)
+            cs[ci++] = {ef, sb2[0], dct_pair_split_basis_rows(w / 2, 0), kp16, w / 16, ef + 3 * p16, sb2[1]};           // AS+ x cosE', BD- x sinE'
+            cs[ci++] = {ef + p16, sb2[2], dct_pair_split_basis_rows(w / 2, 2), kp16, w / 16, ef + 2 * p16, sb2[3]};     // AS- x cosO', BD+ x sinO'
+        } else {
+            cs[ci++] = {sp, sb[0], dct_pair_split_basis_rows(w, 0), kp8, w / 8, sp + plane, sb[1]};              // AS x cosE, BD x sinE
+        }
         cs[ci++] = {sp + 2 * plane, sb[2], dct_pair_split_basis_rows(w, 2), kp8, w / 8, sp + 3 * plane, sb[3]};  // AD x cosO, BS x sinO
         if (ps.deep) {
-            const void *sb2[4], *e0 = nullptr, *e1 = nullptr;
-            for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w / 2, false, true, 5 + b, &sb2[b]));
             SSW_TRY(get_basis(ctx, w / 2, false, true, 9, &rot2));
             SSW_TRY(get_basis(ctx, w / 4, false, true, 3, &e0));
             SSW_TRY(get_basis(ctx, w / 4, false, true, 4, &e1));
-            const size_t kp16 = dct_pair_split_kpad(w / 2), p16 = lines * kp16;
-            double* q = sp + 6 * plane;
             cs[ci++] = {q, sb2[0], dct_pair_split_basis_rows(w / 2, 0), kp16, w / 16, q + p16, sb2[1]};              // AS2 x cosE', BD2 x sinE'
             cs[ci++] = {q + 2 * p16, sb2[2], dct_pair_split_basis_rows(w / 2, 2), kp16, w / 16, q + 3 * p16, sb2[3]}; // AD2 x cosO', BS2 x sinO'
             cs[ci++] = {sp + 4 * plane, e0, w / 8, kp8, w / 8};                                                      // R1 (SSS): 0 mod 8
@@ -933,7 +960,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         cs[ci++] = {ws.operand[3].p, q1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SD : 2 mod 4
     }
     if (ci != plan.n_classes) return SSW_ERR_BAD_ARG;
-    size_t goff[6], goff2[6], gtotal = 0;
+    size_t goff[7], goff2[7], gtotal = 0;
     for (unsigned c = 0; c < plan.n_classes; ++c) {
         goff[c] = gtotal; gtotal += cs[c].kp * plan.c[c].cap * esz;
         goff2[c] = gtotal; if (cs[c].x2) gtotal += cs[c].kp * plan.c[c].cap * esz;

@@ -11,9 +11,10 @@ static int fail(const char* what, unsigned n, unsigned at) { std::printf("FAIL %
 
 int main() {
     for (unsigned n : {256u, 320u, 1024u, 1920u, 3840u, 7680u})
-    for (unsigned t : {n, class_tile(n)}) {
+    for (unsigned t : {n, class_tile(n)})
+    for (bool efold : {false, true}) {
         if (n % t != 0) return fail("tile does not divide the line", n, t);
-        const ForwardClassLayout fl{n, t};
+        const ForwardClassLayout fl{n, t, efold};
         std::vector<int> seen(n, 0);
         for (unsigned p = 0; p < n; ++p) {
             const unsigned u = fl.natural(p);
@@ -25,25 +26,35 @@ int main() {
         for (unsigned i = 0; i < n / 8; ++i) {
             if (fl.natural(fl.pos(ForwardClassLayout::R1, i)) != 8 * i) return fail("R1", n, i);
             if (fl.natural(fl.pos(ForwardClassLayout::R2, i)) != 8 * i + 4) return fail("R2", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::EP, i)) != 8 * i + 1) return fail("E+", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::EM, (i + 1) - 1)) != 8 * (i + 1) - 1) return fail("E-", n, i);
             if (fl.natural(fl.pos(ForwardClassLayout::OP, i)) != 8 * i + 5) return fail("O+", n, i);
             if (fl.natural(fl.pos(ForwardClassLayout::OM, i)) != 8 * i + 3) return fail("O-", n, i);
+        }
+        for (unsigned i = 0; i < n / 8 && !efold; ++i) {      // class E whole: pair i -> 8 i +/- 1
+            if (fl.natural(fl.pos(ForwardClassLayout::EP, i)) != 8 * i + 1) return fail("E+", n, i);
+            if (fl.natural(fl.pos(ForwardClassLayout::EM, (i + 1) - 1)) != 8 * (i + 1) - 1) return fail("E-", n, i);
         }
         for (unsigned i = 0; i < n / 16; ++i) {
             if (fl.natural(fl.pos(ForwardClassLayout::E2P, i)) != 2 * (8 * i + 1)) return fail("E'+", n, i);
             if (fl.natural(fl.pos(ForwardClassLayout::E2M, (i + 1) - 1)) != 2 * (8 * (i + 1) - 1)) return fail("E'-", n, i);
             if (fl.natural(fl.pos(ForwardClassLayout::O2P, i)) != 2 * (8 * i + 5)) return fail("O'+", n, i);
             if (fl.natural(fl.pos(ForwardClassLayout::O2M, i)) != 2 * (8 * i + 3)) return fail("O'-", n, i);
+            // class E folded once more: pair i of the even launch -> 16 i +/- 1 (the "-" output of pair i is entry i - 1),
+            // pair i of the odd launch -> 16 i + 9 and 16 i + 7
+            if (!efold) continue;
+            if (fl.natural(fl.pos(ForwardClassLayout::EEP, i)) != 16 * i + 1) return fail("Ee+", n, i);
+            if (fl.natural(fl.pos(ForwardClassLayout::EEM, (i + 1) - 1)) != 16 * (i + 1) - 1) return fail("Ee-", n, i);
+            if (fl.natural(fl.pos(ForwardClassLayout::EOP, i)) != 16 * i + 9) return fail("Eo+", n, i);
+            if (fl.natural(fl.pos(ForwardClassLayout::EOM, i)) != 16 * i + 7) return fail("Eo-", n, i);
         }
         // the shift form of pos() the GEMM epilogue uses when the tile is a power of two
         if (t != n)
-            for (int c = 0; c < 10; ++c) {
+            for (int c = 0; c < ForwardClassLayout::NCLASS; ++c) {
+                if (!fl.has(c)) continue;
                 const unsigned g = fl.group(c);
                 unsigned gsh = 0;
                 while ((1u << gsh) < g) ++gsh;
                 if ((1u << gsh) != g) return fail("group not a power of two", n, g);
-                for (unsigned e = 0; e < n / (c >= 2 && c < 6 ? 16 : 8); ++e)
+                for (unsigned e = 0; e < n / ForwardClassLayout::mod(c); ++e)
                     if (fl.base(c) + (e >> gsh) * t + (e & (g - 1)) != fl.pos(c, e)) return fail("shift form of pos()", n, e);
             }
         std::vector<int> seen2(n, 0);
