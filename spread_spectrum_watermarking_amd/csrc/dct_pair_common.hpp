@@ -78,36 +78,42 @@ struct PairOutT {
 // frequencies of one GEMM launch class side by side, so that a launch stores runs instead of one float in 8 or 16.
 // (The natural order made every row launch rewrite the whole plane: 5 x 4.2 GB of HBM writes per 128 4K frames instead
 // of 4.2 GB -- PMC WRITE_SIZE -- and the clock the chip holds under that load was 10-20 % lower.)
-//   class      R1     R2     E2P      E2M      O2P      O2M      EeP     EeM      EoP     EoM     OP     OM
-//   u mod      8: 0   8: 4   16: 2    16: 14   16: 10   16: 6    16: 1   16: 15   16: 9   16: 7   8: 5   8: 3
-//   length     t/8    t/8    t/16     t/16     t/16     t/16     t/16    t/16     t/16    t/16    t/8    t/8
+//   class      R1     R2     E2P      E2M      O2P      O2M      EP     EM     OP     OM
+//   u mod      8: 0   8: 4   16: 2    16: 14   16: 10   16: 6    8: 1   8: 7   8: 5   8: 3
+//   length     t/8    t/8    t/16     t/16     t/16     t/16     t/8    t/8    t/8    t/8
 // r4: the order is class-major INSIDE TILES of t natural frequencies (t = 128 when 128 divides n, else t = n: one tile):
 // the t frequencies [T t, T t + t) occupy the memory columns [T t, T t + t), classes side by side.  A row launch still
 // stores runs (t/8 = 16 entries = the 16 pairs of one MFMA tile), and a block of the column pre-pass now reads ONE
 // contiguous 512-byte run per row for 128 consecutive operand lines (the one-tile order gave it ten runs of 64 / 32
 // bytes, or -- read by memory column -- stores scattered over lines 8 or 16 apart: 2.8 TB/s).
-// r4b: class E of the full-length split (8i +/- 1) is folded once more on row passes -- two launches, even rows
-// (16i +/- 1: EeP, EeM) and odd rows (16i + 8 +/- 1: EoP, EoM) of its bases -- so its two classes are four of half the size.
+// r4b (`level2`: row passes of 3072 columns or more, dct_pair_efold): every launch of the pass works on sums of n/16
+// terms and owns two residues mod 16 -- sixteen classes of t/16 entries each, in this order:
+//   class      R1A  R1B  R2A  R2B   E2P  E2M  O2P  O2M   EEP  EEM  EOP  EOM   O5  O11  O3  O13
+//   u mod 16   0    8    4    12    2    14   10   6     1    15   9    7     5   11   3   13
 struct ForwardClassLayout {
     unsigned n, t;
-    bool efold;               // class E folded once more (EEP .. EOM, t/16 each) or whole (EP EM, t/8 each) in the same columns
-    enum { R1 = 0, R2, E2P, E2M, O2P, O2M, EEP, EEM, EOP, EOM, OP, OM, EP, EM, NCLASS };
-    __host__ __device__ ForwardClassLayout(unsigned n_, unsigned t_ = 0, bool efold_ = true) : n(n_), t(t_ ? t_ : n_), efold(efold_) {}
+    bool level2;
+    enum { R1 = 0, R2, E2P, E2M, O2P, O2M, EP, EM, OP, OM, NCLASS1 };                                    // level2 == false
+    enum { R1A = 0, R1B, R2A, R2B, F_E2P, F_E2M, F_O2P, F_O2M, EEP, EEM, EOP, EOM, O5, O11, O3, O13, NCLASS2 };   // level2 == true
+    __host__ __device__ ForwardClassLayout(unsigned n_, unsigned t_ = 0, bool level2_ = false) : n(n_), t(t_ ? t_ : n_), level2(level2_) {}
+    __host__ __device__ int classes() const { return level2 ? (int)NCLASS2 : (int)NCLASS1; }
     // frequencies of class c: mod(c) i + res(c)
-    __host__ __device__ static unsigned mod(int c) { return (c < 2 || c >= OP) ? 8u : 16u; }
-    __host__ __device__ static unsigned res(int c) {
-        return c == R1 ? 0u : c == R2 ? 4u : c == E2P ? 2u : c == E2M ? 14u : c == O2P ? 10u : c == O2M ? 6u : c == EEP ? 1u
-             : c == EEM ? 15u : c == EOP ? 9u : c == EOM ? 7u : c == OP ? 5u : c == OM ? 3u : c == EP ? 1u : 7u;
+    __host__ __device__ unsigned mod(int c) const { return level2 ? 16u : ((c >= E2P && c <= O2M) ? 16u : 8u); }
+    __host__ __device__ unsigned res(int c) const {
+        if (level2) {
+            const unsigned char r[16] = {0, 8, 4, 12, 2, 14, 10, 6, 1, 15, 9, 7, 5, 11, 3, 13};
+            return r[c & 15];
+        }
+        const unsigned char r[10] = {0, 4, 2, 14, 10, 6, 1, 7, 5, 3};
+        return r[c];
     }
-    // does the order hold class c?
-    __host__ __device__ bool has(int c) const { return (c >= EEP && c <= EOM) ? efold : (c == EP || c == EM) ? !efold : c < NCLASS; }
     // entries of class c per tile
     __host__ __device__ unsigned group(int c) const { return t / mod(c); }
-    // offset of class c inside a tile: R1 R2 (t/8 each), E2P .. O2M (t/16 each), class E (EEP EEM EOP EOM, t/16 each, or EP EM,
-    // t/8 each), OP OM (t/8 each)
+    // offset of class c inside a tile
     __host__ __device__ unsigned base(int c) const {
         const unsigned e = t / 8, s = t / 16;
-        return c < 2 ? c * e : c < OP ? 2 * e + (c - 2) * s : c < EP ? 2 * e + 8 * s + (c - OP) * e : 2 * e + 4 * s + (c - EP) * e;
+        if (level2) return (unsigned)c * s;
+        return c < 2 ? c * e : c < 6 ? 2 * e + (c - 2) * s : t / 2 + (c - 6) * e;
     }
     // memory column of entry i of class c
     __host__ __device__ unsigned pos(int c, unsigned i) const {
@@ -120,14 +126,10 @@ struct ForwardClassLayout {
         p -= tb;
         int c;
         unsigned i;
-        if (p < 2 * e) { c = (int)(p / e); i = p - c * e; }
-        else if (p < 2 * e + 4 * s) { const unsigned q = p - 2 * e; c = 2 + (int)(q / s); i = q - (q / s) * s; }
-        else if (p < 2 * e + 8 * s) {
-            const unsigned q = p - 2 * e - 4 * s;
-            if (efold) { c = EEP + (int)(q / s); i = q - (q / s) * s; }
-            else { c = EP + (int)(q / e); i = q - (q / e) * e; }
-        }
-        else { const unsigned q = p - 2 * e - 8 * s; c = OP + (int)(q / e); i = q - (q / e) * e; }
+        if (level2) { c = (int)(p / s); i = p - c * s; }
+        else if (p < 2 * e) { c = (int)(p / e); i = p - c * e; }
+        else if (p < t / 2) { const unsigned q = p - 2 * e; c = 2 + (int)(q / s); i = q - (q / s) * s; }
+        else { const unsigned q = p - t / 2; c = 6 + (int)(q / e); i = q - (q / e) * e; }
         return tb + mod(c) * i + res(c);
     }
 };

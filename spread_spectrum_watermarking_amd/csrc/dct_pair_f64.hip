@@ -85,7 +85,7 @@ struct PairClassArgs {
     unsigned gsh, e2off;               // forward class-major output map (PairOutT::ft)
 };
 struct PairMulti {
-    PairClassArgs c[6];
+    PairClassArgs c[8];
     unsigned n_classes, L, tiles_m, tiles_n_total;
     PairOut po;                        // the fields the classes share; c1 .. bn32 are overwritten per class
 };
@@ -879,11 +879,14 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
                     PairClassArgs& ca, PairInstance& inst) {
     const int kind = d.kind, sub = d.sub;
     // inverse: sub = 1 serves the deep inverse (the half-length transform E): kind 1 -> its even half T2, kinds 3 / 4 -> E
-    if (kind < 0 || kind > 6 || sub < 0 || sub > 8 || (sub > 0 && kind == 0) || (sub > 0 && inverse && sub != 1)) return SSW_ERR_BAD_ARG;
+    if (kind < 0 || kind > 9 || sub < 0 || sub > 8 || (sub > 0 && kind == 0) || (sub > 0 && inverse && sub != 1)) return SSW_ERR_BAD_ARG;
     // kinds 5 / 6 (forward): class E (kind 3) folded once more -- the even / odd rows of its bases, operands AS+ | BD- and
     // AS- | BD+ of half the length: the arithmetic of kinds 3 / 4 on a transform of half the length, frequencies 16i +/- 1
     // and 16i + 8 +/- 1 (dct_pair_common.hpp, ForwardClassLayout)
-    const bool esplit = kind == 5 || kind == 6;
+    // kinds 7 / 8 / 9 (forward, level 2): launches of class E's shape on the bases of kind 5 -- class O rotated once more
+    // (operands (a, b) of AD plus / minus those of the reversed BS: frequencies 16i +/- 5, 16i +/- 3) and R2 rotated (16i +/- 4)
+    const bool esplit = kind >= 5;
+    const bool eshape = kind == 3 || kind == 5 || kind >= 7;       // pairs n/8 + 1 in n/8 slots (fold0), sine basis = its launch variant
     if (esplit && (inverse || sub != 0)) return SSW_ERR_BAD_ARG;
     const bool split = kind == 3 || kind == 4 || esplit;
     if (inverse && sub == 1 && kind != 1 && !has_tmp_out) return SSW_ERR_BAD_ARG;      // the odd part of E needs somewhere to put E
@@ -893,7 +896,7 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
     ca.x1 = d.x1; ca.x2 = d.x2; ca.y1 = d.y1; ca.y2 = d.y2;
     ca.NP = (unsigned)(kind == 0 ? leff / 2 : split ? leff / 8 : leff / 4);      // class E: n/8 + 1 pairs in n/8 slots (fold0)
     ca.Kp = (unsigned)(split ? pair_kpad<double>(leff / 4) : kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
-    ca.yrows = kind == 2 ? 2 * ca.NP : (kind == 3 || kind == 5) ? ca.NP + 1 : ca.NP;      // lines of the basis plane(s): class E's keep row n/8
+    ca.yrows = kind == 2 ? 2 * ca.NP : eshape ? ca.NP + 1 : ca.NP;      // lines of the basis plane(s): class E's keep row n/8
     ca.tiles_n = (ca.NP + 63) / 64;
     ca.c1 = 0; ca.c2 = 1; ca.cs = 2; ca.pm = 0; ca.np1 = 0xFFFFFFFFu; ca.p2lo = 0; ca.bn32 = 0; ca.fold0 = 0;
     ca.gsh = 31; ca.e2off = 0;
@@ -903,9 +906,9 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
     if (split) {
         // odd frequency u = 2k+1 of the (sub-)transform; class E (kind 3) pair i: k = 4i (+), 4i-1 (-); class O: k = 4i+2 (+), 4i+1 (-)
         ca.pm = 1;
-        if (kind == 3 || kind == 5) ca.fold0 = (unsigned)(leff / 8);       // y2 must be the launch variant of the sine basis (row 0 = row n/8)
-        if (kind == 5) { ca.c1 = fs; ca.c2 = 0u - fs; ca.cs = 16 * fs; }
-        else if (kind == 6) { ca.c1 = 9u * fs; ca.c2 = 7u * fs; ca.cs = 16 * fs; }
+        if (eshape) ca.fold0 = (unsigned)(leff / 8);       // y2 must be the launch variant of the sine basis (row 0 = row n/8)
+        if (kind == 6) { ca.c1 = 9u; ca.c2 = 7u; ca.cs = 16; }
+        else if (esplit) { const unsigned r = kind == 5 ? 1u : kind == 7 ? 5u : kind == 8 ? 3u : 4u; ca.c1 = r; ca.c2 = 0u - r; ca.cs = 16; }
         else if (!inverse) {
             ca.c1 = (kind == 3 ? 1u : 5u) * fs; ca.c2 = kind == 3 ? 0u - fs : 3u * fs; ca.cs = 8 * fs;
         } else {
@@ -917,19 +920,22 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
         // dct_pair_common.hpp) instead of 4-byte pieces 16 / 32 bytes apart -- the column pre-pass puts the columns back;
         // inverse: the split classes write (and read E) at one pair of residues mod 4 (po.cm, inverse_class_pos), the
         // quarter-length even half T2 (kind 1) keeps the natural order
-        if (!is_row || !((kind == 1 && sub == 1) || split) || sub > 1) return SSW_ERR_BAD_ARG;
+        if (!is_row || !((kind == 1 && sub >= 1) || split) || sub > 2 || (sub == 2 && kind != 1)) return SSW_ERR_BAD_ARG;
         if (!inverse) {
             // po.ft = the tile: entry e of a class -> column base + (e >> gsh) * ft + (e & (2^gsh - 1)); class E's second
             // output of pair p is entry p - 1 of its "-" class (frequency 8 p - 1)
-            const ForwardClassLayout fl{(unsigned)len, dct_pair_class_tile(len), dct_pair_efold(len)};
-            // class E of the full-length split: folded (kinds 5 / 6) or whole (kind 3) by dct_pair_efold(len), like the pre-pass
-            const bool efold = dct_pair_efold(len);
-            if ((kind == 3 && sub == 0 && efold) || (esplit && !efold)) return SSW_ERR_BAD_ARG;
-            const int k1 = kind == 1 ? ForwardClassLayout::R1 : kind == 3 ? (sub ? ForwardClassLayout::E2P : ForwardClassLayout::EP)
-                         : kind == 5 ? ForwardClassLayout::EEP : kind == 6 ? ForwardClassLayout::EOP : (sub ? ForwardClassLayout::O2P : ForwardClassLayout::OP);
+            // level 2 (dct_pair_efold(len), like the pre-pass): sixteen classes, every launch a sum of len/16 terms
+            const bool l2 = dct_pair_efold(len);
+            const ForwardClassLayout fl{(unsigned)len, dct_pair_class_tile(len), l2};
+            typedef ForwardClassLayout F;
+            int k1 = -1;
+            if (l2) k1 = (kind == 1 && sub == 2) ? F::R1A : (kind == 3 && sub == 1) ? F::F_E2P : (kind == 4 && sub == 1) ? F::F_O2P
+                       : kind == 5 ? F::EEP : kind == 6 ? F::EOP : kind == 7 ? F::O5 : kind == 8 ? F::O3 : kind == 9 ? F::R2A : -1;
+            else k1 = (kind == 1 && sub == 1) ? F::R1 : kind == 3 ? (sub ? F::E2P : F::EP) : kind == 4 ? (sub ? F::O2P : F::OP) : -1;
+            if (k1 < 0) return SSW_ERR_BAD_ARG;
             ca.cs = 1;
             ca.c1 = fl.base(k1); ca.c2 = fl.base(k1 + 1);
-            ca.e2off = (kind == 3 || kind == 5) ? 1u : 0u;
+            ca.e2off = eshape ? 1u : 0u;
             ca.gsh = 31;
             if (fl.t != fl.n) {
                 const unsigned g = fl.group(k1);
@@ -944,7 +950,7 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
         if (kind == 0) inst = {is_row ? EPI_FWD_ADJ : EPI_FWD, false, 0};
         else if (kind == 1) inst = {EPI_FWD, false, sub ? 1 : 0};
         else if (kind == 2) inst = {EPI_FWD, true, sub ? 1 : 0};
-        else inst = {EPI_FWD, false, (is_row && kind == 4 && sub == 0) ? 4 : 3};      // 4: class O of the full-length split, the largest launch of a row pass
+        else inst = {EPI_FWD, false, (is_row && (kind == 7 || (kind == 4 && sub == 0))) ? 4 : 3};      // 4: class O of the full-length split (level 2: its "+" launch), the launch bench.py prices
     } else {
         if (kind == 0) inst = {EPI_INV, false, 0};
         else if (kind == 1) inst = {EPI_INV_E, false, sub ? 1 : 0};
@@ -968,7 +974,7 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
                                    double* tmp, size_t n_frames, size_t w, size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out,
                                    bool class_major) {
     if (n_frames == 0 || n_classes == 0) return SSW_OK;
-    if (n_classes < 0 || n_classes > 6 || !desc) return SSW_ERR_BAD_ARG;
+    if (n_classes < 0 || n_classes > 8 || !desc) return SSW_ERR_BAD_ARG;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t lines = is_row ? n_frames * h : n_frames * w;
     const size_t len = is_row ? w : h;

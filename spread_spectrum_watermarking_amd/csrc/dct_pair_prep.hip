@@ -603,6 +603,7 @@ __global__ __launch_bounds__(256) void pair_prep8_rows_kernel(const void* __rest
 template <typename T, int SRC /*0 plane, 1 rgb f32, 2 rgb u8*/, bool WITH_IQ>
 __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __restrict__ SRCP, DeepPlanes dp,
                                                               const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                              const double* __restrict__ rot3,
                                                               float* __restrict__ IP, float* __restrict__ QP,
                                                               unsigned rows, unsigned W, unsigned K8, unsigned K16, unsigned tiles_e, unsigned efold) {
     const unsigned Nh = W / 2, Nq = W / 4, N8 = W / 8, N16 = W / 16;
@@ -617,8 +618,9 @@ __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __res
     if (e0 >= N16) {                                              // padding of the n/16-wide planes
         put(AS2, e0, zero); put(BD2, e0, zero); put(AD2, e0, zero); put(BS2, e0, zero);
         if (efold) {
-            put(static_cast<T*>(dp.asp), e0, zero); put(static_cast<T*>(dp.asm_), e0, zero);
-            put(static_cast<T*>(dp.bdp), e0, zero); put(static_cast<T*>(dp.bdm), e0, zero);
+            void* const l2[12] = {dp.asp, dp.asm_, dp.bdp, dp.bdm, dp.oap, dp.obp, dp.oam, dp.obm, dp.r1p, dp.r1m, dp.r2a, dp.r2b};
+#pragma unroll
+            for (int a = 0; a < 12; ++a) put(static_cast<T*>(l2[a]), e0, zero);
         }
         return;
     }
@@ -660,11 +662,9 @@ __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __res
     // and a DST-II of length n/8) fold once more with their mirrors -- element e0 + i meets element n/8 - 1 - (e0 + i), which
     // is element 3 - i of the mirror unit: exact additions -- into AS+ AS- BD+ BD- of length n/16 (launches E even / odd)
     {
-        vec4_t<T> as, bd, ad, bs, asm_, bdm_;
+        vec4_t<T> as, bd, ad, bs, asm_, bdm_, adm_, bsm_;
         split_unit<T>(D[0], D[3], D[4], D[7], rot1, e0, Nq, as, bd, ad, bs);
-        put(AD, e0, ad); put(BS, e0, bs);
-        split_unit<T>(D[1], D[2], D[5], D[6], rot1, N8 - 4 - e0, Nq, asm_, bdm_, ad, bs);
-        put(AD, N8 - 4 - e0, ad); put(BS, N8 - 4 - e0, bs);
+        split_unit<T>(D[1], D[2], D[5], D[6], rot1, N8 - 4 - e0, Nq, asm_, bdm_, adm_, bsm_);
         if (efold) {
             vec4_t<T> p, m, q, r;
 #pragma unroll
@@ -674,9 +674,29 @@ __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __res
             }
             put(static_cast<T*>(dp.asp), e0, p); put(static_cast<T*>(dp.asm_), e0, m);
             put(static_cast<T*>(dp.bdp), e0, q); put(static_cast<T*>(dp.bdm), e0, r);
+            // Class O: X[8i+5] = T(i) + U(i), X[8i+3] = T(i) - U(i) with T the DCT-IV of AD and U the DST-IV of BS, length
+            // L = n/8; U(i) = (-1)^i DCT-IV(reversed BS)(i).  One more rotation of the pairs (n, L-1-n), angle pi (2n+1) / (4L)
+            // (the table of a length-n/4 axis), turns a DCT-IV of length L into a DCT-II of a and a DST-II of b, length L/2:
+            //   a = d[n] cos + d[L-1-n] sin,  b = d[L-1-n] cos - d[n] sin;   even outputs A[j] + B[j], odd ones A[j] - B[j].
+            // With (a, b) of AD plus / minus (a, b) of the reversed BS the two signs of (-1)^i sort themselves into two
+            // launches of the class-E shape on the bases of E even: P -> 16j + 5, 16j - 5;  M -> 16j + 3, 16j - 3.
+            const f64x4 c3 = *reinterpret_cast<const f64x4*>(rot3 + e0), s3 = *reinterpret_cast<const f64x4*>(rot3 + N16 + e0);
+            vec4_t<T> oap, obp, oam, obm;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const T cc = (T)c3[i], ss = (T)s3[i];
+                const T au = ad[i] * cc + adm_[3 - i] * ss, bu = adm_[3 - i] * cc - ad[i] * ss;
+                const T av = bsm_[3 - i] * cc + bs[i] * ss, bv = bs[i] * cc - bsm_[3 - i] * ss;
+                oap[i] = au + av; obp[i] = bu + bv;
+                oam[i] = au - av; obm[i] = bu - bv;
+            }
+            put(static_cast<T*>(dp.oap), e0, oap); put(static_cast<T*>(dp.obp), e0, obp);
+            put(static_cast<T*>(dp.oam), e0, oam); put(static_cast<T*>(dp.obm), e0, obm);
         } else {
             put(static_cast<T*>(dp.as), e0, as); put(static_cast<T*>(dp.bd), e0, bd);
             put(static_cast<T*>(dp.as), N8 - 4 - e0, asm_); put(static_cast<T*>(dp.bd), N8 - 4 - e0, bdm_);
+            put(AD, e0, ad); put(BS, e0, bs);
+            put(AD, N8 - 4 - e0, adm_); put(BS, N8 - 4 - e0, bsm_);
         }
     }
     // level 2 on S (length n/2): quad u mirrors quad 7 - u
@@ -695,21 +715,39 @@ __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __res
         put(AS2, e0, as); put(BD2, e0, bd); put(AD2, e0, ad); put(BS2, e0, bs);
     }
     // level 3 on SS (length n/4): quad 0 mirrors quad 3, quad 1 mirrors quad 2
+    vec4_t<T> r1q[2], r2q[2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        vec4_t<T> r1, r2;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            r1[i] = SS[u][i] + SS[3 - u][3 - i];
-            r2[i] = SS[u][i] - SS[3 - u][3 - i];
+            r1q[u][i] = SS[u][i] + SS[3 - u][3 - i];
+            r2q[u][i] = SS[u][i] - SS[3 - u][3 - i];
         }
-        put(R1, pos[u], r1);
-        put(R2, pos[u], r2);
+    if (efold) {
+        // R1 (a DCT-II input of length n/8) folds with its mirror (exact); R2 (a DCT-IV input) rotates like class O above
+        const f64x4 c3 = *reinterpret_cast<const f64x4*>(rot3 + e0), s3 = *reinterpret_cast<const f64x4*>(rot3 + N16 + e0);
+        vec4_t<T> p, m, a, b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            p[i] = r1q[0][i] + r1q[1][3 - i];
+            m[i] = r1q[0][i] - r1q[1][3 - i];
+            const T cc = (T)c3[i], ss = (T)s3[i];
+            a[i] = r2q[0][i] * cc + r2q[1][3 - i] * ss;
+            b[i] = r2q[1][3 - i] * cc - r2q[0][i] * ss;
+        }
+        put(static_cast<T*>(dp.r1p), e0, p); put(static_cast<T*>(dp.r1m), e0, m);
+        put(static_cast<T*>(dp.r2a), e0, a); put(static_cast<T*>(dp.r2b), e0, b);
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        put(R1, pos[u], r1q[u]);
+        put(R2, pos[u], r2q[u]);
     }
     if (e0 == 0)
         for (unsigned z = N8; z < K8; z += 4) {
             put(AD, z, zero); put(BS, z, zero); put(R1, z, zero); put(R2, z, zero);
-            if (!efold) { put(static_cast<T*>(dp.as), z, zero); put(static_cast<T*>(dp.bd), z, zero); }
+            put(static_cast<T*>(dp.as), z, zero); put(static_cast<T*>(dp.bd), z, zero);
         }
 }
 
@@ -1279,10 +1317,13 @@ static size_t deep_min(const char* name, size_t dflt) {           // experiment 
     return e ? (size_t)std::atoll(e) : dflt;
 }
 bool dct_pair_can_deep_rows(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_ROWS", 256); return len % 64 == 0 && len >= mn; }
-// 6 planes K8 wide + 4 K16 wide + (row passes) the 4 folded class-E planes, K16 wide
-size_t dct_pair_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + 8 * dct_pair_split_kpad(len / 2)); }
+// 6 planes K8 wide + 4 K16 wide, or (forward row passes at level 2) 16 planes K16 wide
+size_t dct_pair_deep_elems(size_t lines, size_t len) {
+    const size_t k8 = dct_pair_split_kpad(len), k16 = dct_pair_split_kpad(len / 2);
+    return lines * (6 * k8 + 4 * k16 > 16 * k16 ? 6 * k8 + 4 * k16 : 16 * k16);
+}
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
-                                const double* rot1, const double* rot2, float* ip, float* qp) {
+                                const double* rot1, const double* rot2, const double* rot3, float* ip, float* qp) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull || !dct_pair_can_deep_rows(w)) return SSW_ERR_BAD_DIMS;
     const unsigned K8 = (unsigned)dct_pair_split_kpad(w), K16 = (unsigned)dct_pair_split_kpad(w / 2);
@@ -1293,15 +1334,21 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
     DeepPlanes dp;
     double* p = base;
     const size_t p8 = rows * K8, p16 = rows * K16;
-    dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
-    p += 6 * p8;
-    dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
-    p += 4 * p16;
-    dp.asp = p; dp.asm_ = p + p16; dp.bdp = p + 2 * p16; dp.bdm = p + 3 * p16;
     const unsigned efold = dct_pair_efold(w) ? 1u : 0u;
+    if (efold) {     // level 2: sixteen planes K16 wide, in this order (build_pass and the pruned pass index them by number)
+        void** const l2[16] = {&dp.asp, &dp.asm_, &dp.bdp, &dp.bdm, &dp.oap, &dp.obp, &dp.oam, &dp.obm,
+                               &dp.r1p, &dp.r1m, &dp.r2a, &dp.r2b, &dp.as2, &dp.bd2, &dp.ad2, &dp.bs2};
+        for (int j = 0; j < 16; ++j) *l2[j] = p + (size_t)j * p16;
+        dp.as = dp.bd = dp.ad = dp.bs = dp.r1 = dp.r2 = nullptr;
+        if (!rot3) return SSW_ERR_BAD_ARG;
+    } else {
+        dp.as = p; dp.bd = p + p8; dp.ad = p + 2 * p8; dp.bs = p + 3 * p8; dp.r1 = p + 4 * p8; dp.r2 = p + 5 * p8;
+        p += 6 * p8;
+        dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;
+    }
     const bool iq = ip && qp;
 #define SSW_PREP16(SRCV, IQV) pair_prep16_rows_kernel<double, SRCV, IQV><<<(unsigned)nblk, 256, 0, st>>>( \
-        src, dp, rot1, rot2, ip, qp, (unsigned)rows, (unsigned)w, K8, K16, tiles_e, efold)
+        src, dp, rot1, rot2, rot3, ip, qp, (unsigned)rows, (unsigned)w, K8, K16, tiles_e, efold)
     if (src_kind == 0) SSW_PREP16(0, false);
     else if (src_kind == 1) { if (iq) SSW_PREP16(1, true); else SSW_PREP16(1, false); }
     else if (src_kind == 2) { if (iq) SSW_PREP16(2, true); else SSW_PREP16(2, false); }

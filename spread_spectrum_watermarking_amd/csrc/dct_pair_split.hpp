@@ -42,9 +42,15 @@ struct DeepPlanes {        // device pointers of one pass's operand planes
     void *as, *bd, *ad, *bs;         // K8 wide
     void *r1, *r2;                   // K8 wide
     void *as2, *bd2, *ad2, *bs2;     // K16 wide
-    // forward ROW passes (r4b): class E's operands folded once more, AS +/- its mirror and BD +/- its mirror (K16 wide);
-    // `as` and `bd` are then not written
+    // forward ROW passes at level 2 (r4b, dct_pair_efold): twelve planes K16 wide replace the six K8 wide ones --
+    //   asp asm_ bdp bdm   class E folded once more: AS +/- its mirror, BD +/- its mirror (exact)
+    //   oap obp oam obm    class O (a DCT-IV of AD and a DST-IV of BS, length n/8) rotated once more: (a, b) of AD plus /
+    //                      minus (a, b) of the reversed BS
+    //   r1p r1m            R1 +/- its mirror (exact)
+    //   r2a r2b            R2 (a DCT-IV input of length n/8) rotated: (a, b)
     void *asp = nullptr, *asm_ = nullptr, *bdp = nullptr, *bdm = nullptr;
+    void *oap = nullptr, *obp = nullptr, *oam = nullptr, *obm = nullptr;
+    void *r1p = nullptr, *r1m = nullptr, *r2a = nullptr, *r2b = nullptr;
 };
 
 

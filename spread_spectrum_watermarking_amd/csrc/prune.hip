@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void prune_gather_basis_kernel(const uint32_t*
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,
                        uint32_t* flag, uint32_t* rows, uint32_t* pos, uint32_t* info) {
     SSW_HIP_CHECK(hipMemsetAsync(flag, 0, (size_t)plan.W * sizeof(uint32_t), st));
-    SSW_HIP_CHECK(hipMemsetAsync(info, 0, 8 * sizeof(uint32_t), st));
+    SSW_HIP_CHECK(hipMemsetAsync(info, 0, SSW_PRUNE_INFO * sizeof(uint32_t), st));
     const size_t count = n_frames * k;
     if (count) prune_mark_kernel<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(idx, count, plan.W, flag);
     prune_build_kernel<<<1, 1024, 0, st>>>(flag, plan, rows, pos, info);

@@ -173,7 +173,7 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
                                 const double* rot1, const double* rot2, bool class_major = false);
 size_t dct_pair_deep_elems(size_t lines, size_t len);
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
-                                const double* rot1, const double* rot2, float* ip, float* qp);
+                                const double* rot1, const double* rot2, const double* rot3, float* ip, float* qp);
 int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const float* y, unsigned cap, unsigned Kp, float* out,
                                          unsigned out_stride, unsigned off, size_t lines);
 
@@ -181,15 +181,16 @@ int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const f
 // v is in the class when v % mod == rem, or == rem2 (classes of the split odd half: there the output is the cosine
 // part MINUS the sine part and the gathered sine row is negated); basis row (v + radd) / mod
 constexpr unsigned PRUNE_NO_REM = 0xFFFFFFFFu;
-constexpr uint32_t PRUNE_NEG = 0x40000000u;              // rows[] flag: negate the gathered sine row
+constexpr uint32_t PRUNE_NEG = 0x40000000u;
+constexpr unsigned SSW_PRUNE_INFO = 16;                  // u32 words of a chunk's info block: [0] overflow flag, [1 + c] members of class c              // rows[] flag: negate the gathered sine row
 struct PruneClass { unsigned mod, rem, cap, off, rem2 = PRUNE_NO_REM, radd = 0; };
 struct PrunePlan {
     unsigned n_classes = 0;
-    PruneClass c[7];        // info[] of launch_prune_build holds 1 + 7 words
+    PruneClass c[9];        // info[] of launch_prune_build: SSW_PRUNE_INFO words, 1 + one per class
     unsigned W = 0, cap_total = 0;
 };
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,
-                       uint32_t* flag /*[W]*/, uint32_t* rows /*[cap_total]*/, uint32_t* pos /*[W]*/, uint32_t* info /*[8]*/);
+                       uint32_t* flag /*[W]*/, uint32_t* rows /*[cap_total]*/, uint32_t* pos /*[W]*/, uint32_t* info /*[SSW_PRUNE_INFO]*/);
 int launch_prune_gather_basis(hipStream_t st, const uint32_t* rows, unsigned cap, const void* src, size_t src_rows,
                               size_t kblocks, void* dst, bool negate_flagged_f64 = false);
 int launch_extract_pruned(hipStream_t st, const float* base, const float* compact, size_t n_frames, size_t w, size_t h,

@@ -220,7 +220,7 @@ double pair_gemm_flop(bool is_row, int kind, int sub, size_t n, size_t w, size_t
     const double lines = (double)(is_row ? n * h : n * w);
     const size_t leff = (is_row ? w : h) >> sub;
     if (kind == 3 || kind == 4) return 4.0 * lines * (double)(leff / 8) * (double)(leff / 8);      // class E: n/8 + 1 pairs in n/8 slots
-    if (kind == 5 || kind == 6) return 4.0 * lines * (double)(leff / 16) * (double)(leff / 16);    // class E folded once more: half the length
+    if (kind >= 5) return 4.0 * lines * (double)(leff / 16) * (double)(leff / 16);                  // level 2: sums of len/16 terms, len/16 pairs
     const double np = (double)(kind == 0 ? leff / 2 : leff / 4), k = (double)(kind == 1 ? leff / 4 : leff / 2);
     return 4.0 * lines * np * k;
 }
@@ -283,11 +283,25 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
         // launches (D and SD split, SS folded a third time)
         const bool deep = split && !inverse && (is_row ? dct_pair_can_deep_rows(len) : dct_pair_can_deep_cols(len) && w % 4 == 0);
         if (deep) {
-            const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr;
+            const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr, *rot3 = nullptr, *h0 = nullptr, *h1 = nullptr;
             SSW_TRY(get_basis(ctx, len / 4, false, true, 3, &e0));
             SSW_TRY(get_basis(ctx, len / 4, false, true, 4, &e1));
             for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, false, true, b == 1 ? 10 : 5 + b, &sb2[b]));
             SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
+            // Row passes of 3072 columns or more run at LEVEL 2 (r4b, dct_pair_efold): every operand of the full-length split
+            // and of SS folds or rotates once more in the pre-pass (dct_pair_split.hpp, DeepPlanes), so that all eight
+            // launches are sums of len/16 terms over len/16 pairs -- 2/3 of the level-1 pass's multiply-adds:
+            //   class E (DCT-II of AS, DST-II of BD) folds exactly        -> kinds 5 / 6   16i +/- 1,  16i + 9 | 16i + 7
+            //   class O (DCT-IV of AD, DST-IV of BS) rotates              -> kinds 7 / 8   16i +/- 5,  16i +/- 3
+            //   R2 (DCT-IV) rotates, R1 (DCT-II) folds exactly            -> kind 9, kind 1 sub 2      16i +/- 4,  16i | 16i + 8
+            // Shorter rows (K = len/16 = 120 at 1080p: launches of that sum length run at 51 %) and the column passes stay
+            // at level 1.  The "main" timer brackets ONE launch: kind 7 (level 1: class O of the full-length split).
+            const bool l2 = is_row && dct_pair_efold(len);
+            if (l2) {
+                SSW_TRY(get_basis(ctx, len / 4, false, true, 9, &rot3));
+                SSW_TRY(get_basis(ctx, len / 8, false, true, 3, &h0));
+                SSW_TRY(get_basis(ctx, len / 8, false, true, 4, &h1));
+            }
             const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
             double* q = sp + 6 * p8;
             const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
@@ -300,46 +314,58 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 StageTimer t(ctx, st_prep, st, prep_bytes);
                 if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm);
                 return launch_dct_pair_prep16_rows(st, from_rgb ? pix_src_kind(rgb_u8) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
-                                                   (const double*)rot, (const double*)rot2, from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
+                                                   (const double*)rot, (const double*)rot2, (const double*)rot3,
+                                                   from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
             }});
-            // Row passes (r4b): class E of the full-length split -- a DCT-II of AS and a DST-II of BD, length len/8 -- folds
-            // once more with exact additions (the pre-pass writes AS+ AS- BD+ BD-, length len/16): two launches of half the
-            // sum length and half the pairs each (kinds 5 / 6) instead of one, half of its multiply-adds.  Class O (a
-            // DCT-IV / DST-IV pair: no reflection symmetry) and the column passes (K = len/16 launches run at 51 % there)
-            // stay.  The "main" timer brackets ONE launch: class O of the full-length split (now the largest of the pass).
-            const bool efold = is_row && dct_pair_efold(len);
-            double* ep_ = q + 4 * p16;                                 // AS+ AS- BD+ BD- (launch_dct_pair_prep16_rows)
-            const double f_main = pair_gemm_flop(is_row, 4, 0, n, w, h);
-            const double f_e = efold ? pair_gemm_flop(is_row, 5, 0, n, w, h) + pair_gemm_flop(is_row, 6, 0, n, w, h) : pair_gemm_flop(is_row, 3, 0, n, w, h);
-            const double f_all = f_main + f_e + pair_gemm_flop(is_row, 1, 1, n, w, h) +
-                                 pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             // a single frame's launches are too small alone (class E of a 4K frame: 272 blocks for 512 slots): one launch
-            // over the five classes instead
+            // over all classes instead
             const bool merge = lines <= 8192;             // (merging the batch launches as well: measured, no difference)
+            if (l2) {
+                // the sixteen planes of launch_dct_pair_prep16_rows, K16 wide each, by number
+                auto P = [=](int j) { return (const double*)(sp + (size_t)j * p16); };
+                const double f_main = pair_gemm_flop(is_row, 7, 0, n, w, h), f_all = 8.0 * f_main;
+                const PairClassDesc d[8] = {{1, 2, P(8), P(9), (const double*)h0, (const double*)h1},          // R1+ R1-
+                                            {9, 0, P(10), P(11), (const double*)t0, (const double*)t1},        // R2 rotated
+                                            {3, 1, P(12), P(13), (const double*)t0, (const double*)t1},        // AS2 BD2
+                                            {4, 1, P(14), P(15), (const double*)t2, (const double*)t3},        // AD2 BS2
+                                            {5, 0, P(0), P(3), (const double*)t0, (const double*)t1},          // AS+ BD-
+                                            {6, 0, P(1), P(2), (const double*)t2, (const double*)t3},          // AS- BD+
+                                            {8, 0, P(6), P(7), (const double*)t0, (const double*)t1},          // O rotated, "-"
+                                            {7, 0, P(4), P(5), (const double*)t0, (const double*)t1}};         // O rotated, "+"
+                ch.push_back({false, [=](hipStream_t st) -> int {
+                    StageTimer t(ctx, st_pass, st, f_all);
+                    const bool rcm = cm && is_row;
+                    if (merge) {
+                        StageTimer tm(ctx, st_main, st, f_all);
+                        return launch_dct_pair_gemm_multi_f64(st, is_row, false, 8, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
+                    }
+                    for (int c = 0; c < 7; ++c)
+                        SSW_TRY(pair_gemm(st, true, is_row, false, d[c].kind, d[c].sub, d[c].x1, d[c].x2, d[c].y1, d[c].y2, dst, nullptr, n, w, h, ep,
+                                          nullptr, nullptr, rcm));
+                    StageTimer tm(ctx, st_main, st, f_main);
+                    return pair_gemm(st, true, is_row, false, 7, 0, d[7].x1, d[7].x2, d[7].y1, d[7].y2, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
+                }});
+                return SSW_OK;
+            }
+            const double f_main = pair_gemm_flop(is_row, 4, 0, n, w, h);
+            const double f_all = f_main + pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) +
+                                 pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 const bool rcm = cm && is_row;
                 if (merge) {
-                    // E even / odd: the bases are those of class E' / O' (the quarter-length cosine / sine bases of len/2)
-                    const PairClassDesc d[6] = {{1, 1, sp + 4 * p8, sp + 5 * p8, (const double*)e0, (const double*)e1},
+                    const PairClassDesc d[5] = {{1, 1, sp + 4 * p8, sp + 5 * p8, (const double*)e0, (const double*)e1},
                                                 {3, 1, q, q + p16, (const double*)t0, (const double*)t1},
                                                 {4, 1, q + 2 * p16, q + 3 * p16, (const double*)t2, (const double*)t3},
                                                 {4, 0, sp + 2 * p8, sp + 3 * p8, (const double*)sb2_, (const double*)sb3},
-                                                efold ? PairClassDesc{5, 0, ep_, ep_ + 3 * p16, (const double*)t0, (const double*)t1}
-                                                      : PairClassDesc{3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1},
-                                                {6, 0, ep_ + p16, ep_ + 2 * p16, (const double*)t2, (const double*)t3}};
+                                                {3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1}};
                     StageTimer tm(ctx, st_main, st, f_all);
-                    return launch_dct_pair_gemm_multi_f64(st, is_row, false, efold ? 6 : 5, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
+                    return launch_dct_pair_gemm_multi_f64(st, is_row, false, 5, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
                 }
                 SSW_TRY(pair_gemm(st, true, is_row, false, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
                 SSW_TRY(pair_gemm(st, true, is_row, false, 3, 1, q, q + p16, t0, t1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
                 SSW_TRY(pair_gemm(st, true, is_row, false, 4, 1, q + 2 * p16, q + 3 * p16, t2, t3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
-                if (efold) {
-                    SSW_TRY(pair_gemm(st, true, is_row, false, 5, 0, ep_, ep_ + 3 * p16, t0, t1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
-                    SSW_TRY(pair_gemm(st, true, is_row, false, 6, 0, ep_ + p16, ep_ + 2 * p16, t2, t3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
-                } else {
-                    SSW_TRY(pair_gemm(st, true, is_row, false, 3, 0, sp, sp + p8, sb0, sb1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
-                }
+                SSW_TRY(pair_gemm(st, true, is_row, false, 3, 0, sp, sp + p8, sb0, sb1, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm));
                 StageTimer tm(ctx, st_main, st, f_main);
                 return pair_gemm(st, true, is_row, false, 4, 0, sp + 2 * p8, sp + 3 * p8, sb2_, sb3, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
             }});
@@ -859,13 +885,24 @@ PruneSetup make_prune_setup(const ssw_ctx* ctx, bool f64, size_t n, size_t w, si
         ++nc;
     };
     ps.deep = ps.split && dct_pair_can_deep_rows(w);
+    if (ps.deep && dct_pair_efold(w)) {
+        // level 2 (build_pass): nine classes of sums of w/16 terms; v = 16i +/- r -> row i (= (v + r) / 16) of the bases of
+        // E even, v = 16i + 9 | 16i + 7 -> row i of E odd; the same two for the half-length split; R1 folded: 16i, 16i + 8
+        add(16, 1, c / 8, 15, 1);         // AS+ BD-
+        add(16, 9, c / 8, 7, 0);          // AS- BD+
+        add(16, 5, c / 8, 11, 5);         // O rotated "+"
+        add(16, 3, c / 8, 13, 3);         // O rotated "-"
+        add(16, 2, c / 8, 14, 2);         // AS2 BD2
+        add(16, 10, c / 8, 6, 0);         // AD2 BS2
+        add(16, 4, c / 8, 12, 4);         // R2 rotated
+        add(16, 0, c / 16);               // R1+
+        add(16, 8, c / 16);               // R1-
+        ps.plan.n_classes = nc;
+        ps.on = true;
+        return ps;
+    }
     if (ps.split) {                       // odd v = 8i +/- 1 -> class E row i (= (v + 1) / 8), v = 8i + 5 | 8i + 3 -> class O row i
-        if (ps.deep && dct_pair_efold(w)) {      // class E folded once more (r4b): v = 16i +/- 1 -> row i of E even, v = 16i + 9 | 16i + 7 -> E odd
-            add(16, 1, c / 8, 15, 1);
-            add(16, 9, c / 8, 7, 0);
-        } else {
-            add(8, 1, c / 4, 7, 1);
-        }
+        add(8, 1, c / 4, 7, 1);
         add(8, 5, c / 4, 3, 0);
     } else {
         add(2, 1, c / 2);
@@ -905,12 +942,34 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     uint32_t* rows = pos + w;
     // class -> image operand plane(s), cached basis plane(s), padded / true sum length
     struct ClassSrc { const void* x; const void* basis; size_t src_rows, kp, ktrue; const void* x2 = nullptr; const void* basis2 = nullptr; };
-    ClassSrc cs[7];
+    ClassSrc cs[9];
     unsigned ci = 0;
     const size_t lines = n * h;
-    const void *rot = nullptr, *rot2 = nullptr;
+    const void *rot = nullptr, *rot2 = nullptr, *rot3 = nullptr;
     double* sp = nullptr;
-    if (ps.split) {
+    if (ps.deep && dct_pair_efold(w)) {          // level 2: the plan of make_prune_setup, planes by number like build_pass
+        const void *sb2[4], *h0 = nullptr, *h1 = nullptr;
+        for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w / 2, false, true, 5 + b, &sb2[b]));
+        SSW_TRY(get_basis(ctx, w, false, true, 9, &rot));
+        SSW_TRY(get_basis(ctx, w / 2, false, true, 9, &rot2));
+        SSW_TRY(get_basis(ctx, w / 4, false, true, 9, &rot3));
+        SSW_TRY(get_basis(ctx, w / 8, false, true, 3, &h0));
+        SSW_TRY(get_basis(ctx, w / 8, false, true, 4, &h1));
+        SSW_TRY(grow(ws.operand[5], split_scratch_elems(n, w, h) * sizeof(double)));
+        sp = (double*)ws.operand[5].p;
+        const size_t kp16 = dct_pair_split_kpad(w / 2), p16 = lines * kp16;
+        const size_t re = dct_pair_split_basis_rows(w / 2, 0), ro = dct_pair_split_basis_rows(w / 2, 2);
+        auto P = [=](int j) { return (const void*)(sp + (size_t)j * p16); };
+        cs[ci++] = {P(0), sb2[0], re, kp16, w / 16, P(3), sb2[1]};
+        cs[ci++] = {P(1), sb2[2], ro, kp16, w / 16, P(2), sb2[3]};
+        cs[ci++] = {P(4), sb2[0], re, kp16, w / 16, P(5), sb2[1]};
+        cs[ci++] = {P(6), sb2[0], re, kp16, w / 16, P(7), sb2[1]};
+        cs[ci++] = {P(12), sb2[0], re, kp16, w / 16, P(13), sb2[1]};
+        cs[ci++] = {P(14), sb2[2], ro, kp16, w / 16, P(15), sb2[3]};
+        cs[ci++] = {P(10), sb2[0], re, kp16, w / 16, P(11), sb2[1]};
+        cs[ci++] = {P(8), h0, w / 16, kp16, w / 16};
+        cs[ci++] = {P(9), h1, w / 16, kp16, w / 16};
+    } else if (ps.split) {
         const void* sb[4];
         for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w, false, true, 5 + b, &sb[b]));
         SSW_TRY(get_basis(ctx, w, false, true, 9, &rot));
@@ -921,13 +980,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         const size_t kp16 = dct_pair_split_kpad(w / 2), p16 = lines * kp16;
         double* q = sp + 6 * plane;
         if (ps.deep) for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w / 2, false, true, 5 + b, &sb2[b]));
-        if (ps.deep && dct_pair_efold(w)) {
-            double* ef = q + 4 * p16;                                   // AS+ AS- BD+ BD- (launch_dct_pair_prep16_rows)
-            cs[ci++] = {ef, sb2[0], dct_pair_split_basis_rows(w / 2, 0), kp16, w / 16, ef + 3 * p16, sb2[1]};           // AS+ x cosE', BD- x sinE'
-            cs[ci++] = {ef + p16, sb2[2], dct_pair_split_basis_rows(w / 2, 2), kp16, w / 16, ef + 2 * p16, sb2[3]};     // AS- x cosO', BD+ x sinO'
-        } else {
-            cs[ci++] = {sp, sb[0], dct_pair_split_basis_rows(w, 0), kp8, w / 8, sp + plane, sb[1]};              // AS x cosE, BD x sinE
-        }
+        cs[ci++] = {sp, sb[0], dct_pair_split_basis_rows(w, 0), kp8, w / 8, sp + plane, sb[1]};              // AS x cosE, BD x sinE
         cs[ci++] = {sp + 2 * plane, sb[2], dct_pair_split_basis_rows(w, 2), kp8, w / 8, sp + 3 * plane, sb[3]};  // AD x cosO, BS x sinO
         if (ps.deep) {
             SSW_TRY(get_basis(ctx, w / 2, false, true, 9, &rot2));
@@ -960,7 +1013,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         cs[ci++] = {ws.operand[3].p, q1, w / 4, dct_pair_kpad(f64, w / 2), w / 4};      // SD : 2 mod 4
     }
     if (ci != plan.n_classes) return SSW_ERR_BAD_ARG;
-    size_t goff[7], goff2[7], gtotal = 0;
+    size_t goff[9], goff2[9], gtotal = 0;
     for (unsigned c = 0; c < plan.n_classes; ++c) {
         goff[c] = gtotal; gtotal += cs[c].kp * plan.c[c].cap * esz;
         goff2[c] = gtotal; if (cs[c].x2) gtotal += cs[c].kp * plan.c[c].cap * esz;
@@ -977,7 +1030,8 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     ch.push_back({true, [=](hipStream_t st) -> int {
         SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
         StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, prep_bytes);
-        if (deep) return launch_dct_pair_prep16_rows(st, pix_src_kind(u8), rgb, n, w, h, sp, (const double*)rot, (const double*)rot2, nullptr, nullptr);
+        if (deep) return launch_dct_pair_prep16_rows(st, pix_src_kind(u8), rgb, n, w, h, sp, (const double*)rot, (const double*)rot2,
+                                                     (const double*)rot3, nullptr, nullptr);
         if (levels == 3) SSW_TRY(launch_dct_pair_prep8_rows(st, f64, pix_src_kind(u8), rgb, n, w, h, o2, o3, o0, o1, nullptr, nullptr));
         else SSW_TRY(launch_dct_pair_prep4_rows_rgb(st, f64, u8, rgb, n, w, h, o2, o3, o1, nullptr, nullptr));
         return sp ? launch_dct_pair_rotate(st, (const double*)o1, (const double*)rot, sp, lines, w) : SSW_OK;
@@ -1091,7 +1145,7 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
     const bool allow_prune = capture == hipStreamCaptureStatusNone;
     const PruneSetup ps = !allow_prune ? PruneSetup() : make_prune_setup(ctx, f64, std::min(chunk, n_frames), w, h, k, (const float*)ctx->lane[0].plane[0].p,
                                            (const float*)ctx->lane[0].plane[2].p, dev_derived_rgb, u8);
-    if (ps.on) SSW_TRY(grow(ctx->overflow, n_chunks * 8 * sizeof(uint32_t)));
+    if (ps.on) SSW_TRY(grow(ctx->overflow, n_chunks * SSW_PRUNE_INFO * sizeof(uint32_t)));
     uint32_t* overflow = (uint32_t*)ctx->overflow.p;
 
     // extract + similarity of one chunk from full coefficient planes (the un-pruned path and the redo)
@@ -1131,7 +1185,7 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
             ch.push_back({true, [=](hipStream_t st) -> int { return topk(ctx, st, *sel, yb, n, w, h, c.ordering, k, idx); }});   // :493
         if (!pruned) return full_derived(ws, f0, n, yb, tmp, idx, ch);
         const char* drgb = static_cast<const char*>(dev_derived_rgb) + f0 * plane * px_bytes;
-        SSW_TRY(build_pruned_derived(ctx, ws, c.precision, drgb, u8, n, w, h, k, idx, ps, overflow + ci * 8, ch));
+        SSW_TRY(build_pruned_derived(ctx, ws, c.precision, drgb, u8, n, w, h, k, idx, ps, overflow + ci * SSW_PRUNE_INFO, ch));
         const float* compact = (const float*)ws.compact[1].p;
         const uint32_t* pos = (const uint32_t*)ws.prune_u32.p + w;
         const size_t cap = ps.plan.cap_total;
@@ -1155,13 +1209,13 @@ int batch_extract_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_base
     if (!ps.on) return SSW_OK;
     // Chunks whose column set did not fit the compact plane are redone with the full transform.  This is
     // the one place a batch call waits for the device.
-    std::vector<uint32_t> info(n_chunks * 8);
+    std::vector<uint32_t> info(n_chunks * SSW_PRUNE_INFO);
     SSW_HIP_CHECK(hipMemcpyAsync(info.data(), overflow, info.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (size_t ci = 0; ci < n_chunks; ++ci) {
         ctx->pruned_chunks++;
-        for (unsigned q = 0; q < ps.plan.n_classes; ++q) ctx->pruned_columns += info[ci * 8 + 1 + q];
-        if (info[ci * 8] == 0) continue;
+        for (unsigned q = 0; q < ps.plan.n_classes; ++q) ctx->pruned_columns += info[ci * SSW_PRUNE_INFO + 1 + q];
+        if (info[ci * SSW_PRUNE_INFO] == 0) continue;
         ctx->redone_chunks++;
         Chain ch;
         SSW_TRY(build_chunk(ci, ctx->lane[0], ch, false));
@@ -1187,7 +1241,7 @@ int extract_single_pruned(ssw_ctx* ctx, int precision, const void* derived_rgb, 
     const PruneSetup ps = make_prune_setup(ctx, precision == SSW_PRECISION_F64, 1, w, h, k, (const float*)ws.plane[0].p,
                                            (const float*)ws.plane[2].p, derived_rgb, u8);
     if (!ps.on) return SSW_OK;
-    SSW_TRY(grow(ctx->overflow, 8 * sizeof(uint32_t)));
+    SSW_TRY(grow(ctx->overflow, SSW_PRUNE_INFO * sizeof(uint32_t)));
     uint32_t* info = (uint32_t*)ctx->overflow.p;
     Chain ch;
     SSW_TRY(build_pruned_derived(ctx, ws, precision, derived_rgb, u8, 1, w, h, k, idx, ps, info, ch));

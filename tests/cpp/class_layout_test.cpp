@@ -12,9 +12,11 @@ static int fail(const char* what, unsigned n, unsigned at) { std::printf("FAIL %
 int main() {
     for (unsigned n : {256u, 320u, 1024u, 1920u, 3840u, 7680u})
     for (unsigned t : {n, class_tile(n)})
-    for (bool efold : {false, true}) {
+    for (bool level2 : {false, true}) {
         if (n % t != 0) return fail("tile does not divide the line", n, t);
-        const ForwardClassLayout fl{n, t, efold};
+        if (level2 && n % 16 != 0) continue;
+        typedef ForwardClassLayout F;
+        const F fl{n, t, level2};
         std::vector<int> seen(n, 0);
         for (unsigned p = 0; p < n; ++p) {
             const unsigned u = fl.natural(p);
@@ -22,39 +24,47 @@ int main() {
             if (u / t != p / t) return fail("forward natural() leaves its tile", n, p);
         }
         // the launches' output maps (dct_pair_f64.hip, pair_class_args / fpos1 / fpos2): entry = pair index [- 1 for the
-        // "-" outputs of E], column = base + (entry / group) * tile + entry % group
-        for (unsigned i = 0; i < n / 8; ++i) {
-            if (fl.natural(fl.pos(ForwardClassLayout::R1, i)) != 8 * i) return fail("R1", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::R2, i)) != 8 * i + 4) return fail("R2", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::OP, i)) != 8 * i + 5) return fail("O+", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::OM, i)) != 8 * i + 3) return fail("O-", n, i);
-        }
-        for (unsigned i = 0; i < n / 8 && !efold; ++i) {      // class E whole: pair i -> 8 i +/- 1
-            if (fl.natural(fl.pos(ForwardClassLayout::EP, i)) != 8 * i + 1) return fail("E+", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::EM, (i + 1) - 1)) != 8 * (i + 1) - 1) return fail("E-", n, i);
-        }
-        for (unsigned i = 0; i < n / 16; ++i) {
-            if (fl.natural(fl.pos(ForwardClassLayout::E2P, i)) != 2 * (8 * i + 1)) return fail("E'+", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::E2M, (i + 1) - 1)) != 2 * (8 * (i + 1) - 1)) return fail("E'-", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::O2P, i)) != 2 * (8 * i + 5)) return fail("O'+", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::O2M, i)) != 2 * (8 * i + 3)) return fail("O'-", n, i);
-            // class E folded once more: pair i of the even launch -> 16 i +/- 1 (the "-" output of pair i is entry i - 1),
-            // pair i of the odd launch -> 16 i + 9 and 16 i + 7
-            if (!efold) continue;
-            if (fl.natural(fl.pos(ForwardClassLayout::EEP, i)) != 16 * i + 1) return fail("Ee+", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::EEM, (i + 1) - 1)) != 16 * (i + 1) - 1) return fail("Ee-", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::EOP, i)) != 16 * i + 9) return fail("Eo+", n, i);
-            if (fl.natural(fl.pos(ForwardClassLayout::EOM, i)) != 16 * i + 7) return fail("Eo-", n, i);
+        // "-" outputs of launches of class E's shape], column = base + (entry / group) * tile + entry % group
+        if (!level2) {
+            for (unsigned i = 0; i < n / 8; ++i) {
+                if (fl.natural(fl.pos(F::R1, i)) != 8 * i) return fail("R1", n, i);
+                if (fl.natural(fl.pos(F::R2, i)) != 8 * i + 4) return fail("R2", n, i);
+                if (fl.natural(fl.pos(F::OP, i)) != 8 * i + 5) return fail("O+", n, i);
+                if (fl.natural(fl.pos(F::OM, i)) != 8 * i + 3) return fail("O-", n, i);
+                if (fl.natural(fl.pos(F::EP, i)) != 8 * i + 1) return fail("E+", n, i);
+                if (fl.natural(fl.pos(F::EM, (i + 1) - 1)) != 8 * (i + 1) - 1) return fail("E-", n, i);
+            }
+            for (unsigned i = 0; i < n / 16; ++i) {
+                if (fl.natural(fl.pos(F::E2P, i)) != 2 * (8 * i + 1)) return fail("E'+", n, i);
+                if (fl.natural(fl.pos(F::E2M, (i + 1) - 1)) != 2 * (8 * (i + 1) - 1)) return fail("E'-", n, i);
+                if (fl.natural(fl.pos(F::O2P, i)) != 2 * (8 * i + 5)) return fail("O'+", n, i);
+                if (fl.natural(fl.pos(F::O2M, i)) != 2 * (8 * i + 3)) return fail("O'-", n, i);
+            }
+        } else {
+            // level 2: pair i of a launch of class E's shape with residue r -> 16 i + r and (entry i - 1 of the next class)
+            // 16 i - r; class O's shape (E odd, O'): 16 i + r1 and 16 i + r2; R1 folded: 16 i and 16 i + 8
+            const int eshape[5][2] = {{F::EEP, 1}, {F::O5, 5}, {F::O3, 3}, {F::R2A, 4}, {F::F_E2P, 2}};
+            for (unsigned i = 0; i < n / 16; ++i) {
+                for (auto& e : eshape) {
+                    if (fl.natural(fl.pos(e[0], i)) != 16 * i + e[1]) return fail("level 2, E shape +", n, i);
+                    if (fl.natural(fl.pos(e[0] + 1, (i + 1) - 1)) != 16 * (i + 1) - e[1]) return fail("level 2, E shape -", n, i);
+                }
+                if (fl.natural(fl.pos(F::EOP, i)) != 16 * i + 9) return fail("Eo+", n, i);
+                if (fl.natural(fl.pos(F::EOM, i)) != 16 * i + 7) return fail("Eo-", n, i);
+                if (fl.natural(fl.pos(F::F_O2P, i)) != 16 * i + 10) return fail("O'+", n, i);
+                if (fl.natural(fl.pos(F::F_O2M, i)) != 16 * i + 6) return fail("O'-", n, i);
+                if (fl.natural(fl.pos(F::R1A, i)) != 16 * i) return fail("R1+", n, i);
+                if (fl.natural(fl.pos(F::R1B, i)) != 16 * i + 8) return fail("R1-", n, i);
+            }
         }
         // the shift form of pos() the GEMM epilogue uses when the tile is a power of two
         if (t != n)
-            for (int c = 0; c < ForwardClassLayout::NCLASS; ++c) {
-                if (!fl.has(c)) continue;
+            for (int c = 0; c < fl.classes(); ++c) {
                 const unsigned g = fl.group(c);
                 unsigned gsh = 0;
                 while ((1u << gsh) < g) ++gsh;
                 if ((1u << gsh) != g) return fail("group not a power of two", n, g);
-                for (unsigned e = 0; e < n / ForwardClassLayout::mod(c); ++e)
+                for (unsigned e = 0; e < n / fl.mod(c); ++e)
                     if (fl.base(c) + (e >> gsh) * t + (e & (g - 1)) != fl.pos(c, e)) return fail("shift form of pos()", n, e);
             }
         std::vector<int> seen2(n, 0);
