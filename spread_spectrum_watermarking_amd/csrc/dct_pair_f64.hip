@@ -179,14 +179,15 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     // BM/4 lines x 32 pairs: NI = BM/64) and the tile takes half the MFMAs instead of computing padding.
     auto run = [&](auto nic, auto njc) {
     constexpr int NI = decltype(nic)::value;
-    constexpr int NJ = decltype(njc)::value;                 // pair tiles of 16 per wave: 2, or 1 when the tile holds <= 16 valid pairs
+    constexpr int NJ = decltype(njc)::value;                 // pair tiles of 16 per wave: 2; 1 / 3 (4 x 1 grid) when the tile holds <= 16 / 33 .. 48 valid pairs
+    constexpr int NJA = NJ < 2 ? 2 : NJ;
     constexpr bool FULL = NI == BM / 32;
     const unsigned wm = FULL ? (wave >> 1) * (BM / 2) : wave * (BM / 4), wn = FULL ? (wave & 1) * 32 : 0;
-    f64x4 acc1[NI][2], acc2[NI][2];
+    f64x4 acc1[NI][NJA], acc2[NI][NJA];
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { acc1[i][j] = (f64x4){0, 0, 0, 0}; acc2[i][j] = (f64x4){0, 0, 0, 0}; }
+        for (int j = 0; j < NJA; ++j) { acc1[i][j] = (f64x4){0, 0, 0, 0}; acc2[i][j] = (f64x4){0, 0, 0, 0}; }
 
     // fragment of half-step s: lane group lq supplies k = 4 s + lq
     const unsigned fsw = (li >> 1) & 7;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
         rdx[sh] = (wm + li) * PBK + ((4 * sh + lq) ^ fsw);
         rdy[sh] = (wn + li) * PBK + ((4 * sh + lq) ^ fsw);
     }
-    struct Frag { double x1[NI], x2[NI], y1[2], y2[2]; };
+    struct Frag { double x1[NI], x2[NI], y1[NJA], y2[NJA]; };
     auto fread = [&](auto bufc, auto shc, Frag& f) {
         constexpr int cur = decltype(bufc)::value;
         constexpr int sh = decltype(shc)::value;
@@ -849,10 +850,14 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     };
     // (a tail of at most 16 pairs -- 270 = 4 x 64 + 14 at full HD, the 16-pair classes of the pruned transform -- runs
     // one 16-pair MFMA tile per wave instead of two)
+    // (row passes: a tail of 33 .. 48 pairs -- 240 = 3 x 64 + 48: every launch of a 4K row pass -- runs three per wave on
+    // the 4 x 1 grid: three quarters of a full tile's MFMAs)
     using J1 = std::integral_constant<int, 1>;
     using J2 = std::integral_constant<int, 2>;
+    using J3 = std::integral_constant<int, 3>;
     if (NP - p0 <= 16)                 run(std::integral_constant<int, BM / 64>{}, J1{});
     else if (NP - p0 <= 32 || po.bn32) run(std::integral_constant<int, BM / 64>{}, J2{});
+    else if (!COLS && BM == 128 && NP - p0 <= 48) run(std::integral_constant<int, BM / 64>{}, J3{});
     else                               run(std::integral_constant<int, BM / 32>{}, J2{});
 }
 
