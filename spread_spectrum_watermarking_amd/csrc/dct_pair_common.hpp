@@ -142,15 +142,27 @@ __host__ __device__ inline unsigned class_tile(unsigned n) { return n % 128 == 0
 // inside tiles of t positions (t % 4 == 0, t divides len; t = len: one tile -- the order of the E planes, which only
 // GEMM epilogues exchange):
 //   [ m = 0 mod 4 | m = 3 mod 4 | m = 1 mod 4 | m = 2 mod 4 ], each t/4 long, m / 4 ascending.
-__host__ __device__ inline unsigned inverse_class_pos(unsigned m, unsigned len, unsigned t = 0) {
+// r4c (`l2`: inverse row passes at level 2, dct_pair_efold_inv): the four launches of the odd part produce the positions
+// 8i, 8i-1 | 8i+4, 8i+3 | 8i+2, 8i-3 | 8i+1, 8i-2 and their mirrors -- residues {0, 7}, {4, 3}, {2, 5}, {1, 6} mod 8 (t % 8 == 0):
+//   [ 0 | 7 | 4 | 3 | 2 | 5 | 1 | 6  mod 8 ], each t/8 long, m / 8 ascending
+// (the launches of the half-length odd part, residues {0, 3} and {1, 2} mod 4, write runs of two of these classes).
+__host__ __device__ inline unsigned inverse_class_pos(unsigned m, unsigned len, unsigned t = 0, bool l2 = false) {
     t = t ? t : len;
     const unsigned tb = (m / t) * t, r = m - tb;
+    if (l2) {
+        const unsigned run = (0x17523460u >> (4 * (r & 7u))) & 7u;      // residue -> run: 0 6 4 3 2 5 7 1
+        return tb + run * (t / 8) + (r >> 3);
+    }
     const unsigned c = r & 3u, q = t / 4;
     return tb + (c == 0 ? 0u : c == 3 ? q : c == 1 ? 2 * q : 3 * q) + (r >> 2);
 }
-__host__ __device__ inline unsigned inverse_class_natural(unsigned p, unsigned len, unsigned t = 0) {
+__host__ __device__ inline unsigned inverse_class_natural(unsigned p, unsigned len, unsigned t = 0, bool l2 = false) {
     t = t ? t : len;
     const unsigned tb = (p / t) * t, r = p - tb;
+    if (l2) {
+        const unsigned q = t / 8, run = r / q, i = r - run * q;
+        return tb + 8 * i + ((0x61523470u >> (4 * run)) & 7u);          // run -> residue: 0 7 4 3 2 5 1 6
+    }
     const unsigned q = t / 4, c = r / q, i = r - c * q;
     return tb + 4 * i + (c == 0 ? 0u : c == 1 ? 3u : c == 2 ? 1u : 2u);
 }

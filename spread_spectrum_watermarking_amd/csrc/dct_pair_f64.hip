@@ -365,9 +365,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     // one output line: element idx of the transformed axis lives at lp[idx * es] (and tp[idx * es] in T)
     // element offsets idx * es stay below 2^32 (W * H < 2^32: indices are u32 throughout)
     // position of element m of a line of length len: natural, or class-major on the row pass of a deep inverse transform
-    auto opos = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len) : m; };
+    auto opos = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len, 0, po.cm == 2) : m; };
     // ... of the f32 output line (class-major inside tiles of po.cmt positions; the E planes above: one tile)
-    auto oposf = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len, po.cmt) : m; };
+    auto oposf = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len, po.cmt, po.cm == 2) : m; };
     // forward outputs of a pair: natural c + cs pair, or the class-major column of its entry (PairOutT::ft)
     auto fpos1 = [&](unsigned pair) {
         return po.ft ? po.c1 + (pair >> po.gsh) * po.ft + (pair & ((1u << po.gsh) - 1u)) : po.c1 + po.cs * pair;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     if constexpr (!COLS && (EPI == EPI_FWD || EPI == EPI_INV_O || EPI == EPI_INV_OT)) {
         const unsigned rows_valid = L - m0 < (unsigned)BM ? L - m0 : (unsigned)BM;
         const unsigned long long region = (unsigned long long)rows_valid * W * 4ull;
-        if (region < 0x80000000ull && (EPI == EPI_FWD || (EPI == EPI_INV_O && n == W) || (EPI == EPI_INV_OT && 2 * n == W))) {
+        if (region < 0x80000000ull && (EPI == EPI_FWD || (EPI == EPI_INV_O && n == W) || EPI == EPI_INV_OT)) {
             constexpr unsigned OOB = 0x80000000u;
             const bool plain = ep.first == 1.0f && ep.base == 1.0f;
             const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.out + (size_t)m0 * W), 0, (unsigned)region, 0x00020000);
@@ -454,8 +454,10 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                     }
             } else if constexpr (EPI == EPI_INV_OT) {
                 // T[n1] = T2[n1] + a, T[n-1-n1] = T2[n1] - a as doubles (T lines: n doubles = W * 4 bytes, T2 lines half that)
-                const __amdgpu_buffer_rsrc_t irr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp + (size_t)m0 * (n / 2)), 0, (unsigned)(region / 2), 0x00020000);
-                const __amdgpu_buffer_rsrc_t trr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp_out + (size_t)m0 * n), 0, (unsigned)region, 0x00020000);
+                // (n = W/2: the half-length transform E; n = W/4 at level 2: its even half T2 from the folded quarter)
+                const unsigned tregion = rows_valid * n * 8u;             // <= region: n <= W/2
+                const __amdgpu_buffer_rsrc_t irr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp + (size_t)m0 * (n / 2)), 0, tregion / 2, 0x00020000);
+                const __amdgpu_buffer_rsrc_t trr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp_out + (size_t)m0 * n), 0, tregion, 0x00020000);
                 unsigned vt[NJ][2], vp[NJ][2], vm[NJ][2];
 #pragma unroll
                 for (int jn = 0; jn < NJ; ++jn) {
@@ -884,7 +886,9 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
                     PairClassArgs& ca, PairInstance& inst) {
     const int kind = d.kind, sub = d.sub;
     // inverse: sub = 1 serves the deep inverse (the half-length transform E): kind 1 -> its even half T2, kinds 3 / 4 -> E
-    if (kind < 0 || kind > 9 || sub < 0 || sub > 8 || (sub > 0 && kind == 0) || (sub > 0 && inverse && sub != 1)) return SSW_ERR_BAD_ARG;
+    if (kind < 0 || kind > 9 || sub < 0 || sub > 8 || (sub > 0 && kind == 0)) return SSW_ERR_BAD_ARG;
+    // inverse: sub = 2 (level 2) serves the quarter-length even part T2: kind 1 -> ITS even half, kind 9 -> its odd part + combine
+    if (inverse && sub > 1 && !(sub == 2 && (kind == 1 || kind == 9))) return SSW_ERR_BAD_ARG;
     // kinds 5 / 6 (forward): class E (kind 3) folded once more -- the even / odd rows of its bases, operands AS+ | BD- and
     // AS- | BD+ of half the length: the arithmetic of kinds 3 / 4 on a transform of half the length, frequencies 16i +/- 1
     // and 16i + 8 +/- 1 (dct_pair_common.hpp, ForwardClassLayout)
@@ -892,10 +896,10 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
     // (operands (a, b) of AD plus / minus those of the reversed BS: frequencies 16i +/- 5, 16i +/- 3) and R2 rotated (16i +/- 4)
     const bool esplit = kind >= 5;
     const bool eshape = kind == 3 || kind == 5 || kind >= 7;       // pairs n/8 + 1 in n/8 slots (fold0), sine basis = its launch variant
-    if (esplit && (inverse || sub != 0)) return SSW_ERR_BAD_ARG;
+    if (esplit && sub != ((inverse && kind == 9) ? 2 : 0)) return SSW_ERR_BAD_ARG;
     const bool split = kind == 3 || kind == 4 || esplit;
-    if (inverse && sub == 1 && kind != 1 && !has_tmp_out) return SSW_ERR_BAD_ARG;      // the odd part of E needs somewhere to put E
-    const size_t leff = (len >> sub) >> (esplit ? 1 : 0);     // length of the (sub-)transform this class serves
+    if (inverse && sub >= 1 && kind != 1 && !has_tmp_out) return SSW_ERR_BAD_ARG;      // the odd part of E needs somewhere to put E
+    const size_t leff = esplit ? len / 2 : (len >> sub);      // length of the (sub-)transform this class serves (level 2: of its bases)
     const unsigned fs = 1u << sub;                            // its frequencies in units of the full transform's
     if (split && leff % 8 != 0) return SSW_ERR_BAD_ARG;
     ca.x1 = d.x1; ca.x2 = d.x2; ca.y1 = d.y1; ca.y2 = d.y2;
@@ -912,7 +916,13 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
         // odd frequency u = 2k+1 of the (sub-)transform; class E (kind 3) pair i: k = 4i (+), 4i-1 (-); class O: k = 4i+2 (+), 4i+1 (-)
         ca.pm = 1;
         if (eshape) ca.fold0 = (unsigned)(leff / 8);       // y2 must be the launch variant of the sine basis (row 0 = row n/8)
-        if (kind == 6) { ca.c1 = 9u; ca.c2 = 7u; ca.cs = 16; }
+        if (esplit && inverse) {
+            // positions of the odd part: frequency u = 2 k + 1 of the forward map below -> k; kind 9: of the quarter-length
+            // even part's odd half, 2 j and 2 j - 1
+            const unsigned p1[5] = {0u, 4u, 2u, 1u, 0u}, p2v[5] = {0u - 1u, 3u, 0u - 3u, 0u - 2u, 0u - 1u};
+            ca.c1 = p1[kind - 5]; ca.c2 = p2v[kind - 5]; ca.cs = kind == 9 ? 2 : 8;
+        }
+        else if (kind == 6) { ca.c1 = 9u; ca.c2 = 7u; ca.cs = 16; }
         else if (esplit) { const unsigned r = kind == 5 ? 1u : kind == 7 ? 5u : kind == 8 ? 3u : 4u; ca.c1 = r; ca.c2 = 0u - r; ca.cs = 16; }
         else if (!inverse) {
             ca.c1 = (kind == 3 ? 1u : 5u) * fs; ca.c2 = kind == 3 ? 0u - fs : 3u * fs; ca.cs = 8 * fs;
@@ -960,7 +970,7 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
         if (kind == 0) inst = {EPI_INV, false, 0};
         else if (kind == 1) inst = {EPI_INV_E, false, sub ? 1 : 0};
         else if (with_sink) inst = {EPI_INV_O_RGB, !split, 0};
-        else if (sub == 1) inst = {EPI_INV_OT, !split, 1};          // kinds 2 (semi-deep: one shared operand), 3, 4
+        else if (sub >= 1) inst = {EPI_INV_OT, !split, 1};          // kinds 2 (semi-deep: one shared operand), 3, 4; 9 (level 2)
         else inst = {EPI_INV_O, !split, 0};
     }
     return SSW_OK;
@@ -1018,7 +1028,7 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     ml.n_classes = (unsigned)n_classes; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)(inverse ? leff0 : len), 0, 1, 2};
     po.tmp_out = tmp_out;
-    if (class_major && inverse && (desc[0].kind == 3 || desc[0].kind == 4)) { po.cm = 1; po.cmt = dct_pair_class_tile(len); }
+    if (class_major && inverse && desc[0].kind >= 3 && desc[0].kind <= 8) { po.cm = dct_pair_efold_inv(len) ? 2u : 1u; po.cmt = dct_pair_class_tile(len); }
     if (class_major && !inverse) po.ft = dct_pair_class_tile(len);
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16)) && (!tmp_out || al(tmp_out, 16))) ? 1u : 0u;

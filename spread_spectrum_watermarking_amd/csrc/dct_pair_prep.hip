@@ -94,6 +94,13 @@ bool dct_pair_efold(size_t len) {
     static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_MIN"); return e ? (size_t)std::atoll(e) : (size_t)3072; }();
     return dct_pair_can_deep_rows(len) && len >= mn;
 }
+// Inverse row passes of 3072 columns or more (a multiple of 256) run at level 2 as well (r4c): the odd part's classes and the
+// quarter-length even part fold / rotate once more (dct_pair_prep_staged.hip, prep16_inv_rows_l2_kernel).
+// SSW_EFOLD_INV_MIN: A/B switch (minimum length).
+bool dct_pair_efold_inv(size_t len) {
+    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_INV_MIN"); return e ? (size_t)std::atoll(e) : (size_t)3072; }();
+    return dct_pair_can_deep_inv_rows(len) && dct_pair_prep_staged_rows_ok() && len % 256 == 0 && len >= mn;
+}
 unsigned dct_pair_class_tile(size_t len) {
     static const int one_tile = [] { const char* e = std::getenv("SSW_CLASS_TILE"); return (e && std::atoi(e) == 0) ? 1 : 0; }();
     return one_tile ? (unsigned)len : class_tile((unsigned)len);
@@ -1077,7 +1084,7 @@ __global__ __launch_bounds__(256) void pair_prep16_inv_cols_kernel(const float* 
     // class-major input: lane cl takes NATURAL column c0 + cl, i.e. memory column inverse_class_pos(c0 + cl) -- the loads
     // of a row are four 32-byte runs (one per residue class) and the stores below stay runs of consecutive operand lines
     const unsigned coln = c0 + cl < W ? c0 + cl : W - 1;
-    const unsigned col = class_major ? inverse_class_pos(coln, W, ctile) : coln;
+    const unsigned col = class_major ? inverse_class_pos(coln, W, ctile, class_major == 2) : coln;      // 2: the level-2 order
     auto ld = [&](unsigned r) { return (T)Pz[(size_t)r * W + col]; };
     T* P8[6] = {static_cast<T*>(dp.as), static_cast<T*>(dp.bd), static_cast<T*>(dp.ad), static_cast<T*>(dp.bs), static_cast<T*>(dp.r1), static_cast<T*>(dp.r2)};
     T* P16[4] = {static_cast<T*>(dp.as2), static_cast<T*>(dp.bd2), static_cast<T*>(dp.ad2), static_cast<T*>(dp.bs2)};
@@ -1404,11 +1411,13 @@ static DeepPlanes deep_planes(double* base, size_t lines, size_t len) {
     return dp;
 }
 int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                    const double* rot1, const double* rot2) {
+                                    const double* rot1, const double* rot2, const double* rot3) {
     if (n_frames == 0) return SSW_OK;
     if (!dct_pair_can_deep_inv_rows(w) || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     const size_t rows = n_frames * h;
     if (rows > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if (dct_pair_efold_inv(w))
+        return launch_prep16_inv_rows_l2(st, in, rows, w, base, rot1, rot2, rot3, (unsigned)dct_pair_split_kpad(w / 2));
     if (dct_pair_prep_staged_rows_ok())
         return launch_prep16_inv_rows_staged(st, in, rows, w, base, rot1, rot2, (unsigned)dct_pair_split_kpad(w), (unsigned)dct_pair_split_kpad(w / 2));
     unsigned tp = 1;
@@ -1430,7 +1439,7 @@ int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_fr
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
     const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the c[4q+2] plane
     if (dct_pair_prep_staged_cols_ok(w, class_major))
-        return launch_prep16_inv_cols_staged(st, in, n_frames, w, h, base, rot1, rot2, class_major, semi, K8, K16);
+        return launch_prep16_inv_cols_staged(st, in, n_frames, w, h, base, rot1, rot2, class_major, semi, K8, K16, class_major && dct_pair_efold_inv(w));
     // groups of 8 units: K16 / 8 covers the padding of the n/16-wide planes; semi: the units (and the R planes' padding up to K8)
     const unsigned groups = semi ? (unsigned)((K8 / 2 + 7) / 8) : K16 / 8, tiles_c = (unsigned)((w + 31) / 32);
     const unsigned long long nblk = (unsigned long long)groups * tiles_c * n_frames;
@@ -1443,7 +1452,7 @@ int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_fr
     p += 6 * p8;
     dp.as2 = p; dp.bd2 = p + p16; dp.ad2 = p + 2 * p16; dp.bs2 = p + 3 * p16;      // semi: as2 = the c[4q+2] plane, the others unused
     if (semi) pair_prep16_inv_cols_kernel<double, false><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, 0u, (unsigned)w);
-    else      pair_prep16_inv_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, class_major ? 1u : 0u, dct_pair_class_tile(w));
+    else      pair_prep16_inv_cols_kernel<double, true><<<(unsigned)nblk, 256, 0, st>>>(in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, groups, tiles_c, class_major ? (dct_pair_efold_inv(w) ? 2u : 1u) : 0u, dct_pair_class_tile(w));
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

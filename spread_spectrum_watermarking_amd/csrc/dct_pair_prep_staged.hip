@@ -33,9 +33,9 @@ __device__ inline unsigned slab_sw(unsigned l) {
 }
 // operand line (inside the tile) of memory column m of the tile
 template <int MODE>
-__device__ inline unsigned tile_line(unsigned m, bool efold = true) {
-    if (MODE == 1) return ForwardClassLayout{CT, CT, efold}.natural(m);
-    if (MODE == 2) return inverse_class_natural(m, CT, CT);
+__device__ inline unsigned tile_line(unsigned m, bool level2) {
+    if (MODE == 1) return ForwardClassLayout{CT, CT, level2}.natural(m);
+    if (MODE == 2) return inverse_class_natural(m, CT, CT, level2);
     return m;
 }
 // memory quad (4 columns) of lane l32 of a half-wave.  Forward tile: the quads of the classes with odd lines (EP EM OP
@@ -287,7 +287,8 @@ template <int MODE, bool SPLIT_MID>
 __global__ __launch_bounds__(256) void prep16_inv_cols_staged_kernel(const float* __restrict__ IN, DeepPlanes dp,
                                                                      const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                                      unsigned W, unsigned H, unsigned K8, unsigned K16,
-                                                                     unsigned n_frames, unsigned tasks0, unsigned tasks1, unsigned tiles_c, unsigned nwork) {
+                                                                     unsigned n_frames, unsigned tasks0, unsigned tasks1, unsigned tiles_c, unsigned nwork,
+                                                                     unsigned l2) {
     __shared__ __attribute__((aligned(16))) double lds[3 * SLABD];
     const unsigned id = xcd_contiguous_id(blockIdx.x, nwork);
     const unsigned tasks = tasks0 + tasks1;
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void prep16_inv_cols_staged_kernel(const float
     unsigned off[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const unsigned l = tile_line<MODE>(4 * mq + i);
+        const unsigned l = tile_line<MODE>(4 * mq + i, l2 != 0);
         off[i] = l * 8 + (u ^ slab_sw<MODE>(l));
     }
     unsigned c = col0 + 4 * mq;
@@ -532,6 +533,188 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_staged_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Inverse row pass at LEVEL 2 (r4c; n % 256 == 0, dct_pair_efold_inv): the operands of launches that all sum n/16 terms
+// (build_pass, "deep inverse").  Sixteen planes K16 wide, numbered like the forward level-2 pass:
+//   0 .. 3   AS+ AS- BD+ BD-      class E of the odd part c[2k+1] folded once more (exact)
+//   4 .. 7   (a, b) of AD plus / minus (a, b) of the reversed BS: class O rotated once more
+//   8, 9     c[16 s], c[16 s + 8]                     the quarter-length even part, folded once more
+//   10, 11   (a, b) of R2 = c[8 q + 4] rotated
+//   12 .. 15 AS2 BD2 AD2 BS2                          the half-length odd part c[4 q + 2], as at level 1
+// The folds and rotations pair unit e of AS / BD / AD / BS with unit n/8 - 1 - e, i.e. k-block tau with k-block
+// NT - 1 - tau (NT = n/64): a block takes 32 lines x (4 neighbouring tau from the low half + their 4 partners); thread =
+// (line, slot t), slots t and 7 - t are partners.  Rounds 1 / 2 stage AS BD (AD BS) of the eight tau in LDS slabs, the
+// store sweep combines slab t with slab 7 - t and writes whole 64-byte pieces of four planes; round 3 as at level 1;
+// round 4: R2 rotates and c[16 s], c[16 s + 8] gather inside a thread (regions 0 <-> 3 and 1 <-> 2 are mirrors).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep16_inv_rows_l2_kernel(const float* __restrict__ X, double* __restrict__ base,
+                                                                 const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                                 const double* __restrict__ rot3,
+                                                                 unsigned rows, unsigned W, unsigned K16, unsigned tblocks) {
+    __shared__ __attribute__((aligned(16))) double lds[RNS * RSL];
+    __shared__ double* s_plane[RNS];
+    __shared__ unsigned s_piece[RNS], s_mask[RNS];
+    const unsigned tid = threadIdx.x, t = tid & 7u, lr = tid >> 3;
+    const unsigned tb = blockIdx.x % tblocks, lb = blockIdx.x / tblocks;
+    const unsigned NT = W / 64, NTh = NT / 2;                       // region sets per line; NT % 4 == 0
+    const unsigned tl = t < 4 ? t : 7u - t;                          // the pair's low slot
+    const unsigned tlow = 4 * tb + tl;
+    const bool grp = t >= 4;                                         // partner side
+    const size_t row_base = (size_t)lb * RL;
+    const unsigned nl = rows - row_base < RL ? (unsigned)(rows - row_base) : RL;
+    const unsigned nt = NTh - 4 * tb < 4 ? NTh - 4 * tb : 4u;       // valid low slots (even)
+    const bool tok = tl < nt, ok = tok && lr < nl;
+    const unsigned tg = tok ? (grp ? NT - 1 - tlow : tlow) : 0;
+    const unsigned R = 16 * tg;
+    const unsigned Nh = W / 2, Nq = W / 4, N8 = W / 8, N16 = W / 16;
+    auto plane = [&](unsigned a) { return base + (size_t)a * rows * K16; };
+    const unsigned g[4] = {R, Nh - 16 - R, Nh + R, W - 16 - R};
+    f32x4 c[4][4];
+    if (ok) {
+        const float* xr = X + (row_base + lr) * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[j][q] = *reinterpret_cast<const f32x4*>(xr + g[j] + 4 * q);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[j][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    auto odd = [&](int j, int half) { return (f64x4){(double)c[j][2 * half][1], (double)c[j][2 * half][3], (double)c[j][2 * half + 1][1], (double)c[j][2 * half + 1][3]}; };
+    auto mid = [&](int j) { return (f64x4){(double)c[j][0][2], (double)c[j][1][2], (double)c[j][2][2], (double)c[j][3][2]}; };
+    auto put4 = [&](unsigned slab, unsigned at, const f64x4& v) {
+        *reinterpret_cast<f64x2*>(lds + slab * RSL + lr * 8 + at) = (f64x2){v[0], v[1]};
+        *reinterpret_cast<f64x2*>(lds + slab * RSL + lr * 8 + at + 2) = (f64x2){v[2], v[3]};
+    };
+    auto flush = [&](unsigned nslabs) {
+        __syncthreads();
+        rows_store(lds, nslabs, s_plane, s_piece, s_mask, rows, row_base, nl, tid);
+        __syncthreads();
+    };
+    // 16-byte chunk ch of piece `piece` of plane a, line l of the block
+    auto out2 = [&](unsigned a, unsigned piece, unsigned l, unsigned ch, f64x2 v) {
+        *reinterpret_cast<f64x2*>(plane(a) + ((size_t)piece * rows + row_base + l) * 8 + 2 * ch) = v;
+    };
+    // ---- rounds 1, 2: unit e = 8 tau + i of slot tl with its mirror n/8 - 1 - e = unit 7 - i of the partner slot
+    {
+        f64x4 as[2], bd[2], ad[2], bs[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            split_unit<double>(odd(0, half), odd(1, 1 - half), odd(2, half), odd(3, 1 - half), rot1, R / 2 + 4 * half, Nq, as[half], bd[half], ad[half], bs[half]);
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                put4(t, 4 * half, rnd ? ad[half] : as[half]);
+                put4(8 + t, 4 * half, rnd ? bs[half] : bd[half]);
+            }
+            __syncthreads();
+            // work item = (low slot, line, chunk): 4 x 32 x 4, two per thread; a chunk = units 2 ch, 2 ch + 1
+            for (unsigned w = tid; w < 512; w += 256) {
+                const unsigned ch = w & 3u, l = (w >> 2) & 31u, sl = w >> 7;
+                if (l >= nl || sl >= nt) continue;
+                const unsigned piece = 4 * tb + sl;
+                const double* pa = lds + sl * RSL + l * 8, *pb = lds + (7 - sl) * RSL + l * 8;
+                const f64x2 a0 = *reinterpret_cast<const f64x2*>(pa + 2 * ch), m0 = *reinterpret_cast<const f64x2*>(pb + 6 - 2 * ch);
+                const f64x2 a1 = *reinterpret_cast<const f64x2*>(pa + 8 * RSL + 2 * ch), m1 = *reinterpret_cast<const f64x2*>(pb + 8 * RSL + 6 - 2 * ch);
+                if (rnd == 0) {          // AS +/- its mirror, BD +/- its mirror
+                    out2(0, piece, l, ch, (f64x2){a0[0] + m0[1], a0[1] + m0[0]});
+                    out2(1, piece, l, ch, (f64x2){a0[0] - m0[1], a0[1] - m0[0]});
+                    out2(2, piece, l, ch, (f64x2){a1[0] + m1[1], a1[1] + m1[0]});
+                    out2(3, piece, l, ch, (f64x2){a1[0] - m1[1], a1[1] - m1[0]});
+                } else {                 // the rotation of pair_prep16_rows_kernel's class O: a0 = AD, a1 = BS
+                    const unsigned e = 8 * piece + 2 * ch;
+                    const f64x2 cc = *reinterpret_cast<const f64x2*>(rot3 + e), ss = *reinterpret_cast<const f64x2*>(rot3 + N16 + e);
+                    f64x2 oap, obp, oam, obm;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const double ad_ = a0[i], adm = m0[1 - i], bs_ = a1[i], bsm = m1[1 - i];
+                        const double au = ad_ * cc[i] + adm * ss[i], bu = adm * cc[i] - ad_ * ss[i];
+                        const double av = bsm * cc[i] + bs_ * ss[i], bv = bs_ * cc[i] - bsm * ss[i];
+                        oap[i] = au + av; obp[i] = bu + bv;
+                        oam[i] = au - av; obm[i] = bu - bv;
+                    }
+                    out2(4, piece, l, ch, oap); out2(5, piece, l, ch, obp);
+                    out2(6, piece, l, ch, oam); out2(7, piece, l, ch, obm);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    auto slot_ok = [&](unsigned tt) { return (tt < 4 ? tt : 7u - tt) < nt; };
+    // ---- round 3: AS2 BD2 AD2 BS2 at the units 4 tau .. 4 tau + 3: half tau & 1 of piece tau / 2; slots 2 pi, 2 pi + 1 share
+    // the block's piece pi: 2 tb + pi (low side), (NT - 4 - 4 tb) / 2 + pi - 2 (partner side)
+    {
+        if (tid < 16) {
+            const unsigned pi = tid & 3u, pp = tid >> 2;
+            s_plane[tid] = plane(12 + pp);
+            s_piece[tid] = pi < 2 ? 2 * tb + pi : (NT - 4 - 4 * tb) / 2 + (pi - 2);
+            s_mask[tid] = (slot_ok(2 * pi) ? 0x3u : 0u) | (slot_ok(2 * pi + 1) ? 0xCu : 0u);
+        }
+        f64x4 as, bd, ad, bs;
+        split_unit<double>(mid(0), mid(1), mid(2), mid(3), rot2, R / 4, N8, as, bd, ad, bs);
+        const unsigned at = 4 * (t & 1u), sl = t >> 1;
+        put4(sl, at, as); put4(4 + sl, at, bd); put4(8 + sl, at, ad); put4(12 + sl, at, bs);
+        flush(16);
+    }
+    // ---- round 4.  R2 = c[8 q + 4]: region 0 holds q = 2 tau, 2 tau + 1 and region 3 their mirrors n/8 - 1 - q; region 1
+    // holds q = n/16 - 2 - 2 tau, + 1 and region 2 their mirrors: (a, b)[q] = (r c + rm s, rm c - r s), table of n/4.
+    // c[16 s], c[16 s + 8]: region j holds s = g[j] / 16.  Slabs: 0 .. 3 a, 4 .. 7 b (pair A / B x low / partner side: whole
+    // pieces), 8 .. 15 c[16 s], 16 .. 23 c[16 s + 8] (region x side: four doubles = half a piece each).
+    {
+        auto n_of = [&](unsigned pr, unsigned tau) { return pr ? N16 - 2 - 2 * tau : 2 * tau; };
+        auto s_of = [&](unsigned j, unsigned tau) { return j == 0 ? tau : j == 1 ? 2 * NT - 1 - tau : j == 2 ? 2 * NT + tau : 4 * NT - 1 - tau; };
+        auto tau_of = [&](unsigned side, unsigned sl) { return side ? NT - 1 - (4 * tb + sl) : 4 * tb + sl; };
+        if (tid < 24) {
+            unsigned pl, first, m = 0;
+            if (tid < 8) {
+                const unsigned pr = (tid & 3u) >> 1, side = tid & 1u;
+                pl = 10 + (tid >> 2);
+                first = n_of(pr, tau_of(side, 0)) >> 3;
+                for (unsigned sl = 0; sl < nt; ++sl) m |= 1u << ((n_of(pr, tau_of(side, sl)) & 7u) >> 1);
+            } else {
+                const unsigned u = tid - 8, j = (u & 7u) >> 1, side = u & 1u;
+                pl = 8 + (u >> 3);
+                first = s_of(j, tau_of(side, 0)) >> 3;
+                for (unsigned sl = 0; sl < nt; ++sl) m |= 1u << ((s_of(j, tau_of(side, sl)) & 7u) >> 1);
+            }
+            s_plane[tid] = plane(pl);
+            s_piece[tid] = first;
+            s_mask[tid] = m;
+        }
+        if (tok) {
+            const unsigned side = grp ? 1u : 0u;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const unsigned n0 = n_of(pr, tg);
+                const int jr = pr ? 1 : 0, jm = pr ? 2 : 3;
+                const double r0 = (double)c[jr][1][0], r1 = (double)c[jr][3][0];        // R2[n0], R2[n0 + 1]
+                const double m0 = (double)c[jm][3][0], m1 = (double)c[jm][1][0];        // their mirrors
+                const f64x2 cc = *reinterpret_cast<const f64x2*>(rot3 + n0), ss = *reinterpret_cast<const f64x2*>(rot3 + N16 + n0);
+                const unsigned sl = 2 * pr + side;
+                *reinterpret_cast<f64x2*>(lds + sl * RSL + lr * 8 + (n0 & 7u)) = (f64x2){r0 * cc[0] + m0 * ss[0], r1 * cc[1] + m1 * ss[1]};
+                *reinterpret_cast<f64x2*>(lds + (4 + sl) * RSL + lr * 8 + (n0 & 7u)) = (f64x2){m0 * cc[0] - r0 * ss[0], m1 * cc[1] - r1 * ss[1]};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned sv = s_of(j, tg);
+                lds[(8 + 2 * j + side) * RSL + lr * 8 + (sv & 7u)] = (double)c[j][0][0];
+                lds[(16 + 2 * j + side) * RSL + lr * 8 + (sv & 7u)] = (double)c[j][2][0];
+            }
+        }
+        flush(24);
+    }
+    if (tb == 0) {                                                  // zero padding [n/16, K16): whole pieces
+        const unsigned l = tid >> 3, ch = tid & 7u;
+        if (l < nl)
+            for (unsigned k = N16 + ch; k < K16; k += 8)
+#pragma unroll
+                for (int a = 0; a < 16; ++a) plane(a)[((size_t)(k >> 3) * rows + row_base + l) * 8 + (k & 7u)] = 0.0;
+    }
+}
+
 bool staged_enabled() {
     static const int on = [] { const char* e = std::getenv("SSW_PREP_STAGED"); return e ? std::atoi(e) : 1; }();
     return on != 0;
@@ -573,16 +756,27 @@ int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, 
 }
 
 int launch_prep16_inv_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                  const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16) {
+                                  const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16, bool l2) {
     const unsigned tasks0 = K8 / 8, tasks1 = semi ? (K16 / 8 + 2) / 3 : K16 / 8, tiles_c = (unsigned)((w + CT - 1) / CT);
     const unsigned long long nwork = (unsigned long long)(tasks0 + tasks1) * tiles_c * n_frames;
     if (nwork > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     const DeepPlanes dp = planes_of(base, n_frames * w, K8, K16);
 #define SSW_L(MODEV, SPLITV) prep16_inv_cols_staged_kernel<MODEV, SPLITV><<<(unsigned)nwork, 256, 0, st>>>( \
-        in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tasks0, tasks1, tiles_c, (unsigned)nwork)
+        in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tasks0, tasks1, tiles_c, (unsigned)nwork, l2 ? 1u : 0u)
     if (class_major) { if (semi) SSW_L(2, false); else SSW_L(2, true); }
     else             { if (semi) SSW_L(0, false); else SSW_L(0, true); }
 #undef SSW_L
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+int launch_prep16_inv_rows_l2(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
+                               const double* rot1, const double* rot2, const double* rot3, unsigned K16) {
+    if (w % 256 != 0 || !rot3) return SSW_ERR_BAD_ARG;
+    const unsigned NT = (unsigned)(w / 64), tblocks = (NT / 2 + 3) / 4;
+    const unsigned long long nblk = (unsigned long long)((rows + RL - 1) / RL) * tblocks;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    prep16_inv_rows_l2_kernel<<<(unsigned)nblk, 256, 0, st>>>(in, base, rot1, rot2, rot3, (unsigned)rows, (unsigned)w, K16, tblocks);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

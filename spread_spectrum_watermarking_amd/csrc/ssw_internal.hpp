@@ -142,14 +142,17 @@ int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1,
 bool dct_pair_can_split(size_t len, bool is_row);
 size_t dct_pair_split_kpad(size_t len);
 unsigned dct_pair_class_tile(size_t len);               // tile width of the class-major plane orders (dct_pair_common.hpp)
-bool dct_pair_efold(size_t len);                        // forward row passes of this length fold class E once more (r4b)
+bool dct_pair_efold(size_t len);                        // forward row passes of this length run at level 2 (r4b)
+bool dct_pair_efold_inv(size_t len);                    // inverse row passes of this length run at level 2 (r4c)
 // LDS-staged forms of the deep pre-passes (dct_pair_prep_staged.hip; SSW_PREP_STAGED=0 keeps the r3 kernels)
 bool dct_pair_prep_staged_cols_ok(size_t w, bool class_major);
 bool dct_pair_prep_staged_rows_ok();
 int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                               const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16, bool efold);
 int launch_prep16_inv_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                  const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16);
+                                  const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16, bool l2);
+int launch_prep16_inv_rows_l2(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
+                              const double* rot1, const double* rot2, const double* rot3, unsigned K16);
 int launch_prep16_inv_rows_staged(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
                                   const double* rot1, const double* rot2, unsigned K8, unsigned K16);
 size_t dct_pair_split_elems(size_t n_frames, size_t w, size_t h);
@@ -166,7 +169,7 @@ bool dct_pair_can_semi_deep_cols(size_t len);            // H % 8 == 0, not % 16
 size_t dct_pair_semi_deep_elems(size_t lines, size_t len);
 // deep inverse pre-passes (coefficient plane -> the same ten planes; R1 = c[8q], R2 = c[8q+4])
 int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                    const double* rot1, const double* rot2);
+                                    const double* rot1, const double* rot2, const double* rot3 = nullptr);
 int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                     const double* rot1, const double* rot2, bool class_major = false);
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,

@@ -463,13 +463,28 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
         // split odd part + T -> the output; one pre-pass for all five launches
         const bool deep_inv = split && inverse && (is_row ? dct_pair_can_deep_inv_rows(len) : dct_pair_can_deep_cols(len) && w % 4 == 0);
         if (deep_inv) {
-            const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr;
+            const void *e0 = nullptr, *e1 = nullptr, *sb2[4], *rot2 = nullptr, *rot3 = nullptr, *h0 = nullptr, *h1 = nullptr;
             SSW_TRY(get_basis(ctx, len / 4, true, true, 3, &e0));
             SSW_TRY(get_basis(ctx, len / 4, true, true, 4, &e1));
             for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, true, true, b == 1 ? 10 : 5 + b, &sb2[b]));
             SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
             SSW_TRY(grow(ws.operand[1], bytes));
             SSW_TRY(grow(ws.operand[4], bytes));
+            // Row passes of 3072 columns or more (a multiple of 256) run at LEVEL 2 (r4c, dct_pair_efold_inv), the transpose of
+            // the forward pass's: every launch sums len/16 coefficients --
+            //   the quarter-length even part T2 = (its even half A1: kind 1 sub 2, folded) +/- (its odd half: R2 rotated, kind 9)
+            //   the half-length odd part (kinds 3 / 4 sub 1) as at level 1:  E = T2 +/- .
+            //   the odd part: class E folded (kinds 5 / 6), class O rotated (kinds 7 / 8):  x = E +/- .
+            // 8/14 of the level-1 pass's multiply-adds.
+            const bool il2 = is_row && dct_pair_efold_inv(len);
+            void* A1 = nullptr;
+            if (il2) {
+                SSW_TRY(get_basis(ctx, len / 4, false, true, 9, &rot3));
+                SSW_TRY(get_basis(ctx, len / 8, true, true, 3, &h0));
+                SSW_TRY(get_basis(ctx, len / 8, true, true, 4, &h1));
+                SSW_TRY(grow(ws.operand[2], bytes));
+                A1 = ws.operand[2].p;             // the eighth-length even part, unrounded
+            }
             void* T2 = ws.operand[1].p;       // quarter-length even half, unrounded
             void* TE = ws.operand[4].p;       // the even half E, unrounded
             const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
@@ -483,7 +498,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
                 if (!is_row) return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm);
-                return launch_dct_pair_prep16_inv_rows(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2);
+                return launch_dct_pair_prep16_inv_rows(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, (const double*)rot3);
             }});
             RgbSink sink;
             if (!first_pass && !is_row && x.rgb_out && x.iq_i && x.iq_q) {
@@ -491,6 +506,33 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 if (fused_rgb) *fused_rgb = true;
             }
             const bool with_sink = sink.rgb != nullptr;
+            if (il2) {
+                auto P = [=](int j) { return (const double*)(sp + (size_t)j * p16); };      // the planes of prep16_inv_rows_l2_kernel
+                const double f_all = 8.0 * pair_gemm_flop(is_row, 7, 0, n, w, h);
+                const PairClassDesc da = {1, 2, P(8), P(9), (const double*)h0, (const double*)h1};             // c[16 s] | c[16 s + 8] -> A1
+                const PairClassDesc db = {9, 2, P(10), P(11), (const double*)t0, (const double*)t1};           // R2 rotated + A1 -> T2
+                const PairClassDesc d1[2] = {{3, 1, P(12), P(13), (const double*)t0, (const double*)t1},       // AS2 BD2 + T2 -> E
+                                             {4, 1, P(14), P(15), (const double*)t2, (const double*)t3}};      // AD2 BS2
+                const PairClassDesc d0[4] = {{5, 0, P(0), P(3), (const double*)t0, (const double*)t1},         // AS+ BD-  + E -> x
+                                             {6, 0, P(1), P(2), (const double*)t2, (const double*)t3},         // AS- BD+
+                                             {7, 0, P(4), P(5), (const double*)t0, (const double*)t1},         // O rotated, "+"
+                                             {8, 0, P(6), P(7), (const double*)t0, (const double*)t1}};        // O rotated, "-"
+                ch.push_back({false, [=](hipStream_t st) -> int {
+                    StageTimer t(ctx, st_pass, st, f_all);
+                    SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &da, dst, (double*)A1, n, w, h, ep));
+                    SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &db, dst, (double*)A1, n, w, h, ep, nullptr, (double*)T2));
+                    if (lines <= 8192) {          // single frames: the classes of each dependent stage in one launch
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d1, dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
+                        return launch_dct_pair_gemm_multi_f64(st, is_row, true, 4, d0, dst, (double*)TE, n, w, h, ep, nullptr, nullptr, rcm);
+                    }
+                    for (int c = 0; c < 2; ++c)
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &d1[c], dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
+                    for (int c = 0; c < 4; ++c)
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &d0[c], dst, (double*)TE, n, w, h, ep, nullptr, nullptr, rcm));
+                    return SSW_OK;
+                }});
+                return SSW_OK;
+            }
             const double f_all = pair_gemm_flop(is_row, 3, 0, n, w, h) + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) +
                                  pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {

@@ -5,6 +5,7 @@ r3 pre-passes by shape) and of the batch pipelines (pruned + two lanes against f
 hand-picked shapes of test_gpu_parity.py.  Reference: src/dct2d.rs:83-219 (the transform the oracle restates),
 src/algorithm.rs:295-316, :355-379, :529-593 (the batch flows).  Everything goes through the C ABI; the oracle checks."""
 import os
+import subprocess
 import sys
 
 import pytest
@@ -35,3 +36,14 @@ def test_random_shapes_through_the_batch_pipelines(case):
     r = fuzz_batch.check(*case)
     assert r["same"], "pruned + two lanes differs from full transforms + one lane"
     assert fuzz_batch.passes(r), r
+
+
+def test_level2_row_passes_on_small_shapes():
+    """Rows of 3072 columns or more take the level-2 row passes (csrc/ssw_pipeline.hip build_pass; 4K and 8K frames in
+    test_gpu_parity.py / test_pipeline_gpu.py run them at full size, where only size-independent properties and committed
+    vectors can check).  Here the thresholds are lowered in a child process (they are read once per process) so that
+    small shapes the oracle transforms in seconds take the same kernels: tools/level2_check.py."""
+    env = dict(os.environ, SSW_EFOLD_MIN="256", SSW_EFOLD_INV_MIN="256")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "level2_check.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "level-2 checks: all good" in r.stdout

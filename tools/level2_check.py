@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""The level-2 row passes (forward: dct_pair_efold, inverse: dct_pair_efold_inv -- by default rows of 3072 columns or more)
+on SMALL shapes the oracle finishes in seconds: run with SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 so that every row of a
+multiple of 64 (forward) / 256 (inverse) columns takes them; tests/test_fuzz_gpu.py does, in a child process (the
+switches are read once per process).  Transforms against the oracle's correctly rounded one, and two batch pipelines
+(pruned + two lanes against full + one lane, both against the oracle).
+usage: SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 python tools/level2_check.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import fuzz_batch  # noqa: E402
+import fuzz_dct  # noqa: E402
+
+# (h, w, frames): class-major tiles behind deep columns (h % 16 == 0), natural order behind others, one and several
+# tiles of region sets per block of the inverse pre-pass (w / 64 = 4 .. 32), ragged last blocks (w = 768, 1280: w / 128 % 4 != 0)
+SHAPES = [(128, 256, 1), (128, 512, 2), (256, 768, 1), (136, 1024, 3), (480, 1280, 2), (512, 1536, 1), (100, 2048, 2),
+          (1080, 256, 1), (64, 3840, 2), (272, 320, 2)]
+BATCH = [(256, 512, 3, 150, 11, 21), (144, 1024, 2, 200, 12, 22)]      # (h, w, frames, k, frame seed, mark seed)
+
+if __name__ == "__main__":
+    bad = 0
+    for (h, w, n) in SHAPES:
+        for name in ("fwd", "ortho", "inv"):
+            same, err = fuzz_dct.check(h, w, n, 1234 + h + w, name)
+            ok = same >= fuzz_dct.BAR_IDENTICAL and err <= fuzz_dct.BAR_ERR
+            bad += not ok
+            print(f"{h:5d} x {w:5d} n={n} {name:5s} identical {same:.6f} err/ACmax {err:.2e}{'' if ok else '   <-- FAIL'}", flush=True)
+    for case in BATCH:
+        r = fuzz_batch.check(*case)
+        ok = r["same"] and fuzz_batch.passes(r)
+        bad += not ok
+        print(f"batch {case}: {r}{'' if ok else '   <-- FAIL'}", flush=True)
+    print("level-2 checks:", "FAILED" if bad else "all good")
+    sys.exit(1 if bad else 0)
