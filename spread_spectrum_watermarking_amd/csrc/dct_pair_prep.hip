@@ -101,6 +101,12 @@ bool dct_pair_efold_inv(size_t len) {
     static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_INV_MIN"); return e ? (size_t)std::atoll(e) : (size_t)3072; }();
     return dct_pair_can_deep_inv_rows(len) && dct_pair_prep_staged_rows_ok() && len % 256 == 0 && len >= mn;
 }
+// Column passes of 2048 rows or more run at level 2 in both directions (r4c; the staged pre-passes only): launches of
+// K = H/16 = 135 at 4K run at 50 TFLOP/s against 64 for K = 270, but do half the multiply-adds.  SSW_EFOLD_COLS_MIN: A/B switch.
+bool dct_pair_efold_cols(size_t h, size_t w, bool class_major) {
+    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_COLS_MIN"); return e ? (size_t)std::atoll(e) : (size_t)2048; }();
+    return dct_pair_can_deep_cols(h) && dct_pair_prep_staged_cols_ok(w, class_major) && h >= mn;
+}
 unsigned dct_pair_class_tile(size_t len) {
     static const int one_tile = [] { const char* e = std::getenv("SSW_CLASS_TILE"); return (e && std::atoi(e) == 0) ? 1 : 0; }();
     return one_tile ? (unsigned)len : class_tile((unsigned)len);
@@ -1371,13 +1377,15 @@ bool dct_pair_can_deep_cols(size_t len) { static const size_t mn = deep_min("SSW
 bool dct_pair_can_semi_deep_cols(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_COLS", 256); return len % 8 == 0 && len % 16 != 0 && len >= mn; }
 size_t dct_pair_semi_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + pair_kpad<double>(len / 2)); }
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                const double* rot1, const double* rot2, bool class_major) {
+                                const double* rot1, const double* rot2, bool class_major, const double* rot3) {
     if (n_frames == 0) return SSW_OK;
     const bool semi = dct_pair_can_semi_deep_cols(h);
     if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !(dct_pair_can_deep_cols(h) || semi) || w % 4 != 0) return SSW_ERR_BAD_DIMS;
     if (semi && class_major) return SSW_ERR_BAD_ARG;
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
     const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the SD plane
+    if (dct_pair_efold_cols(h, w, class_major))
+        return launch_prep16_cols_l2(st, in, n_frames, w, h, base, rot1, rot2, rot3, class_major, class_major && dct_pair_efold(w), K16);
     if (dct_pair_prep_staged_cols_ok(w, class_major))
         return launch_prep16_cols_staged(st, in, n_frames, w, h, base, rot1, rot2, class_major, semi, K8, K16, dct_pair_efold(w));
     const unsigned units = semi ? (unsigned)(((h / 8 + 1) / 2 + 3) & ~(size_t)3) : K16;
@@ -1431,13 +1439,15 @@ int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_fr
     return SSW_OK;
 }
 int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                    const double* rot1, const double* rot2, bool class_major) {
+                                    const double* rot1, const double* rot2, bool class_major, const double* rot3) {
     if (n_frames == 0) return SSW_OK;
     const bool semi = dct_pair_can_semi_deep_cols(h);
     if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !(dct_pair_can_deep_cols(h) || semi)) return SSW_ERR_BAD_DIMS;
     if (semi && class_major) return SSW_ERR_BAD_ARG;
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
     const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the c[4q+2] plane
+    if (dct_pair_efold_cols(h, w, class_major))
+        return launch_prep16_inv_cols_l2(st, in, n_frames, w, h, base, rot1, rot2, rot3, class_major, class_major && dct_pair_efold_inv(w), K16);
     if (dct_pair_prep_staged_cols_ok(w, class_major))
         return launch_prep16_inv_cols_staged(st, in, n_frames, w, h, base, rot1, rot2, class_major, semi, K8, K16, class_major && dct_pair_efold_inv(w));
     // groups of 8 units: K16 / 8 covers the padding of the n/16-wide planes; semi: the units (and the R planes' padding up to K8)

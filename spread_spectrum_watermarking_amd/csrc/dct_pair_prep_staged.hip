@@ -274,6 +274,114 @@ __global__ __launch_bounds__(256) void prep16_cols_staged_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward column pass at LEVEL 2 (r4c; H % 16 == 0, dct_pair_efold_cols): the thread of unit e holds the 16 rows of unit e
+// AND of its mirror unit H/8 - 1 - e, so the extra fold / rotation of pair_prep16_rows_kernel's level 2 happens in
+// registers and the mirrored round B disappears.  Sixteen planes K16 wide, numbered like the row pass's:
+//   round A (exact)     0 .. 3 AS+ AS- BD+ BD-,  8 9 R1+ R1-
+//   round B (rotated)   4 .. 7 (a, b) of AD plus / minus (a, b) of the reversed BS,  10 11 (a, b) of R2     [table of H/4]
+//   round C             12 .. 15 AS2 BD2 AD2 BS2
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void prep16_cols_l2_kernel(const float* __restrict__ IN, double* __restrict__ base,
+                                                             const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                             const double* __restrict__ rot3,
+                                                             unsigned W, unsigned H, unsigned K16,
+                                                             unsigned n_frames, unsigned groups, unsigned tiles_c, unsigned nwork, unsigned in_l2) {
+    __shared__ __attribute__((aligned(16))) double lds[6 * SLABD];
+    const unsigned id = xcd_contiguous_id(blockIdx.x, nwork);
+    const unsigned g = id % groups, zt = id / groups, ct = zt % tiles_c, z = zt / tiles_c;
+    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, HU = H / 16;
+    const unsigned tid = threadIdx.x, u = tid >> 5;
+    const unsigned mq = lane_quad<MODE>(tid & 31u);
+    const unsigned col0 = ct * CT;
+    const unsigned nl = W - col0 < CT ? W - col0 : CT;
+    unsigned off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned l = tile_line<MODE>(4 * mq + i, in_l2 != 0);
+        off[i] = l * 8 + (u ^ slab_sw<MODE>(l));
+    }
+    const unsigned e = 8 * g + u;
+    const bool unit_ok = e < HU;
+    const unsigned ec = unit_ok ? e : 0;
+    f32x4 x[16];
+    const Rot4 ra = rot_load(rot1, ec, Hq), rb = rot_load(rot1, H8 - 1 - ec, Hq), rc = rot_load(rot2, ec, H8);
+    const double c3 = rot3[ec], s3 = rot3[HU + ec];
+    {
+        unsigned c = col0 + 4 * mq;
+        c = c + 4 <= W ? c : W - 4;
+        const float* __restrict__ Pz = IN + (size_t)z * H * W + c;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) x[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (unit_ok) {
+            const unsigned rp[8] = {e, H8 - 1 - e, H8 + e, Hq - 1 - e, Hq + e, 3 * H8 - 1 - e, 3 * H8 + e, Hh - 1 - e};
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                x[v] = *reinterpret_cast<const f32x4*>(Pz + (size_t)rp[v] * W);
+                x[15 - v] = *reinterpret_cast<const f32x4*>(Pz + (size_t)(H - 1 - rp[v]) * W);
+            }
+        }
+    }
+    auto plane = [&](unsigned a) { return base + (size_t)a * n_frames * W * K16; };
+    const size_t lines = (size_t)n_frames * W, line_base = (size_t)z * W + col0;
+    // entries of the group inside the planes (zeros between H/16 and K16 come from the units beyond the axis)
+    const unsigned mk = 8 * g + 8 <= K16 ? 0xFFu : (8 * g >= K16 ? 0u : (1u << (K16 - 8 * g)) - 1u);
+    // ---- rounds A, B
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double D[8], S[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                S[v] = (double)x[v][i] + (double)x[15 - v][i];
+                D[v] = (double)x[v][i] - (double)x[15 - v][i];
+            }
+            double as, bd, ad, bs, asm_, bdm, adm, bsm;
+            split_one_r(D[0], D[3], D[4], D[7], ra, as, bd, ad, bs);            // unit e
+            split_one_r(D[1], D[2], D[5], D[6], rb, asm_, bdm, adm, bsm);       // unit H/8 - 1 - e
+            const double ss0 = S[0] + S[7], ss3 = S[3] + S[4], ss1 = S[1] + S[6], ss2 = S[2] + S[5];
+            const double r1 = ss0 + ss3, r2 = ss0 - ss3, r1m = ss1 + ss2, r2m = ss1 - ss2;
+            double o[6];
+            if (rnd == 0) {
+                o[0] = as + asm_; o[1] = as - asm_; o[2] = bd + bdm; o[3] = bd - bdm; o[4] = r1 + r1m; o[5] = r1 - r1m;
+            } else {
+                const double au = ad * c3 + adm * s3, bu = adm * c3 - ad * s3;
+                const double av = bsm * c3 + bs * s3, bv = bs * c3 - bsm * s3;
+                o[0] = au + av; o[1] = bu + bv; o[2] = au - av; o[3] = bu - bv;
+                o[4] = r2 * c3 + r2m * s3; o[5] = r2m * c3 - r2 * s3;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) lds[a * SLABD + off[i]] = unit_ok ? o[a] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+            slab_store<MODE>(lds + a * SLABD, plane(a < 4 ? 4 * rnd + a : 8 + 2 * rnd + (a - 4)), lines, line_base, nl, 8 * g, mk, tid);
+        __syncthreads();
+    }
+    // ---- round C: the level-2 difference SD
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double S[8], SD[4];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) S[v] = (double)x[v][i] + (double)x[15 - v][i];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) SD[v] = S[v] - S[7 - v];
+        double o[4] = {0, 0, 0, 0};
+        split_one_r(SD[0], SD[1], SD[2], SD[3], rc, o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) lds[a * SLABD + off[i]] = unit_ok ? o[a] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 4; ++a) slab_store<MODE>(lds + a * SLABD, plane(12 + a), lines, line_base, nl, 8 * g, mk, tid);
+    if (g == 0)
+#pragma unroll
+        for (int a = 0; a < 16; ++a) zero_range(plane(a), lines, line_base, nl, 8 * groups, K16, tid);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Inverse column pass.  Every operand element of the inverse depends on its own four (or one) coefficient rows only:
 //   AS BD AD BS at unit k < H/8:    rows 2k+1, H/2-1-2k, H/2+2k+1, H-1-2k        (rotation table of H, half length H/4)
 //   R1[k] = row 8k, R2[k] = row 8k+4
@@ -375,6 +483,98 @@ __global__ __launch_bounds__(256) void prep16_inv_cols_staged_kernel(const float
 #pragma unroll
         for (int s = 0; s < 3; ++s)
             if (8 * (kb0 + s) < K16) slab_store<MODE>(lds + s * SLABD, P16[0], lines, line_base, nl, 8 * (kb0 + s), 0xFFu, tid);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Inverse column pass at LEVEL 2 (r4c; dct_pair_efold_cols): unit k < H/16 with its mirror unit H/8 - 1 - k in one thread.
+//   task < tasks0 (k-blocks of H/16 units): rows 2k+1, H/2-1-2k, H/2+2k+1, H-1-2k of unit k and of unit H/8-1-k -> planes
+//       0 .. 7; rows 16k, 16k+8 -> planes 8, 9; rows 8k+4, H-4-8k (R2 at k and at its mirror) -> planes 10, 11
+//   then tasks1 k-blocks of AS2 BD2 AD2 BS2 (planes 12 .. 15) as at level 1.  Four rounds of three slabs.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void prep16_inv_cols_l2_kernel(const float* __restrict__ IN, double* __restrict__ base,
+                                                                 const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                                 const double* __restrict__ rot3,
+                                                                 unsigned W, unsigned H, unsigned K16,
+                                                                 unsigned n_frames, unsigned tasks0, unsigned tasks1, unsigned tiles_c, unsigned nwork,
+                                                                 unsigned in_l2) {
+    __shared__ __attribute__((aligned(16))) double lds[3 * SLABD];
+    const unsigned id = xcd_contiguous_id(blockIdx.x, nwork);
+    const unsigned tasks = tasks0 + tasks1;
+    const unsigned task = id % tasks, zt = id / tasks, ct = zt % tiles_c, z = zt / tiles_c;
+    const unsigned Hh = H / 2, Hq = H / 4, H8 = H / 8, H16 = H / 16;
+    const unsigned tid = threadIdx.x, u = tid >> 5;
+    const unsigned mq = lane_quad<MODE>(tid & 31u);
+    const unsigned col0 = ct * CT;
+    const unsigned nl = W - col0 < CT ? W - col0 : CT;
+    unsigned off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned l = tile_line<MODE>(4 * mq + i, in_l2 != 0);
+        off[i] = l * 8 + (u ^ slab_sw<MODE>(l));
+    }
+    unsigned c = col0 + 4 * mq;
+    c = c + 4 <= W ? c : W - 4;
+    const float* __restrict__ Pz = IN + (size_t)z * H * W + c;
+    auto ld = [&](unsigned r) { return *reinterpret_cast<const f32x4*>(Pz + (size_t)r * W); };
+    auto plane = [&](unsigned a) { return base + (size_t)a * n_frames * W * K16; };
+    const size_t lines = (size_t)n_frames * W, line_base = (size_t)z * W + col0;
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if (task < tasks0) {
+        const unsigned k = 8 * task + u;
+        const bool ok = k < H16;
+        const unsigned kc = ok ? k : 0, km = H8 - 1 - kc;
+        const f32x4 d0 = ok ? ld(2 * kc + 1) : z4, d1 = ok ? ld(Hh - 1 - 2 * kc) : z4, d2 = ok ? ld(Hh + 2 * kc + 1) : z4, d3 = ok ? ld(H - 1 - 2 * kc) : z4;
+        const f32x4 m0 = ok ? ld(2 * km + 1) : z4, m1 = ok ? ld(Hh - 1 - 2 * km) : z4, m2 = ok ? ld(Hh + 2 * km + 1) : z4, m3 = ok ? ld(H - 1 - 2 * km) : z4;
+        const f32x4 xa = ok ? ld(16 * kc) : z4, xb = ok ? ld(16 * kc + 8) : z4, r2 = ok ? ld(8 * kc + 4) : z4, r2m = ok ? ld(8 * km + 4) : z4;
+        const Rot4 rr = rot_load(rot1, kc, Hq), rm = rot_load(rot1, km, Hq);
+        const double c3 = rot3[kc], s3 = rot3[H16 + kc];
+        double o[4][12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double as, bd, ad, bs, asm_, bdm, adm, bsm;
+            split_one_r((double)d0[i], (double)d1[i], (double)d2[i], (double)d3[i], rr, as, bd, ad, bs);
+            split_one_r((double)m0[i], (double)m1[i], (double)m2[i], (double)m3[i], rm, asm_, bdm, adm, bsm);
+            o[i][0] = as + asm_; o[i][1] = as - asm_; o[i][2] = bd + bdm; o[i][3] = bd - bdm;
+            const double au = ad * c3 + adm * s3, bu = adm * c3 - ad * s3;
+            const double av = bsm * c3 + bs * s3, bv = bs * c3 - bsm * s3;
+            o[i][4] = au + av; o[i][5] = bu + bv; o[i][6] = au - av; o[i][7] = bu - bv;
+            o[i][8] = (double)xa[i]; o[i][9] = (double)xb[i];
+            const double q = (double)r2[i], qm = (double)r2m[i];
+            o[i][10] = q * c3 + qm * s3; o[i][11] = qm * c3 - q * s3;
+        }
+#pragma unroll
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            if (rnd) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) lds[a * SLABD + off[i]] = ok ? o[i][3 * rnd + a] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 3; ++a) slab_store<MODE>(lds + a * SLABD, plane(3 * rnd + a), lines, line_base, nl, 8 * task, 0xFFu, tid);
+        }
+    } else {
+        const unsigned kb = task - tasks0, e = 8 * kb + u;
+        const bool ok = e < H16;
+        const unsigned ec = ok ? e : 0;
+        const f32x4 q0 = ok ? ld(4 * ec + 2) : z4, q1 = ok ? ld(Hh - 2 - 4 * ec) : z4, q2 = ok ? ld(Hh + 4 * ec + 2) : z4, q3 = ok ? ld(H - 2 - 4 * ec) : z4;
+        const Rot4 rr = rot_load(rot2, ec, H8);
+        double o[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_one_r((double)q0[i], (double)q1[i], (double)q2[i], (double)q3[i], rr, o[i][0], o[i][1], o[i][2], o[i][3]);
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (rnd) __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int a = 0; a < 2; ++a) lds[a * SLABD + off[i]] = ok ? o[i][2 * rnd + a] : 0.0;
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 2; ++a) slab_store<MODE>(lds + a * SLABD, plane(12 + 2 * rnd + a), lines, line_base, nl, 8 * kb, 0xFFu, tid);
+        }
     }
 }
 
@@ -765,6 +965,34 @@ int launch_prep16_inv_cols_staged(hipStream_t st, const float* in, size_t n_fram
         in, dp, rot1, rot2, (unsigned)w, (unsigned)h, K8, K16, (unsigned)n_frames, tasks0, tasks1, tiles_c, (unsigned)nwork, l2 ? 1u : 0u)
     if (class_major) { if (semi) SSW_L(2, false); else SSW_L(2, true); }
     else             { if (semi) SSW_L(0, false); else SSW_L(0, true); }
+#undef SSW_L
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+int launch_prep16_cols_l2(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                          const double* rot1, const double* rot2, const double* rot3, bool class_major, bool in_l2, unsigned K16) {
+    if (h % 16 != 0 || !rot3) return SSW_ERR_BAD_ARG;
+    const unsigned HU = (unsigned)(h / 16), groups = (HU + 7) / 8, tiles_c = (unsigned)((w + CT - 1) / CT);
+    const unsigned long long nwork = (unsigned long long)groups * tiles_c * n_frames;
+    if (nwork > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+#define SSW_L(MODEV) prep16_cols_l2_kernel<MODEV><<<(unsigned)nwork, 256, 0, st>>>( \
+        in, base, rot1, rot2, rot3, (unsigned)w, (unsigned)h, K16, (unsigned)n_frames, groups, tiles_c, (unsigned)nwork, in_l2 ? 1u : 0u)
+    if (class_major) SSW_L(1); else SSW_L(0);
+#undef SSW_L
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+int launch_prep16_inv_cols_l2(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                              const double* rot1, const double* rot2, const double* rot3, bool class_major, bool in_l2, unsigned K16) {
+    if (h % 16 != 0 || !rot3) return SSW_ERR_BAD_ARG;
+    const unsigned tasks0 = K16 / 8, tasks1 = K16 / 8, tiles_c = (unsigned)((w + CT - 1) / CT);
+    const unsigned long long nwork = (unsigned long long)(tasks0 + tasks1) * tiles_c * n_frames;
+    if (nwork > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+#define SSW_L(MODEV) prep16_inv_cols_l2_kernel<MODEV><<<(unsigned)nwork, 256, 0, st>>>( \
+        in, base, rot1, rot2, rot3, (unsigned)w, (unsigned)h, K16, (unsigned)n_frames, tasks0, tasks1, tiles_c, (unsigned)nwork, in_l2 ? 1u : 0u)
+    if (class_major) SSW_L(2); else SSW_L(0);
 #undef SSW_L
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;

@@ -144,6 +144,11 @@ size_t dct_pair_split_kpad(size_t len);
 unsigned dct_pair_class_tile(size_t len);               // tile width of the class-major plane orders (dct_pair_common.hpp)
 bool dct_pair_efold(size_t len);                        // forward row passes of this length run at level 2 (r4b)
 bool dct_pair_efold_inv(size_t len);                    // inverse row passes of this length run at level 2 (r4c)
+bool dct_pair_efold_cols(size_t h, size_t w, bool class_major);      // column passes (both directions) of h rows run at level 2 (r4c)
+int launch_prep16_cols_l2(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                          const double* rot1, const double* rot2, const double* rot3, bool class_major, bool in_l2, unsigned K16);
+int launch_prep16_inv_cols_l2(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
+                              const double* rot1, const double* rot2, const double* rot3, bool class_major, bool in_l2, unsigned K16);
 // LDS-staged forms of the deep pre-passes (dct_pair_prep_staged.hip; SSW_PREP_STAGED=0 keeps the r3 kernels)
 bool dct_pair_prep_staged_cols_ok(size_t w, bool class_major);
 bool dct_pair_prep_staged_rows_ok();
@@ -171,9 +176,9 @@ size_t dct_pair_semi_deep_elems(size_t lines, size_t len);
 int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                     const double* rot1, const double* rot2, const double* rot3 = nullptr);
 int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                    const double* rot1, const double* rot2, bool class_major = false);
+                                    const double* rot1, const double* rot2, bool class_major = false, const double* rot3 = nullptr);
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                const double* rot1, const double* rot2, bool class_major = false);
+                                const double* rot1, const double* rot2, bool class_major = false, const double* rot3 = nullptr);
 size_t dct_pair_deep_elems(size_t lines, size_t len);
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, const double* rot3, float* ip, float* qp);

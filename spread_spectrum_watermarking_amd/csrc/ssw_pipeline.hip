@@ -296,7 +296,13 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             //   R2 (DCT-IV) rotates, R1 (DCT-II) folds exactly            -> kind 9, kind 1 sub 2      16i +/- 4,  16i | 16i + 8
             // Shorter rows (K = len/16 = 120 at 1080p: launches of that sum length run at 51 %) and the column passes stay
             // at level 1.  The "main" timer brackets ONE launch: kind 7 (level 1: class O of the full-length split).
-            const bool l2 = is_row && dct_pair_efold(len);
+            // Column passes of 2048 rows or more do the same (r4c, dct_pair_efold_cols; the pre-pass holds a unit and its
+            // mirror in one thread): K = H/16 = 135 at 4K -- such launches reach 50 TFLOP/s against 64 for K = 270, at half
+            // the multiply-adds.
+            const size_t fh0 = x.full_h ? x.full_h : h;
+            const bool cm0 = !x.natural_order && w >= fh0 && w % 4 == 0 && dct_pair_can_deep_rows(w) && dct_pair_can_deep_cols(fh0) &&
+                             dct_pair_can_fold2_cols(fh0) && (is_row ? first_pass : !first_pass);
+            const bool l2 = is_row ? dct_pair_efold(len) : dct_pair_efold_cols(len, w, cm0);
             if (l2) {
                 SSW_TRY(get_basis(ctx, len / 4, false, true, 9, &rot3));
                 SSW_TRY(get_basis(ctx, len / 8, false, true, 3, &h0));
@@ -312,7 +318,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                             dct_pair_can_fold2_cols(fh) && (is_row ? first_pass : !first_pass);
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
-                if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm);
+                if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm, (const double*)rot3);
                 return launch_dct_pair_prep16_rows(st, from_rgb ? pix_src_kind(rgb_u8) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
                                                    (const double*)rot, (const double*)rot2, (const double*)rot3,
                                                    from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr);
@@ -476,7 +482,10 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             //   the half-length odd part (kinds 3 / 4 sub 1) as at level 1:  E = T2 +/- .
             //   the odd part: class E folded (kinds 5 / 6), class O rotated (kinds 7 / 8):  x = E +/- .
             // 8/14 of the level-1 pass's multiply-adds.
-            const bool il2 = is_row && dct_pair_efold_inv(len);
+            // Column passes of 2048 rows or more likewise (dct_pair_efold_cols).
+            const bool cm0 = !x.natural_order && w >= h && w % 4 == 0 && dct_pair_can_deep_inv_rows(w) && dct_pair_can_deep_cols(h) &&
+                             dct_pair_can_fold2_cols(h) && (is_row ? first_pass : !first_pass);
+            const bool il2 = is_row ? dct_pair_efold_inv(len) : dct_pair_efold_cols(len, w, cm0);
             void* A1 = nullptr;
             if (il2) {
                 SSW_TRY(get_basis(ctx, len / 4, false, true, 9, &rot3));
@@ -497,7 +506,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const bool rcm = cm && is_row;
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
-                if (!is_row) return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm);
+                if (!is_row) return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm, (const double*)rot3);
                 return launch_dct_pair_prep16_inv_rows(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, (const double*)rot3);
             }});
             RgbSink sink;
@@ -523,12 +532,12 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &db, dst, (double*)A1, n, w, h, ep, nullptr, (double*)T2));
                     if (lines <= 8192) {          // single frames: the classes of each dependent stage in one launch
                         SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d1, dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
-                        return launch_dct_pair_gemm_multi_f64(st, is_row, true, 4, d0, dst, (double*)TE, n, w, h, ep, nullptr, nullptr, rcm);
+                        return launch_dct_pair_gemm_multi_f64(st, is_row, true, 4, d0, dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm);
                     }
                     for (int c = 0; c < 2; ++c)
                         SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &d1[c], dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
                     for (int c = 0; c < 4; ++c)
-                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &d0[c], dst, (double*)TE, n, w, h, ep, nullptr, nullptr, rcm));
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &d0[c], dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm));
                     return SSW_OK;
                 }});
                 return SSW_OK;

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """The level-2 row passes (forward: dct_pair_efold, inverse: dct_pair_efold_inv -- by default rows of 3072 columns or more)
-on SMALL shapes the oracle finishes in seconds: run with SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 so that every row of a
-multiple of 64 (forward) / 256 (inverse) columns takes them; tests/test_fuzz_gpu.py does, in a child process (the
-switches are read once per process).  Transforms against the oracle's correctly rounded one, and two batch pipelines
+and column passes (dct_pair_efold_cols: 2048 rows or more) on SMALL shapes the oracle finishes in seconds: run with
+SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 SSW_EFOLD_COLS_MIN=64 so that every row of a multiple of 64 (forward) / 256
+(inverse) columns and every column of a multiple of 16 rows takes them; tests/test_fuzz_gpu.py does, in a child process
+(the switches are read once per process).  Transforms against the oracle's correctly rounded one, and two batch pipelines
 (pruned + two lanes against full + one lane, both against the oracle).
-usage: SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 python tools/level2_check.py"""
+usage: SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 SSW_EFOLD_COLS_MIN=64 python tools/level2_check.py"""
 import os
 import sys
 
@@ -18,7 +19,7 @@ import fuzz_dct  # noqa: E402
 # (h, w, frames): class-major tiles behind deep columns (h % 16 == 0), natural order behind others, one and several
 # tiles of region sets per block of the inverse pre-pass (w / 64 = 4 .. 32), ragged last blocks (w = 768, 1280: w / 128 % 4 != 0)
 SHAPES = [(128, 256, 1), (128, 512, 2), (256, 768, 1), (136, 1024, 3), (480, 1280, 2), (512, 1536, 1), (100, 2048, 2),
-          (1080, 256, 1), (64, 3840, 2), (272, 320, 2)]
+          (1080, 256, 1), (64, 3840, 2), (272, 320, 2), (2160, 512, 1), (1104, 200, 2), (336, 132, 1)]
 BATCH = [(256, 512, 3, 150, 11, 21), (144, 1024, 2, 200, 12, 22)]      # (h, w, frames, k, frame seed, mark seed)
 
 if __name__ == "__main__":
