@@ -140,12 +140,15 @@ def hbm_report(stage, names):
     return out
 
 
-# The launch bench.py's `roofline` block is about: the largest single GEMM launch of a forward transform.
-#   f64 (default): class E of the split odd half of a row pass -- (AS x cosine rows 2i) + (BD x sine rows 2i), W/8 + 1
-#       output pairs in W/8 slots, sums of W/8 terms (csrc/dct_pair_prep.hip "Split odd half"); its own template instance (SUB = 4)
+# The launch `roofline.best_launch` is about: ONE GEMM launch of a forward row pass, under its own template instance.
+#   f64 (default): rows of 3072 columns or more run at level 2 (csrc/ssw_pipeline.hip build_pass): eight launches that all
+#       sum W/16 terms over W/16 output pairs; the timed one is kind 7 -- class O of the split odd half rotated once more,
+#       its "+" launch: (a, b) of AD plus (a, b) of the reversed BS against the cosine / sine rows of the W/2 bases
+#       (csrc/dct_pair_prep.hip pair_prep16_rows_kernel); its own template instance (SUB = 4).  Shorter rows (level 1): class O
+#       of the split odd half itself, W/8 pairs x W/8 terms.
 #   f32: the unsplit odd half (the f32 twin keeps exact-operand folding)
 def main_kernel_label(prec_name):
-    return "pair_gemm_f64_kernel<rows, split odd half, class E>" if prec_name == "f64" else "pair_gemm_f32_kernel<rows, odd half>"
+    return "pair_gemm_f64_kernel<rows, split odd half, class O (level 2: rotated, '+' launch)>" if prec_name == "f64" else "pair_gemm_f32_kernel<rows, odd half>"
 
 
 def main_kernel_instance(prec_name):
@@ -153,9 +156,10 @@ def main_kernel_instance(prec_name):
 
 
 MAIN_KERNEL_NOTE = {
-    "f64": ("executed flop of one launch (two products of lines x W/8 pair slots x W/8 sums: the cosine and the sine part of "
-            "class E of the split odd half -- W/8 + 1 output pairs, the first and the last sharing a slot -- counted by the "
-            "library per launch) / its average duration from a hipEvent pair on the stream it runs on, inside the timed region"),
+    "f64": ("executed flop of one launch (two products of lines x P pair slots x P sums, P = W/16 at level 2 (rows of 3072 "
+            "columns or more), W/8 below: the cosine and the sine part of class O of the split odd half -- at level 2 of its "
+            "rotated '+' launch, P + 1 output pairs, the first and the last sharing a slot -- counted by the library per "
+            "launch) / its average duration from a hipEvent pair on the stream it runs on, inside the timed region"),
     "f32": ("executed flop of one launch (2 * lines * (W/2) outputs * (W/2) sums: the odd-frequency half of the even/odd-"
             "folded basis GEMM, counted by the library per launch) / its average duration from a hipEvent pair on the "
             "stream it runs on, inside the timed region"),
@@ -199,7 +203,7 @@ def family_rooflines(prec_name, stage, steps, W, H, chunk_eff, frames_per_step):
     pre-passes timed as stage rgb_to_yiq and the transposing / inverse ones timed as stage dct_prep), algorithmic bytes /
     summed duration.  Flop and bytes are counted by the library per launch; durations are hipEvent pairs on the stream
     each stage runs on.  `share_of_step` = the family's share of the summed kernel time of all stages (two lanes overlap in
-    wall time).  `best_launch` keeps r3's single-launch block (class E of the split odd half of a forward row pass)."""
+    wall time).  `best_launch` keeps r3's single-launch block (one launch of a forward row pass: main_kernel_label)."""
     peak = PEAK_F64_MFMA_TFLOPS if prec_name == "f64" else PEAK_F32_MFMA_TFLOPS
     all_ms = sum(v["ms"] for k, v in stage.items() if not k.endswith("_main"))
     gemm_ms = stage["dct_row"]["ms"] + stage["dct_col"]["ms"]

@@ -86,7 +86,7 @@ struct PairOutT {
 // stores runs (t/8 = 16 entries = the 16 pairs of one MFMA tile), and a block of the column pre-pass now reads ONE
 // contiguous 512-byte run per row for 128 consecutive operand lines (the one-tile order gave it ten runs of 64 / 32
 // bytes, or -- read by memory column -- stores scattered over lines 8 or 16 apart: 2.8 TB/s).
-// r4b (`level2`: row passes of 3072 columns or more, dct_pair_efold): every launch of the pass works on sums of n/16
+// r4b (`level2`: row passes of 1280 columns or more, dct_pair_efold): every launch of the pass works on sums of n/16
 // terms and owns two residues mod 16 -- sixteen classes of t/16 entries each, in this order:
 //   class      R1A  R1B  R2A  R2B   E2P  E2M  O2P  O2M   EEP  EEM  EOP  EOM   O5  O11  O3  O13
 //   u mod 16   0    8    4    12    2    14   10   6     1    15   9    7     5   11   3   13

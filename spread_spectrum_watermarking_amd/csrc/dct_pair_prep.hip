@@ -87,24 +87,27 @@ __global__ void make_rot_table_kernel(size_t n, double* out) {
 // first-level split through pair_rotate_kernel: any axis whose quarter length folds (rows and columns alike)
 // tile width of the class-major plane orders of a line of length len (dct_pair_common.hpp); SSW_CLASS_TILE=0: one tile
 // (the r3 order)
-// Row passes long enough fold class E of the full-length split once more (launches of K = len/16: 240 at 4K, where such
-// launches run at 71 % of peak against 84 % for K = len/8; at 1080p, K = 120, the same fold LOSES 10 % of the row pass).
-// SSW_EFOLD_MIN: A/B switch (minimum length).
+// Forward row passes of 1280 columns or more run at LEVEL 2 (r4b / r4c; ssw_pipeline.hip build_pass): every operand folds or
+// rotates once more and all eight launches sum len/16 terms (240 at 4K: 79 % of peak against 84 % for len/8, at 2/3 of the
+// multiply-adds).  Measured a gain from 1280 x 720 up (smaller: not measured) -- once the plane between the passes is
+// class-major; in the natural order every launch writes 4-byte pieces 64 bytes apart (1080p before r4c: such launches took
+// 1.0 ms for 16 GFLOP).  SSW_EFOLD_MIN: A/B switch (minimum length).
 bool dct_pair_efold(size_t len) {
-    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_MIN"); return e ? (size_t)std::atoll(e) : (size_t)3072; }();
+    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_MIN"); return e ? (size_t)std::atoll(e) : (size_t)1280; }();
     return dct_pair_can_deep_rows(len) && len >= mn;
 }
-// Inverse row passes of 3072 columns or more (a multiple of 256) run at level 2 as well (r4c): the odd part's classes and the
+// Inverse row passes of 1280 columns or more (a multiple of 256) run at level 2 as well (r4c): the odd part's classes and the
 // quarter-length even part fold / rotate once more (dct_pair_prep_staged.hip, prep16_inv_rows_l2_kernel).
 // SSW_EFOLD_INV_MIN: A/B switch (minimum length).
 bool dct_pair_efold_inv(size_t len) {
-    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_INV_MIN"); return e ? (size_t)std::atoll(e) : (size_t)3072; }();
+    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_INV_MIN"); return e ? (size_t)std::atoll(e) : (size_t)1280; }();
     return dct_pair_can_deep_inv_rows(len) && dct_pair_prep_staged_rows_ok() && len % 256 == 0 && len >= mn;
 }
-// Column passes of 2048 rows or more run at level 2 in both directions (r4c; the staged pre-passes only): launches of
-// K = H/16 = 135 at 4K run at 50 TFLOP/s against 64 for K = 270, but do half the multiply-adds.  SSW_EFOLD_COLS_MIN: A/B switch.
+// Column passes of 720 rows or more (a multiple of 16) run at level 2 in both directions (r4c; the staged pre-passes only):
+// launches of K = H/16 = 135 at 4K run at 50 TFLOP/s against 64 for K = 270, but do half the multiply-adds (measured a gain
+// from 1280 x 720 up).  SSW_EFOLD_COLS_MIN: A/B switch.
 bool dct_pair_efold_cols(size_t h, size_t w, bool class_major) {
-    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_COLS_MIN"); return e ? (size_t)std::atoll(e) : (size_t)2048; }();
+    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_COLS_MIN"); return e ? (size_t)std::atoll(e) : (size_t)720; }();
     return dct_pair_can_deep_cols(h) && dct_pair_prep_staged_cols_ok(w, class_major) && h >= mn;
 }
 unsigned dct_pair_class_tile(size_t len) {
@@ -1381,7 +1384,7 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
     if (n_frames == 0) return SSW_OK;
     const bool semi = dct_pair_can_semi_deep_cols(h);
     if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !(dct_pair_can_deep_cols(h) || semi) || w % 4 != 0) return SSW_ERR_BAD_DIMS;
-    if (semi && class_major) return SSW_ERR_BAD_ARG;
+    if (semi && class_major && !dct_pair_prep_staged_cols_ok(w, true)) return SSW_ERR_BAD_ARG;      // the r3 semi-deep kernels read the natural order only
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
     const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the SD plane
     if (dct_pair_efold_cols(h, w, class_major))
@@ -1443,7 +1446,7 @@ int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_fr
     if (n_frames == 0) return SSW_OK;
     const bool semi = dct_pair_can_semi_deep_cols(h);
     if (w > 0xFFFFFFull || h > 0xFFFFFFull || n_frames > 0xFFFFFFull || !(dct_pair_can_deep_cols(h) || semi)) return SSW_ERR_BAD_DIMS;
-    if (semi && class_major) return SSW_ERR_BAD_ARG;
+    if (semi && class_major && !dct_pair_prep_staged_cols_ok(w, true)) return SSW_ERR_BAD_ARG;      // the r3 semi-deep kernels read the natural order only
     const unsigned K8 = (unsigned)dct_pair_split_kpad(h);
     const unsigned K16 = semi ? (unsigned)pair_kpad<double>(h / 2) : (unsigned)dct_pair_split_kpad(h / 2);      // semi: width of the c[4q+2] plane
     if (dct_pair_efold_cols(h, w, class_major))

@@ -234,6 +234,12 @@ size_t split_scratch_elems(size_t n, size_t w, size_t h) {
     return e;
 }
 
+// Can the column pre-pass of an `fh`-row plane read the class-major order a deep row pass leaves (dct_pair_common.hpp)?  The
+// deep kernels all can; of the semi-deep ones (fh % 16 == 8: 1080 rows) only the LDS-staged forms.
+static bool cols_read_class_major(size_t fh, size_t w) {
+    return dct_pair_can_fold2_cols(fh) && (dct_pair_can_deep_cols(fh) || (dct_pair_can_semi_deep_cols(fh) && dct_pair_prep_staged_cols_ok(w, true)));
+}
+
 // One pass of the separable transform (src -> dst along rows or columns) appended to `ch`.
 int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass, bool is_row, const float* src, float* dst,
                Epilogue ep, Chain& ch, bool* fused_rgb = nullptr) {
@@ -288,20 +294,19 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             SSW_TRY(get_basis(ctx, len / 4, false, true, 4, &e1));
             for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, false, true, b == 1 ? 10 : 5 + b, &sb2[b]));
             SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
-            // Row passes of 3072 columns or more run at LEVEL 2 (r4b, dct_pair_efold): every operand of the full-length split
+            // Row passes of 1280 columns or more run at LEVEL 2 (r4b, dct_pair_efold): every operand of the full-length split
             // and of SS folds or rotates once more in the pre-pass (dct_pair_split.hpp, DeepPlanes), so that all eight
             // launches are sums of len/16 terms over len/16 pairs -- 2/3 of the level-1 pass's multiply-adds:
             //   class E (DCT-II of AS, DST-II of BD) folds exactly        -> kinds 5 / 6   16i +/- 1,  16i + 9 | 16i + 7
             //   class O (DCT-IV of AD, DST-IV of BS) rotates              -> kinds 7 / 8   16i +/- 5,  16i +/- 3
             //   R2 (DCT-IV) rotates, R1 (DCT-II) folds exactly            -> kind 9, kind 1 sub 2      16i +/- 4,  16i | 16i + 8
-            // Shorter rows (K = len/16 = 120 at 1080p: launches of that sum length run at 51 %) and the column passes stay
-            // at level 1.  The "main" timer brackets ONE launch: kind 7 (level 1: class O of the full-length split).
-            // Column passes of 2048 rows or more do the same (r4c, dct_pair_efold_cols; the pre-pass holds a unit and its
+            // Shorter rows stay at level 1.  The "main" timer brackets ONE launch: kind 7 (level 1: class O of the full-length split).
+            // Column passes of 720 rows or more do the same (r4c, dct_pair_efold_cols; the pre-pass holds a unit and its
             // mirror in one thread): K = H/16 = 135 at 4K -- such launches reach 50 TFLOP/s against 64 for K = 270, at half
             // the multiply-adds.
             const size_t fh0 = x.full_h ? x.full_h : h;
-            const bool cm0 = !x.natural_order && w >= fh0 && w % 4 == 0 && dct_pair_can_deep_rows(w) && dct_pair_can_deep_cols(fh0) &&
-                             dct_pair_can_fold2_cols(fh0) && (is_row ? first_pass : !first_pass);
+            const bool cm0 = !x.natural_order && w >= fh0 && w % 4 == 0 && dct_pair_can_deep_rows(w) && cols_read_class_major(fh0, w) &&
+                             (is_row ? first_pass : !first_pass);
             const bool l2 = is_row ? dct_pair_efold(len) : dct_pair_efold_cols(len, w, cm0);
             if (l2) {
                 SSW_TRY(get_basis(ctx, len / 4, false, true, 9, &rot3));
@@ -314,8 +319,8 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const void *t0 = sb2[0], *t1 = sb2[1], *t2 = sb2[2], *t3 = sb2[3];
             // rows first and both passes deep: the row launches write class-major, the column pre-pass reads it back
             const size_t fh = x.full_h ? x.full_h : h;
-            const bool cm = !x.natural_order && w >= fh && w % 4 == 0 && dct_pair_can_deep_rows(w) && dct_pair_can_deep_cols(fh) &&
-                            dct_pair_can_fold2_cols(fh) && (is_row ? first_pass : !first_pass);
+            const bool cm = cm0;
+            (void)fh;
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
                 if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm, (const double*)rot3);
@@ -399,9 +404,12 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const size_t p8 = lines * dct_pair_split_kpad(len);
             double* m = sp + 6 * p8;
             const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
+            // behind a deep row pass the plane arrives class-major (r4c: the staged pre-pass reads it like the deep one)
+            const size_t fh = x.full_h ? x.full_h : h;
+            const bool cm = !x.natural_order && w >= fh && dct_pair_can_deep_rows(w) && cols_read_class_major(fh, w) && !first_pass;
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
-                return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot, false);
+                return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot, cm);
             }});
             const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h);
             const double f_all = f_main + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 2, 1, n, w, h);
@@ -439,9 +447,10 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const size_t p8 = lines * dct_pair_split_kpad(len);
             double* m = sp + 6 * p8;
             const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
+            const bool cm = !x.natural_order && w >= h && dct_pair_can_deep_inv_rows(w) && cols_read_class_major(h, w) && !first_pass;
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
-                return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot, false);
+                return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot, cm);
             }});
             RgbSink sink;
             if (!first_pass && x.rgb_out && x.iq_i && x.iq_q) {
@@ -476,15 +485,15 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
             SSW_TRY(grow(ws.operand[1], bytes));
             SSW_TRY(grow(ws.operand[4], bytes));
-            // Row passes of 3072 columns or more (a multiple of 256) run at LEVEL 2 (r4c, dct_pair_efold_inv), the transpose of
+            // Row passes of 1280 columns or more (a multiple of 256) run at LEVEL 2 (r4c, dct_pair_efold_inv), the transpose of
             // the forward pass's: every launch sums len/16 coefficients --
             //   the quarter-length even part T2 = (its even half A1: kind 1 sub 2, folded) +/- (its odd half: R2 rotated, kind 9)
             //   the half-length odd part (kinds 3 / 4 sub 1) as at level 1:  E = T2 +/- .
             //   the odd part: class E folded (kinds 5 / 6), class O rotated (kinds 7 / 8):  x = E +/- .
             // 8/14 of the level-1 pass's multiply-adds.
-            // Column passes of 2048 rows or more likewise (dct_pair_efold_cols).
-            const bool cm0 = !x.natural_order && w >= h && w % 4 == 0 && dct_pair_can_deep_inv_rows(w) && dct_pair_can_deep_cols(h) &&
-                             dct_pair_can_fold2_cols(h) && (is_row ? first_pass : !first_pass);
+            // Column passes of 720 rows or more likewise (dct_pair_efold_cols).
+            const bool cm0 = !x.natural_order && w >= h && w % 4 == 0 && dct_pair_can_deep_inv_rows(w) && cols_read_class_major(h, w) &&
+                             (is_row ? first_pass : !first_pass);
             const bool il2 = is_row ? dct_pair_efold_inv(len) : dct_pair_efold_cols(len, w, cm0);
             void* A1 = nullptr;
             if (il2) {
@@ -501,8 +510,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
             const void *t0 = sb2[0], *t1 = sb2[1], *t2 = sb2[2], *t3 = sb2[3];
             // rows first and both passes deep: the row pass's split launches write (and exchange E) class-major
-            const bool cm = !x.natural_order && w >= h && w % 4 == 0 && dct_pair_can_deep_inv_rows(w) && dct_pair_can_deep_cols(h) &&
-                            dct_pair_can_fold2_cols(h) && (is_row ? first_pass : !first_pass);
+            const bool cm = cm0;
             const bool rcm = cm && is_row;
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);

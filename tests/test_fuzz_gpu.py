@@ -39,7 +39,7 @@ def test_random_shapes_through_the_batch_pipelines(case):
 
 
 def test_level2_row_passes_on_small_shapes():
-    """Rows of 3072 columns or more (and columns of 2048 rows or more) take the level-2 passes (csrc/ssw_pipeline.hip build_pass; 4K and 8K frames in
+    """Rows of 1280 columns or more (and columns of 720 rows or more) take the level-2 passes (csrc/ssw_pipeline.hip build_pass; 4K and 8K frames in
     test_gpu_parity.py / test_pipeline_gpu.py run them at full size, where only size-independent properties and committed
     vectors can check).  Here the thresholds are lowered in a child process (they are read once per process) so that
     small shapes the oracle transforms in seconds take the same kernels: tools/level2_check.py."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The level-2 row passes (forward: dct_pair_efold, inverse: dct_pair_efold_inv -- by default rows of 3072 columns or more)
-and column passes (dct_pair_efold_cols: 2048 rows or more) on SMALL shapes the oracle finishes in seconds: run with
+"""The level-2 row passes (forward: dct_pair_efold, inverse: dct_pair_efold_inv -- by default rows of 1280 columns or more)
+and column passes (dct_pair_efold_cols: 720 rows or more) on SMALL shapes the oracle finishes in seconds: run with
 SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 SSW_EFOLD_COLS_MIN=64 so that every row of a multiple of 64 (forward) / 256
 (inverse) columns and every column of a multiple of 16 rows takes them; tests/test_fuzz_gpu.py does, in a child process
 (the switches are read once per process).  Transforms against the oracle's correctly rounded one, and two batch pipelines
