@@ -234,6 +234,13 @@ size_t split_scratch_elems(size_t n, size_t w, size_t h) {
     return e;
 }
 
+// Passes of at most this many lines run the classes of a stage as ONE launch (a single frame's launches are too small alone).
+// SSW_MERGE_MAX_LINES: A/B switch.
+static size_t merge_max_lines() {
+    static const size_t v = [] { const char* e = std::getenv("SSW_MERGE_MAX_LINES"); return e ? (size_t)std::atoll(e) : (size_t)8192; }();
+    return v;
+}
+
 // Can the column pre-pass of an `fh`-row plane read the class-major order a deep row pass leaves (dct_pair_common.hpp)?  The
 // deep kernels all can; of the semi-deep ones (fh % 16 == 8: 1080 rows) only the LDS-staged forms.
 static bool cols_read_class_major(size_t fh, size_t w) {
@@ -330,7 +337,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             }});
             // a single frame's launches are too small alone (class E of a 4K frame: 272 blocks for 512 slots): one launch
             // over all classes instead
-            const bool merge = lines <= 8192;             // (merging the batch launches as well: measured, no difference)
+            const bool merge = lines <= merge_max_lines();             // (merging the batch launches as well: measured, no difference)
             if (l2) {
                 // the sixteen planes of launch_dct_pair_prep16_rows, K16 wide each, by number
                 auto P = [=](int j) { return (const double*)(sp + (size_t)j * p16); };
@@ -413,7 +420,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             }});
             const double f_main = pair_gemm_flop(is_row, 3, 0, n, w, h);
             const double f_all = f_main + pair_gemm_flop(is_row, 4, 0, n, w, h) + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 2, 1, n, w, h);
-            const bool merge = lines <= 8192;
+            const bool merge = lines <= merge_max_lines();
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 if (merge) {      // the SD launch shares its image operand between its two products: another template instance
@@ -464,7 +471,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 StageTimer t(ctx, st_pass, st, f_all);
                 SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
                 SSW_TRY(pair_gemm(st, true, is_row, true, 2, 1, m, m, h1, (const char*)h1 + (len / 8) * 64, dst, T2, n, w, h, ep, nullptr, TE));
-                if (lines <= 8192) {
+                if (lines <= merge_max_lines()) {
                     const PairClassDesc d0[2] = {{3, 0, sp, sp + p8, (const double*)sb0, (const double*)sb1},
                                                  {4, 0, sp + 2 * p8, sp + 3 * p8, (const double*)sb2_, (const double*)sb3}};
                     return launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d0, dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr);
@@ -538,7 +545,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                     StageTimer t(ctx, st_pass, st, f_all);
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &da, dst, (double*)A1, n, w, h, ep));
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &db, dst, (double*)A1, n, w, h, ep, nullptr, (double*)T2));
-                    if (lines <= 8192) {          // single frames: the classes of each dependent stage in one launch
+                    if (lines <= merge_max_lines()) {          // single frames: the classes of each dependent stage in one launch
                         SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d1, dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
                         return launch_dct_pair_gemm_multi_f64(st, is_row, true, 4, d0, dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm);
                     }
@@ -555,7 +562,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
                 SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
-                if (lines <= 8192) {          // single frames: the two classes of each dependent stage in one launch
+                if (lines <= merge_max_lines()) {          // single frames: the two classes of each dependent stage in one launch
                     const PairClassDesc d1[2] = {{3, 1, q, q + p16, (const double*)t0, (const double*)t1},
                                                  {4, 1, q + 2 * p16, q + 3 * p16, (const double*)t2, (const double*)t3}};
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d1, dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
