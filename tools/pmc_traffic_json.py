@@ -46,25 +46,31 @@ except OSError:
 lines_r, lines_c = chunk * H, chunk * W
 esz = 8
 K8 = lambda n: -(-(n // 8) // 16) * 16        # padded sum length of the n/8-wide operand planes
+K16 = lambda n: -(-(n // 16) // 16) * 16      # ... of the n/16-wide ones
+# level 2 (csrc/dct_pair_prep.hip dct_pair_efold / dct_pair_efold_cols): rows of 1280 columns or more, columns of 720 rows or more
+# (a multiple of 16): every launch sums n/16 terms over n/16 pairs; below, the full-length classes sum n/8 terms over n/8 pairs
+l2r, l2c = W >= 1280 and W % 64 == 0, H >= 720 and H % 16 == 0
+PR, KR = (W // 16, K16(W)) if l2r else (W // 8, K8(W))
+PC, KC = (H // 16, K16(H)) if l2c else (H // 8, K8(H))
 names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESIGN.md, algorithmic bytes per launch, note)
-    "pair_gemm_f64_kernel<false, 0, false, 4>": ("pair_gemm_f64_kernel<rows, split odd half, class E>",
-        2 * lines_r * K8(W) * esz + 2 * (W // 8 + 1) * K8(W) * esz + lines_r * (W // 4) * 4,
-        "AS and BD operand planes (k-blocked f64) x cosine / sine rows 2i -> frequencies 8i +/- 1 (f32); W/8 + 1 pairs in W/8 slots"),
+    "pair_gemm_f64_kernel<false, 0, false, 4>": ("pair_gemm_f64_kernel<rows, split odd half, class O (level 2: rotated, '+' launch)>",
+        2 * lines_r * KR * esz + 2 * (PR + 1) * KR * esz + lines_r * (2 * PR) * 4,
+        "two operand planes (k-blocked f64) x cosine / sine rows -> two frequencies per pair (f32); level 2: W/16 + 1 pairs in W/16 slots"),
     "pair_gemm_f64_kernel<false, 0, false, 3>": ("pair_gemm_f64_kernel<rows, split odd halves, other classes>",
-        2 * lines_r * K8(W) * esz + 2 * (W // 8) * K8(W) * esz + lines_r * (W // 4) * 4,
-        "class O of the full-length split and both classes of the half-length one (half the size), and the gathered launches of the pruned transform: mean over launches"),
+        2 * lines_r * KR * esz + 2 * PR * KR * esz + lines_r * (2 * PR) * 4,
+        "the other split classes of the forward row pass (level 2: six launches of the same size) and the gathered launches of the pruned transform: mean over launches"),
     "pair_gemm_f64_kernel<false, 0, false, 1>": ("pair_gemm_f64_kernel<rows, (SSS, SS-) launch>",
-        2 * lines_r * (W // 8) * esz + 2 * (W // 8) ** 2 * esz + lines_r * (W // 4) * 4, "frequencies 0 and 4 mod 8"),
+        2 * lines_r * KR * esz + 2 * PR * KR * esz + lines_r * (2 * PR) * 4, "frequencies 0 and 4 mod 8 (level 2: R1 folded, 0 and 8 mod 16)"),
     "pair_gemm_f64_kernel<true, 0, false, 3>": ("pair_gemm_f64_kernel<cols, split odd halves>",
-        2 * lines_c * K8(H) * esz + 2 * (H // 8) * K8(H) * esz + lines_c * (H // 4) * 4, "forward column pass, classes E / O of both split levels: mean over launches"),
+        2 * lines_c * KC * esz + 2 * PC * KC * esz + lines_c * (2 * PC) * 4, "forward column pass, the split classes (level 2: seven launches of the same size): mean over launches"),
     "pair_gemm_f64_kernel<true, 0, false, 1>": ("pair_gemm_f64_kernel<cols, (SSS, SS-) launch>",
-        2 * lines_c * (H // 8) * esz + 2 * (H // 8) ** 2 * esz + lines_c * (H // 4) * 4, "forward column pass, frequencies 0 and 4 mod 8"),
+        2 * lines_c * KC * esz + 2 * PC * KC * esz + lines_c * (2 * PC) * 4, "forward column pass, frequencies 0 and 4 mod 8 (level 2: 0 and 8 mod 16)"),
     "pair_gemm_f64_kernel<false, 4, false, 0>": ("pair_gemm_f64_kernel<rows, inverse split odd half>",
-        2 * lines_r * K8(W) * esz + 2 * (W // 8) * K8(W) * esz + lines_r * (W // 4) * esz + lines_r * (W // 2) * 4,
-        "inverse row pass: split odd part + the unrounded even half E -> half of the outputs (f32)"),
+        2 * lines_r * KR * esz + 2 * PR * KR * esz + lines_r * (2 * PR) * esz + lines_r * (4 * PR) * 4,
+        "inverse row pass: one launch of the split odd part + the unrounded even half E -> four outputs per pair (f32); level 2: four such launches"),
     "pair_gemm_f64_kernel<true, 5, false, 0>": ("pair_gemm_f64_kernel<cols, inverse split odd half + yiq->rgb>",
-        2 * lines_c * K8(H) * esz + 2 * (H // 8) * K8(H) * esz + lines_c * (H // 4) * esz + lines_c * (H // 2) * (8 + 12),
-        "last pass of Writer::result: split odd part + unrounded even half in, I and Q in, RGB f32 out (per launch: half of the rows)"),
+        2 * lines_c * KC * esz + 2 * PC * KC * esz + lines_c * (2 * PC) * esz + lines_c * (4 * PC) * (8 + 12),
+        "last pass of Writer::result: split odd part + unrounded even half in, I and Q in, RGB f32 out (level 2: four launches, a quarter of the rows each)"),
     "pair_prep16_rows_kernel<double, 1, false>": ("pair_prep16_rows_kernel<double, rgb>", lines_r * W * (12 + esz),
         "reader: RGB f32 in, the ten f64 operand planes of the deep row pass out"),
     "pair_prep16_rows_kernel<double, 1, true>": ("pair_prep16_rows_kernel<double, rgb, with I/Q>", lines_r * W * (12 + 8 + esz),
@@ -82,6 +88,13 @@ names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESI
     "prep16_inv_cols_staged_kernel<2, true>": ("prep16_inv_cols_staged_kernel<class-major tile, deep>", lines_r * W * (4 + esz), "inverse column pre-pass (transposing)"),
     "prep16_inv_cols_staged_kernel<0, true>": ("prep16_inv_cols_staged_kernel<natural, deep>", lines_r * W * (4 + esz), "the same from a natural-order plane"),
     "prep16_inv_cols_staged_kernel<0, false>": ("prep16_inv_cols_staged_kernel<natural, semi-deep>", lines_r * W * (4 + esz), "H % 16 != 0 (1080 rows)"),
+    # r4c: the level-2 forms
+    "prep16_cols_l2_kernel<1>": ("prep16_cols_l2_kernel<class-major tile>", lines_r * W * (4 + esz),
+        "forward column pre-pass at level 2: f32 plane (class-major tiles) in, sixteen transposed f64 operand planes H/16 wide out"),
+    "prep16_cols_l2_kernel<0>": ("prep16_cols_l2_kernel<natural>", lines_r * W * (4 + esz), "the same from a natural-order plane (the compact planes of the pruned transform: mean over launches)"),
+    "prep16_inv_rows_l2_kernel": ("prep16_inv_rows_l2_kernel", lines_r * W * (4 + esz), "inverse row pre-pass at level 2: coefficient plane in, sixteen operand planes W/16 wide out"),
+    "prep16_inv_cols_l2_kernel<2>": ("prep16_inv_cols_l2_kernel<class-major tile>", lines_r * W * (4 + esz), "inverse column pre-pass at level 2 (transposing)"),
+    "prep16_inv_cols_l2_kernel<0>": ("prep16_inv_cols_l2_kernel<natural>", lines_r * W * (4 + esz), "the same from a natural-order plane"),
     "select_compact_kernel<true>": ("select_compact_kernel<energy>", lines_r * W * 4, "the one full pass of the top-k selection"),
 }
 out = {"_how": __doc__.strip().split("usage:")[0].strip(), "commit": commit,
