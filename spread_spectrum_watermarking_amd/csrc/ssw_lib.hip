@@ -209,7 +209,9 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
     // second stream of the batch pipelines (ssw_pipeline.hip): the HBM-bound stages of one chunk run here
     // while the basis GEMMs of the other chunk in flight run on the context's stream.
     // (Measured: restricting this stream to 16 .. 128 CUs with a CU mask only slows the step down -- the
-    // chunk's GEMMs wait for its pre-pass -- so it is a plain stream.)
+    // chunk's GEMMs wait for its pre-pass -- so it is a plain stream.  Measured again at level 2, where the pre-passes
+    // are a third of a step, also with the complement mask on the GEMM stream: 64 CUs 8.8 / 9.8, 96 + complement 10.0,
+    // 128 CUs 12.1 Gpix/s against 13.9.)
     // Stream priorities (either way round) change nothing either.
     e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { (void)hipStreamDestroy(ctx->own_stream); delete ctx; set_last_error(hipGetErrorString(e)); return SSW_ERR_HIP; }
