@@ -96,12 +96,12 @@ bool dct_pair_efold(size_t len) {
     static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_MIN"); return e ? (size_t)std::atoll(e) : (size_t)1280; }();
     return dct_pair_can_deep_rows(len) && len >= mn;
 }
-// Inverse row passes of 1280 columns or more (a multiple of 256) run at level 2 as well (r4c): the odd part's classes and the
+// Inverse row passes of 1280 columns or more run at level 2 as well (r4c): the odd part's classes and the
 // quarter-length even part fold / rotate once more (dct_pair_prep_staged.hip, prep16_inv_rows_l2_kernel).
 // SSW_EFOLD_INV_MIN: A/B switch (minimum length).
 bool dct_pair_efold_inv(size_t len) {
     static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_INV_MIN"); return e ? (size_t)std::atoll(e) : (size_t)1280; }();
-    return dct_pair_can_deep_inv_rows(len) && dct_pair_prep_staged_rows_ok() && len % 256 == 0 && len >= mn;
+    return dct_pair_can_deep_inv_rows(len) && dct_pair_prep_staged_rows_ok() && len >= mn;      // (len % 128 == 0: can_deep_inv_rows)
 }
 // Column passes of 720 rows or more (a multiple of 16) run at level 2 in both directions (r4c; the staged pre-passes only):
 // launches of K = H/16 = 135 at 4K run at 50 TFLOP/s against 64 for K = 270, but do half the multiply-adds (measured a gain

@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_staged_kernel(const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// Inverse row pass at LEVEL 2 (r4c; n % 256 == 0, dct_pair_efold_inv): the operands of launches that all sum n/16 terms
+// Inverse row pass at LEVEL 2 (r4c; n % 128 == 0, dct_pair_efold_inv): the operands of launches that all sum n/16 terms
 // (build_pass, "deep inverse").  Sixteen planes K16 wide, numbered like the forward level-2 pass:
 //   0 .. 3   AS+ AS- BD+ BD-      class E of the odd part c[2k+1] folded once more (exact)
 //   4 .. 7   (a, b) of AD plus / minus (a, b) of the reversed BS: class O rotated once more
@@ -756,15 +756,17 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_l2_kernel(const float* __
     __shared__ unsigned s_piece[RNS], s_mask[RNS];
     const unsigned tid = threadIdx.x, t = tid & 7u, lr = tid >> 3;
     const unsigned tb = blockIdx.x % tblocks, lb = blockIdx.x / tblocks;
-    const unsigned NT = W / 64, NTh = NT / 2;                       // region sets per line; NT % 4 == 0
+    const unsigned NT = W / 64, NTh = NT / 2;                       // region sets per line; NT even
     const unsigned tl = t < 4 ? t : 7u - t;                          // the pair's low slot
     const unsigned tlow = 4 * tb + tl;
     const bool grp = t >= 4;                                         // partner side
     const size_t row_base = (size_t)lb * RL;
     const unsigned nl = rows - row_base < RL ? (unsigned)(rows - row_base) : RL;
-    const unsigned nt = NTh - 4 * tb < 4 ? NTh - 4 * tb : 4u;       // valid low slots (even)
-    const bool tok = tl < nt, ok = tok && lr < nl;
-    const unsigned tg = tok ? (grp ? NT - 1 - tlow : tlow) : 0;
+    const unsigned nt = NTh - 4 * tb < 4 ? NTh - 4 * tb : 4u;       // low slots whose tau is in the low half
+    // (a slot beyond nt holds a tau of the upper half -- the partner of another block's slot: rounds 1 / 2 leave its pair
+    // to that block, rounds 3 / 4 store its own outputs like any other's: the same values twice)
+    const bool ok = lr < nl;
+    const unsigned tg = grp ? NT - 1 - tlow : tlow;
     const unsigned R = 16 * tg;
     const unsigned Nh = W / 2, Nq = W / 4, N8 = W / 8, N16 = W / 16;
     auto plane = [&](unsigned a) { return base + (size_t)a * rows * K16; };
@@ -843,7 +845,6 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_l2_kernel(const float* __
             __syncthreads();
         }
     }
-    auto slot_ok = [&](unsigned tt) { return (tt < 4 ? tt : 7u - tt) < nt; };
     // ---- round 3: AS2 BD2 AD2 BS2 at the units 4 tau .. 4 tau + 3: half tau & 1 of piece tau / 2; slots 2 pi, 2 pi + 1 share
     // the block's piece pi: 2 tb + pi (low side), (NT - 4 - 4 tb) / 2 + pi - 2 (partner side)
     {
@@ -851,7 +852,7 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_l2_kernel(const float* __
             const unsigned pi = tid & 3u, pp = tid >> 2;
             s_plane[tid] = plane(12 + pp);
             s_piece[tid] = pi < 2 ? 2 * tb + pi : (NT - 4 - 4 * tb) / 2 + (pi - 2);
-            s_mask[tid] = (slot_ok(2 * pi) ? 0x3u : 0u) | (slot_ok(2 * pi + 1) ? 0xCu : 0u);
+            s_mask[tid] = 0xFu;
         }
         f64x4 as, bd, ad, bs;
         split_unit<double>(mid(0), mid(1), mid(2), mid(3), rot2, R / 4, N8, as, bd, ad, bs);
@@ -861,50 +862,64 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_l2_kernel(const float* __
     }
     // ---- round 4.  R2 = c[8 q + 4]: region 0 holds q = 2 tau, 2 tau + 1 and region 3 their mirrors n/8 - 1 - q; region 1
     // holds q = n/16 - 2 - 2 tau, + 1 and region 2 their mirrors: (a, b)[q] = (r c + rm s, rm c - r s), table of n/4.
-    // c[16 s], c[16 s + 8]: region j holds s = g[j] / 16.  Slabs: 0 .. 3 a, 4 .. 7 b (pair A / B x low / partner side: whole
-    // pieces), 8 .. 15 c[16 s], 16 .. 23 c[16 s + 8] (region x side: four doubles = half a piece each).
+    // c[16 s], c[16 s + 8]: region j holds s = g[j] / 16.  The four slots of a side cover 8 (a, b) or 4 (c[16 s]) consecutive
+    // entries per group -- whole or half pieces when n % 256 == 0, else (1920 columns) straddling two pieces: two slabs per
+    // group, three sub-rounds of 16 slabs: (a, b) x {pair A, B} x side; c[16 s] x region x side; c[16 s + 8] likewise.
     {
         auto n_of = [&](unsigned pr, unsigned tau) { return pr ? N16 - 2 - 2 * tau : 2 * tau; };
         auto s_of = [&](unsigned j, unsigned tau) { return j == 0 ? tau : j == 1 ? 2 * NT - 1 - tau : j == 2 ? 2 * NT + tau : 4 * NT - 1 - tau; };
         auto tau_of = [&](unsigned side, unsigned sl) { return side ? NT - 1 - (4 * tb + sl) : 4 * tb + sl; };
-        if (tid < 24) {
-            unsigned pl, first, m = 0;
-            if (tid < 8) {
-                const unsigned pr = (tid & 3u) >> 1, side = tid & 1u;
-                pl = 10 + (tid >> 2);
-                first = n_of(pr, tau_of(side, 0)) >> 3;
-                for (unsigned sl = 0; sl < nt; ++sl) m |= 1u << ((n_of(pr, tau_of(side, sl)) & 7u) >> 1);
+        const unsigned side = grp ? 1u : 0u;
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub) {
+            // entry (index inside its plane) of group gi, slot sl; step = doubles per slot
+            auto entry = [&](unsigned gi, unsigned sd, unsigned sl) {
+                return sub == 0 ? n_of(gi & 1u, tau_of(sd, sl)) : s_of(gi & 3u, tau_of(sd, sl));
+            };
+            const unsigned ngroups = sub == 0 ? 4u : 8u;          // sub 0: (plane a | b) x 2 pairs x 2 sides = 8 groups of 2 slabs
+            if (tid < 16) {
+                // slab tid = group * 2 + which piece; sub 0: group = plane * 4 + pair * 2 + side; else group = region * 2 + side
+                const unsigned gr = tid >> 1, which = tid & 1u;
+                const unsigned pl = sub == 0 ? 10 + (gr >> 2) : 7 + sub;
+                const unsigned gi = sub == 0 ? (gr >> 1) & 1u : gr >> 1, sd = gr & 1u;
+                const unsigned e0 = entry(gi, sd, 0), e3 = entry(gi, sd, 3);
+                const unsigned p0 = (e0 < e3 ? e0 : e3) >> 3;
+                unsigned m = 0;
+                for (unsigned sl = 0; sl < 4; ++sl) {
+                    const unsigned en = entry(gi, sd, sl);
+                    if ((en >> 3) == p0 + which) m |= 1u << ((en & 7u) >> 1);
+                }
+                s_plane[tid] = plane(pl);
+                s_piece[tid] = p0 + which;
+                s_mask[tid] = m;
+            }
+            (void)ngroups;
+            if (sub == 0) {
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const unsigned n0 = n_of(pr, tg);
+                    const unsigned e0 = n_of(pr, tau_of(side, 0)), e3 = n_of(pr, tau_of(side, 3));
+                    const unsigned p0 = (e0 < e3 ? e0 : e3) >> 3;
+                    const int jr = pr ? 1 : 0, jm = pr ? 2 : 3;
+                    const double r0 = (double)c[jr][1][0], r1 = (double)c[jr][3][0];        // R2[n0], R2[n0 + 1]
+                    const double m0 = (double)c[jm][3][0], m1 = (double)c[jm][1][0];        // their mirrors
+                    const f64x2 cc = *reinterpret_cast<const f64x2*>(rot3 + n0), ss = *reinterpret_cast<const f64x2*>(rot3 + N16 + n0);
+                    const unsigned sl = (2 * pr + side) * 2 + ((n0 >> 3) - p0);
+                    *reinterpret_cast<f64x2*>(lds + sl * RSL + lr * 8 + (n0 & 7u)) = (f64x2){r0 * cc[0] + m0 * ss[0], r1 * cc[1] + m1 * ss[1]};
+                    *reinterpret_cast<f64x2*>(lds + (8 + sl) * RSL + lr * 8 + (n0 & 7u)) = (f64x2){m0 * cc[0] - r0 * ss[0], m1 * cc[1] - r1 * ss[1]};
+                }
             } else {
-                const unsigned u = tid - 8, j = (u & 7u) >> 1, side = u & 1u;
-                pl = 8 + (u >> 3);
-                first = s_of(j, tau_of(side, 0)) >> 3;
-                for (unsigned sl = 0; sl < nt; ++sl) m |= 1u << ((s_of(j, tau_of(side, sl)) & 7u) >> 1);
-            }
-            s_plane[tid] = plane(pl);
-            s_piece[tid] = first;
-            s_mask[tid] = m;
-        }
-        if (tok) {
-            const unsigned side = grp ? 1u : 0u;
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                const unsigned n0 = n_of(pr, tg);
-                const int jr = pr ? 1 : 0, jm = pr ? 2 : 3;
-                const double r0 = (double)c[jr][1][0], r1 = (double)c[jr][3][0];        // R2[n0], R2[n0 + 1]
-                const double m0 = (double)c[jm][3][0], m1 = (double)c[jm][1][0];        // their mirrors
-                const f64x2 cc = *reinterpret_cast<const f64x2*>(rot3 + n0), ss = *reinterpret_cast<const f64x2*>(rot3 + N16 + n0);
-                const unsigned sl = 2 * pr + side;
-                *reinterpret_cast<f64x2*>(lds + sl * RSL + lr * 8 + (n0 & 7u)) = (f64x2){r0 * cc[0] + m0 * ss[0], r1 * cc[1] + m1 * ss[1]};
-                *reinterpret_cast<f64x2*>(lds + (4 + sl) * RSL + lr * 8 + (n0 & 7u)) = (f64x2){m0 * cc[0] - r0 * ss[0], m1 * cc[1] - r1 * ss[1]};
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned sv = s_of(j, tg);
+                    const unsigned e0 = s_of(j, tau_of(side, 0)), e3 = s_of(j, tau_of(side, 3));
+                    const unsigned p0 = (e0 < e3 ? e0 : e3) >> 3;
+                    const unsigned sl = (2 * j + side) * 2 + ((sv >> 3) - p0);
+                    lds[sl * RSL + lr * 8 + (sv & 7u)] = sub == 1 ? (double)c[j][0][0] : (double)c[j][2][0];
+                }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned sv = s_of(j, tg);
-                lds[(8 + 2 * j + side) * RSL + lr * 8 + (sv & 7u)] = (double)c[j][0][0];
-                lds[(16 + 2 * j + side) * RSL + lr * 8 + (sv & 7u)] = (double)c[j][2][0];
-            }
+            flush(16);
         }
-        flush(24);
     }
     if (tb == 0) {                                                  // zero padding [n/16, K16): whole pieces
         const unsigned l = tid >> 3, ch = tid & 7u;
@@ -1000,7 +1015,7 @@ int launch_prep16_inv_cols_l2(hipStream_t st, const float* in, size_t n_frames, 
 
 int launch_prep16_inv_rows_l2(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
                                const double* rot1, const double* rot2, const double* rot3, unsigned K16) {
-    if (w % 256 != 0 || !rot3) return SSW_ERR_BAD_ARG;
+    if (w % 128 != 0 || !rot3) return SSW_ERR_BAD_ARG;
     const unsigned NT = (unsigned)(w / 64), tblocks = (NT / 2 + 3) / 4;
     const unsigned long long nblk = (unsigned long long)((rows + RL - 1) / RL) * tblocks;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;

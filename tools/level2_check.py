@@ -17,9 +17,10 @@ import fuzz_batch  # noqa: E402
 import fuzz_dct  # noqa: E402
 
 # (h, w, frames): class-major tiles behind deep columns (h % 16 == 0), natural order behind others, one and several
-# tiles of region sets per block of the inverse pre-pass (w / 64 = 4 .. 32), ragged last blocks (w = 768, 1280: w / 128 % 4 != 0)
+# tiles of region sets per block of the inverse pre-pass (w / 64 = 4 .. 60), ragged last blocks and groups that straddle
+# k-block pieces (w = 384, 640, 896, 1920: w / 64 % 4 == 2; w / 128 odd)
 SHAPES = [(128, 256, 1), (128, 512, 2), (256, 768, 1), (136, 1024, 3), (480, 1280, 2), (512, 1536, 1), (100, 2048, 2),
-          (1080, 256, 1), (64, 3840, 2), (272, 320, 2), (2160, 512, 1), (1104, 200, 2), (336, 132, 1)]
+          (1080, 256, 1), (64, 3840, 2), (272, 320, 2), (2160, 512, 1), (1104, 200, 2), (336, 132, 1), (72, 1920, 2), (1080, 1920, 1), (144, 384, 3), (80, 640, 1), (96, 896, 2)]
 BATCH = [(256, 512, 3, 150, 11, 21), (144, 1024, 2, 200, 12, 22)]      # (h, w, frames, k, frame seed, mark seed)
 
 if __name__ == "__main__":
