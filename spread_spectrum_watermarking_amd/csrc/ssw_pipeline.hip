@@ -507,8 +507,8 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 SSW_TRY(get_basis(ctx, len / 4, false, true, 9, &rot3));
                 SSW_TRY(get_basis(ctx, len / 8, true, true, 3, &h0));
                 SSW_TRY(get_basis(ctx, len / 8, true, true, 4, &h1));
-                SSW_TRY(grow(ws.operand[2], bytes));
-                A1 = ws.operand[2].p;             // the eighth-length even part, unrounded
+                SSW_TRY(grow(ws.operand[2], lines * (len / 8) * sizeof(double)));
+                A1 = ws.operand[2].p;             // the eighth-length even part, unrounded: len/8 doubles per line
             }
             void* T2 = ws.operand[1].p;       // quarter-length even half, unrounded
             void* TE = ws.operand[4].p;       // the even half E, unrounded
