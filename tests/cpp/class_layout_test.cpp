@@ -67,12 +67,27 @@ int main() {
                 for (unsigned e = 0; e < n / fl.mod(c); ++e)
                     if (fl.base(c) + (e >> gsh) * t + (e & (g - 1)) != fl.pos(c, e)) return fail("shift form of pos()", n, e);
             }
-        std::vector<int> seen2(n, 0);
-        for (unsigned m = 0; m < n; ++m) {
-            const unsigned p = inverse_class_pos(m, n, t);
-            if (p >= n || seen2[p]++) return fail("inverse_class_pos not a bijection", n, m);
-            if (p / t != m / t) return fail("inverse_class_pos leaves its tile", n, m);
-            if (inverse_class_natural(p, n, t) != m) return fail("inverse_class_natural", n, m);
+        // inverse row pass: by residue mod 4 (level 1) or mod 8 (level 2; t % 8 == 0)
+        for (bool l2 : {false, true}) {
+            if (l2 != level2 || (l2 && t % 8 != 0)) continue;
+            std::vector<int> seen2(n, 0);
+            for (unsigned m = 0; m < n; ++m) {
+                const unsigned p = inverse_class_pos(m, n, t, l2);
+                if (p >= n || seen2[p]++) return fail("inverse_class_pos not a bijection", n, m);
+                if (p / t != m / t) return fail("inverse_class_pos leaves its tile", n, m);
+                if (inverse_class_natural(p, n, t, l2) != m) return fail("inverse_class_natural", n, m);
+            }
+            if (!l2) continue;
+            // the four launches of the odd part own {0,7} {4,3} {2,5} {1,6} mod 8: each pair of residues (and the mirrors
+            // n - 1 - m, the same pair) occupies two neighbouring runs of t/8 positions, m / 8 ascending inside a run
+            const unsigned pairs[4][2] = {{0, 7}, {4, 3}, {2, 5}, {1, 6}};
+            for (unsigned c = 0; c < 4; ++c)
+                for (unsigned i = 0; i < t / 8; ++i)
+                    for (unsigned h = 0; h < 2; ++h) {
+                        const unsigned m = 8 * i + pairs[c][h];
+                        if (inverse_class_pos(m, n, t, true) != (2 * c + h) * (t / 8) + i) return fail("level-2 inverse run", n, m);
+                        if ((n - 1 - m) % 8 != pairs[c][1 - h]) return fail("mirror leaves its class", n, m);
+                    }
         }
     }
     std::printf("ok\n");
