@@ -245,11 +245,16 @@ __device__ inline void pair_store_rgb_quad(const PairOutT<T>& po, size_t px, con
     }
 }
 
-// row stride (in elements) of the operand planes / half bases of a length-n axis for precision T:
-// n/2 rounded up so that the GEMM runs an even number of k-steps (f64: 8 per step, f32: 16)
+// row stride (in elements) of the operand planes / half bases of a length-n axis for precision T: n/2 rounded up to whole
+// k-steps (f64: 8 per step, f32: 16), at least two of them; the f32 GEMM wants an even number of steps, the f64 one has a
+// compile-time variant of its tile body for odd counts (135 -> 136 instead of 144 at 4K columns)
 template <typename T> inline size_t pair_kpad(size_t n) {
     const size_t m = 2 * KBlock<T>::KB;
     return ((n / 2 + m - 1) / m) * m;
+}
+template <> inline size_t pair_kpad<double>(size_t n) {
+    const size_t m = KBlock<double>::KB, k = ((n / 2 + m - 1) / m) * m;
+    return k < 2 * m ? 2 * m : k;
 }
 
 }  // namespace ssw

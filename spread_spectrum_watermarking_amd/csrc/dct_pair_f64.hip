@@ -37,12 +37,8 @@
 #include <cstdlib>
 #include <type_traits>
 
-namespace ssw {
-
-constexpr int PT = 256;
-constexpr int PBK = 8;
-
 #ifdef SSW_TILE_TRACE
+namespace ssw {
 // diagnostic build only: per block (thread 0) the 100 MHz wall clock at entry, after the first tile is staged, after
 // the main loop and after the epilogue, plus the hardware id (XCC / SE / CU) -- tools/tile_trace.py
 __device__ unsigned long long* g_tile_trace = nullptr;
@@ -59,809 +55,15 @@ extern "C" int ssw_debug_set_tile_trace(void* dev_ptr, unsigned cap) {
 extern "C" int ssw_debug_get_tile_trace_count(unsigned* n) {
     return hipMemcpyFromSymbol(n, HIP_SYMBOL(g_tile_trace_n), sizeof(*n)) == hipSuccess ? 0 : -1;
 }
-#define SSW_TT(i) do { if (threadIdx.x == 0) tt[i] = wall_clock64(); } while (0)
-#else
-#define SSW_TT(i) do { } while (0)
+}  // namespace ssw
 #endif
-typedef PairOutT<double> PairOut;
-
-
-// COLS: lines are (frame, column) and the transformed axis runs down the rows.  SAMEX: X2 == X1
-// (one product's image operand feeds both basis operands; it is staged and read once).
-// (A 256-line x 32-pair block tile for pair counts that 64 divides badly -- 540 at 4K -- was measured:
-// equal on the shared-X launches, 10 % slower on the two-operand ones; not kept.)
-// SUB only names the instance (launches that serve a deeper folding level show up separately in profiles).
-// BM: lines per block tile.  128 is the tile of every large launch; 64 serves launches whose 128-line grid
-// would leave the chip half empty (a single 4K frame: 17 x 15 = 255 tiles for 512 block slots).
-// One launch serves up to five "classes" -- GEMMs of the same kind (template instance) over the same lines with their own
-// operands, bases, pair counts, sum lengths and output maps: the tile columns of the classes lie side by side in the
-// launch's tile grid.  Batch launches carry one class; the five launches of a deep forward pass (two or three of an
-// inverse pass) of a single frame are merged into one, because each alone fills half of the chip's block slots for one
-// round (a 4K frame's class E: 34 x 8 = 272 blocks of 64 lines for 512 slots).
-struct PairClassArgs {
-    const double *x1, *x2, *y1, *y2;
-    unsigned NP, Kp, yrows, tiles_n;
-    unsigned c1, c2, cs, pm, np1, p2lo, bn32, fold0;
-    unsigned gsh, e2off;               // forward class-major output map (PairOutT::ft)
-};
-struct PairMulti {
-    PairClassArgs c[8];
-    unsigned n_classes, L, tiles_m, tiles_n_total;
-    PairOut po;                        // the fields the classes share; c1 .. bn32 are overwritten per class
-};
-
-template <bool COLS, int EPI, bool SAMEX, int SUB = 0, int BM = 128>
-__global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml, Epilogue ep) {
-    constexpr int NX = SAMEX ? 1 : 2;
-    constexpr int BN = 64, XQ = BM / 64;                                   // XQ: X lines per staging thread
-    // operand tiles [buffer][product][rows * 8]; a column pass reuses the region to transpose its results (epilogue)
-    constexpr int SXD = 2 * NX * BM * PBK, SYD = 2 * 2 * BN * PBK;
-    constexpr int TRD = COLS ? 4 * 32 * (BM / 2 + 16) / 2 : 0;              // 4 waves x 32 result rows x pitch floats
-    __shared__ __attribute__((aligned(16))) double lds[SXD + SYD > TRD ? SXD + SYD : TRD];
-    double (*sX)[NX][BM * PBK] = reinterpret_cast<double (*)[NX][BM * PBK]>(lds);
-    double (*sY)[2][BN * PBK] = reinterpret_cast<double (*)[2][BN * PBK]>(lds + SXD);
-
+#include "dct_pair_f64_kernel.hpp"
 #ifdef SSW_TILE_TRACE
-    unsigned long long tt[5] = {0, 0, 0, 0, 0};
-    const unsigned long long cyc0 = clock64();
+#define SSW_INV_PART -1
+#include "dct_pair_f64_inv.inc"      // the diagnostic build keeps one unit (one set of trace globals)
 #endif
-    SSW_TT(0);
-    unsigned tm, tn;
-    tile_of_block(blockIdx.x, gridDim.x, ml.tiles_m, ml.tiles_n_total, tm, tn);
-    unsigned cls = 0;
-    while (cls + 1 < ml.n_classes && tn >= ml.c[cls].tiles_n) { tn -= ml.c[cls].tiles_n; ++cls; }      // block-uniform
-    const PairClassArgs& ca = ml.c[cls];
-    const double* __restrict__ X1g = ca.x1;
-    const double* __restrict__ X2g = ca.x2;
-    const double* __restrict__ Y1g = ca.y1;
-    const double* __restrict__ Y2g = ca.y2;
-    const unsigned L = ml.L, NP = ca.NP, Kp = ca.Kp, yrows = ca.yrows;
-    PairOut po = ml.po;
-    po.c1 = ca.c1; po.c2 = ca.c2; po.cs = ca.cs; po.pm = ca.pm; po.np1 = ca.np1; po.p2lo = ca.p2lo; po.bn32 = ca.bn32; po.fold0 = ca.fold0;
-    po.gsh = ca.gsh; po.e2off = ca.e2off;
-    const unsigned m0 = tm * BM, p0 = tn * (po.bn32 ? 32u : (unsigned)BN);
-    const unsigned tid = threadIdx.x;
-    const unsigned lane = tid & 63, wave = tid >> 6;
-    const unsigned li = lane & 15, lq = lane >> 4;
 
-    // LDS tile rows hold 8 consecutive k (64 bytes); double k of row r sits at position
-    // k ^ ((r >> 1) & 7): conflict-free for the ds_read_b64 / ds_read2_b64 fragment reads (16 lanes
-    // cover a 128-byte bank window exactly) and for the staging ds_write_b64.
-    // staging: line = tid / 4 (+ 64 q), k-pair = tid % 4
-    const unsigned srow = tid >> 2, sc = tid & 3;
-    const unsigned ssw = (srow >> 1) & 7;
-    unsigned xoff[XQ];
-#pragma unroll
-    for (int q = 0; q < XQ; ++q) {
-        unsigned r = m0 + srow + 64 * q;
-        r = r < L ? r : L - 1;
-        xoff[q] = ((r - m0) * 8 + 2 * sc) * 8u;
-    }
-    unsigned yr = p0 + srow;
-    yr = yr < NP ? yr : NP - 1;
-    const unsigned yoff = ((yr - p0) * 8 + 2 * sc) * 8u;
-    // block-uniform buffer resources (scalar registers) at the tile's first line of k-block 0; a k-step
-    // advances a scalar byte offset by one k-block (< 4 GB: checked by the launcher)
-    const __amdgpu_buffer_rsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc((void*)(X1g + (size_t)m0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void*)(X2g + (size_t)m0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t y1r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y1g + (size_t)p0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y2g + (size_t)p0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
-    const unsigned xstep = L * 64u, ystep = yrows * 64u;
-
-    u32x4 rx1[XQ], rx2[XQ], ry1, ry2;
-    auto gload = [&](unsigned t) {
-        const unsigned xadv = t * xstep, yadv = t * ystep;
-#pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            rx1[q] = __builtin_amdgcn_raw_buffer_load_b128(x1r, xoff[q], xadv, 0);
-            if (!SAMEX) rx2[q] = __builtin_amdgcn_raw_buffer_load_b128(x2r, xoff[q], xadv, 0);
-        }
-        ry1 = __builtin_amdgcn_raw_buffer_load_b128(y1r, yoff, yadv, 0);
-        ry2 = __builtin_amdgcn_raw_buffer_load_b128(y2r, yoff, yadv, 0);
-    };
-    const unsigned st0 = srow * PBK + ((2 * sc) ^ ssw), st1 = srow * PBK + ((2 * sc + 1) ^ ssw);
-    auto put = [&](double* tile, const u32x4& v) {
-        *reinterpret_cast<u32x2*>(tile + st0) = (u32x2){v[0], v[1]};
-        *reinterpret_cast<u32x2*>(tile + st1) = (u32x2){v[2], v[3]};
-    };
-    auto lstore = [&](auto bufc) {
-        constexpr int buf = decltype(bufc)::value;
-#pragma unroll
-        for (int q = 0; q < XQ; ++q) {
-            put(&sX[buf][0][64 * q * PBK], rx1[q]);
-            if (!SAMEX) put(&sX[buf][NX - 1][64 * q * PBK], rx2[q]);
-        }
-        put(&sY[buf][0][0], ry1);
-        put(&sY[buf][1][0], ry2);
-    };
-    // The wave grid is 2 x 2 (each wave BM/2 lines x 32 pairs: NI = BM/32 line tiles) unless the tile holds at
-    // most 32 valid pairs -- the last tile column of e.g. 540 pairs -- where it is 4 x 1 (each wave
-    // BM/4 lines x 32 pairs: NI = BM/64) and the tile takes half the MFMAs instead of computing padding.
-    auto run = [&](auto nic, auto njc) {
-    constexpr int NI = decltype(nic)::value;
-    constexpr int NJ = decltype(njc)::value;                 // pair tiles of 16 per wave: 2; 1 / 3 (4 x 1 grid) when the tile holds <= 16 / 33 .. 48 valid pairs
-    constexpr int NJA = NJ < 2 ? 2 : NJ;
-    constexpr bool FULL = NI == BM / 32;
-    const unsigned wm = FULL ? (wave >> 1) * (BM / 2) : wave * (BM / 4), wn = FULL ? (wave & 1) * 32 : 0;
-    f64x4 acc1[NI][NJA], acc2[NI][NJA];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJA; ++j) { acc1[i][j] = (f64x4){0, 0, 0, 0}; acc2[i][j] = (f64x4){0, 0, 0, 0}; }
-
-    // fragment of half-step s: lane group lq supplies k = 4 s + lq
-    const unsigned fsw = (li >> 1) & 7;
-    unsigned rdx[2], rdy[2];
-#pragma unroll
-    for (int sh = 0; sh < 2; ++sh) {
-        rdx[sh] = (wm + li) * PBK + ((4 * sh + lq) ^ fsw);
-        rdy[sh] = (wn + li) * PBK + ((4 * sh + lq) ^ fsw);
-    }
-    struct Frag { double x1[NI], x2[NI], y1[NJA], y2[NJA]; };
-    auto fread = [&](auto bufc, auto shc, Frag& f) {
-        constexpr int cur = decltype(bufc)::value;
-        constexpr int sh = decltype(shc)::value;
-#pragma unroll
-        for (int jn = 0; jn < NJ; ++jn) {
-            f.y1[jn] = sY[cur][0][rdy[sh] + 16 * jn * PBK];
-            f.y2[jn] = sY[cur][1][rdy[sh] + 16 * jn * PBK];
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            f.x1[i] = sX[cur][0][rdx[sh] + 16 * i * PBK];
-            if (!SAMEX) f.x2[i] = sX[cur][NX - 1][rdx[sh] + 16 * i * PBK];
-        }
-    };
-    auto fmma = [&](const Frag& f) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int jn = 0; jn < NJ; ++jn) {
-                const double xb = SAMEX ? f.x1[i] : f.x2[i];
-                if (!COLS) {      // D[row = line][col = pair]
-                    acc1[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.x1[i], f.y1[jn], acc1[i][jn], 0, 0, 0);
-                    acc2[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb, f.y2[jn], acc2[i][jn], 0, 0, 0);
-                } else {          // D[row = pair][col = line]: image columns along the lanes
-                    acc1[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y1[jn], f.x1[i], acc1[i][jn], 0, 0, 0);
-                    acc2[i][jn] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y2[jn], xb, acc2[i][jn], 0, 0, 0);
-                }
-            }
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-
-    // Software pipeline, shifted by half a k-step: the fragments of a half-step are read from LDS
-    // while the MFMAs of the previous half-step run; the tile of step t+1 is written (and the
-    // barrier taken) in the middle of step t, its global loads having been issued a step earlier.
-    const unsigned nk = Kp / PBK;          // even and >= 2: Kp is a multiple of 16
-    Frag fa, fb;
-    // k-steps 0 and 1 are requested together (one memory latency at the start of a tile, not two): step 1
-    // waits in registers that the fragments will use later
-    gload(1);
-    u32x4 nx1[XQ], nx2[XQ];
-#pragma unroll
-    for (int q = 0; q < XQ; ++q) { nx1[q] = rx1[q]; if (!SAMEX) nx2[q] = rx2[q]; }
-    const u32x4 ny1 = ry1, ny2 = ry2;
-    gload(0);
-    lstore(B0{});
-    __syncthreads();
-    SSW_TT(1);
-#pragma unroll
-    for (int q = 0; q < XQ; ++q) { rx1[q] = nx1[q]; if (!SAMEX) rx2[q] = nx2[q]; }
-    ry1 = ny1; ry2 = ny2;
-    fread(B0{}, B0{}, fa);
-    // full step t on buffer CUR: needs t + 2 < nk
-    // one LDS read behind each of the first MFMAs of a half-step (a burst of reads would stall the
-    // wave at the LDS queue with its MFMAs behind it), then the staging writes two per MFMA
-    auto interleave = [&](auto storec) {
-        constexpr bool STORE = decltype(storec)::value != 0;
-        constexpr int NMF = 2 * NJ * NI;                        // MFMAs per half-step
-        constexpr int NRD = (2 * NJ + NI * NX + 1) / 2;         // ds_read2_b64 per half-step (fragments pair up)
-#pragma unroll
-        for (int i = 0; i < NRD; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        if (STORE) {
-            constexpr int NLD = XQ * NX + 2;                    // staged 16-byte loads per thread (2 LDS writes each)
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD - NLD > 0 ? NMF - NRD - NLD : 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, NLD, 0);
-        } else {
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NRD, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto step = [&](auto curc, auto nxtc, unsigned t) {
-        fread(curc, B1{}, fb);
-        fmma(fa);
-        lstore(nxtc);                          // loaded a whole step ago
-        gload(t + 2);
-        interleave(B1{});
-        __syncthreads();
-        fread(nxtc, B0{}, fa);
-        fmma(fb);
-        interleave(B0{});
-    };
-    unsigned t = 0;
-    for (; t + 2 < nk; t += 2) {
-        step(B0{}, B1{}, t);
-        step(B1{}, B0{}, t + 1);
-    }
-    // steps nk - 2 (buffer 0) and nk - 1 (buffer 1)
-    fread(B0{}, B1{}, fb);
-    fmma(fa);
-    interleave(B0{});
-    lstore(B1{});
-    __syncthreads();
-    fread(B1{}, B0{}, fa);
-    fmma(fb);
-    interleave(B0{});
-    fread(B1{}, B1{}, fb);
-    fmma(fa);
-    interleave(B0{});
-    fmma(fb);
-    SSW_TT(2);
-
-#ifdef SSW_TILE_TRACE
-    auto trace_end = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x == 0) tt[4] = wall_clock64();
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0);
-    if (threadIdx.x == 0 && g_tile_trace) {
-        tt[3] = wall_clock64();
-        const unsigned slot = atomicAdd(&g_tile_trace_n, 1u);
-        if (slot < g_tile_trace_cap) {
-            unsigned hwid = 0, xcc = 0;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* o = g_tile_trace + 8ull * slot;
-            o[0] = tt[0]; o[1] = tt[1]; o[2] = tt[2]; o[3] = tt[3];
-            o[4] = ((unsigned long long)xcc << 32) | hwid;
-            o[5] = (unsigned long long)(unsigned)(COLS * 1000 + EPI * 100 + SAMEX * 10 + SUB);
-            o[6] = ((unsigned long long)Kp << 32) | NP;
-            o[5] |= ((clock64() - cyc0) & 0xFFFFFFFull) << 36;     // shader cycles of the block (28 bits) above the tag
-            o[7] = tt[4];
-        }
-    }
-    };
-#else
-    auto trace_end = [] {};
-#endif
-    if (po.pm) {                               // split odd half: cosine part +/- sine part (block-uniform branch)
-        // fold0 (class E): pair 0 multiplied cosine row 0 and sine row n/8; its outputs are acc1 itself (first output of
-        // pair 0: the sine row of pair 0 is zero) and -acc2 (second output of pair n/8: its cosine row is zero).  Only the
-        // first tile column holds pair 0: block-uniform branch, one select per value there.
-        const bool has0 = po.fold0 != 0 && p0 == 0 && wn == 0;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double a1 = acc1[i][jn][r], a2 = acc2[i][jn][r];
-                    double s = a1 + a2, d = a1 - a2;
-                    if (jn == 0 && has0) {
-                        // !COLS: the pair runs along the lanes (li); COLS: along the accumulator rows (lq + 4 r)
-                        const bool p = COLS ? (lq == 0 && r == 0) : (li == 0);
-                        s = p ? a1 : s;
-                        d = p ? 0.0 - a2 : d;
-                    }
-                    acc1[i][jn][r] = s;
-                    acc2[i][jn][r] = d;
-                }
-    }
-    const bool second_out = po.pm != 2;
-    // pair whose second output this pair's slot carries (fold0: pair 0 carries pair n/8's)
-    auto p2 = [&](unsigned pair) { return (po.fold0 && pair == 0) ? po.fold0 : pair; };
-
-    // D map of 16x16x4 f64: col = lane & 15, row = (lane >> 4) + 4 reg
-    const unsigned n = po.n, W = po.W, H = po.H;
-    // one output line: element idx of the transformed axis lives at lp[idx * es] (and tp[idx * es] in T)
-    // element offsets idx * es stay below 2^32 (W * H < 2^32: indices are u32 throughout)
-    // position of element m of a line of length len: natural, or class-major on the row pass of a deep inverse transform
-    auto opos = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len, 0, po.cm == 2) : m; };
-    // ... of the f32 output line (class-major inside tiles of po.cmt positions; the E planes above: one tile)
-    auto oposf = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len, po.cmt, po.cm == 2) : m; };
-    // forward outputs of a pair: natural c + cs pair, or the class-major column of its entry (PairOutT::ft)
-    auto fpos1 = [&](unsigned pair) {
-        return po.ft ? po.c1 + (pair >> po.gsh) * po.ft + (pair & ((1u << po.gsh) - 1u)) : po.c1 + po.cs * pair;
-    };
-    auto fpos2 = [&](unsigned pair) {
-        const unsigned q = p2(pair), e = q - po.e2off;
-        return po.ft ? po.c2 + (e >> po.gsh) * po.ft + (e & ((1u << po.gsh) - 1u)) : po.c2 + po.cs * q;
-    };
-    auto emit = [&](float* lp, double* tp, double* to, unsigned es, unsigned pair, double a1, double a2) {
-        if (EPI == EPI_FWD || EPI == EPI_FWD_ADJ) {
-            const unsigned i1 = fpos1(pair), i2 = fpos2(pair);
-            if (EPI == EPI_FWD_ADJ) {
-                const f32x2 v = {apply_epilogue(ep, (float)a1, i1), apply_epilogue(ep, (float)a2, i2)};
-                *reinterpret_cast<f32x2*>(lp + i1) = v;
-            } else {
-                if (pair < po.np1) lp[i1 * es] = apply_epilogue(ep, (float)a1, i1);
-                if (pair >= po.p2lo && second_out) lp[i2 * es] = apply_epilogue(ep, (float)a2, i2);
-            }
-        } else if (EPI == EPI_INV) {
-            lp[pair * es] = apply_epilogue(ep, (float)(a1 + a2), pair);
-            lp[(n - 1 - pair) * es] = apply_epilogue(ep, (float)(a1 - a2), n - 1 - pair);
-        } else if (EPI == EPI_INV_E) {
-            tp[pair * es] = a1 + a2;
-            tp[(n / 2 - 1 - pair) * es] = a1 - a2;
-        } else if (EPI == EPI_INV_OT) {
-            const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * p2(pair);
-            if (n1 < n / 2) { const double e1 = tp[n1 * es]; to[opos(n1, n) * es] = e1 + a1; to[opos(n - 1 - n1, n) * es] = e1 - a1; }
-            if (n2 < n / 2) { const double e2 = tp[n2 * es]; to[opos(n2, n) * es] = e2 + a2; to[opos(n - 1 - n2, n) * es] = e2 - a2; }
-        } else {
-            const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * p2(pair);      // positions in the odd part, < n/2
-            if (n1 < n / 2) {
-                const double e1 = tp[opos(n1, n / 2) * es];
-                lp[oposf(n1, n) * es] = apply_epilogue(ep, (float)(e1 + a1), n1);
-                lp[oposf(n - 1 - n1, n) * es] = apply_epilogue(ep, (float)(e1 - a1), n - 1 - n1);
-            }
-            if (n2 < n / 2) {
-                const double e2 = tp[opos(n2, n / 2) * es];
-                lp[oposf(n2, n) * es] = apply_epilogue(ep, (float)(e2 + a2), n2);
-                lp[oposf(n - 1 - n2, n) * es] = apply_epilogue(ep, (float)(e2 - a2), n - 1 - n2);
-            }
-        }
-    };
-    // Row passes, EPI_FWD / EPI_INV_O.  While this wave stores its results the other resident block streams f64 MFMAs
-    // on the same SIMD, and a VALU instruction of this wave then gets an issue slot about once per MFMA (64 cycles):
-    // measured, the epilogue takes ~70 cycles per VALU instruction (tools/tile_trace.py) -- 36 us of a 125 us tile with
-    // per-element bounds checks and 64-bit addresses.  So: buffer stores whose lane offsets are computed once per
-    // 16-pair tile, rows advanced through the scalar offset, invalid lanes / rows dropped by the buffer's range check
-    // (offset 2^31 >= num_records) instead of branches; per output element one conversion and one store.
-    if constexpr (!COLS && (EPI == EPI_FWD || EPI == EPI_INV_O || EPI == EPI_INV_OT)) {
-        const unsigned rows_valid = L - m0 < (unsigned)BM ? L - m0 : (unsigned)BM;
-        const unsigned long long region = (unsigned long long)rows_valid * W * 4ull;
-        if (region < 0x80000000ull && (EPI == EPI_FWD || (EPI == EPI_INV_O && n == W) || EPI == EPI_INV_OT)) {
-            constexpr unsigned OOB = 0x80000000u;
-            const bool plain = ep.first == 1.0f && ep.base == 1.0f;
-            const __amdgpu_buffer_rsrc_t orr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.out + (size_t)m0 * W), 0, (unsigned)region, 0x00020000);
-            const unsigned swm = __builtin_amdgcn_readfirstlane(wm);
-            auto st = [&](float v, unsigned voff, unsigned soff) {
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), orr, voff, soff, 0);
-            };
-            if constexpr (EPI == EPI_FWD) {
-                unsigned vo1[NJ], vo2[NJ];
-                float f1[NJ], f2[NJ];
-#pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) {
-                    const unsigned pair = p0 + wn + 16 * jn + li;
-                    const unsigned i1 = fpos1(pair), i2 = fpos2(pair);
-                    vo1[jn] = (pair < NP && pair < po.np1) ? (lq * W + i1) * 4u : OOB;
-                    vo2[jn] = (pair < NP && pair >= po.p2lo && second_out) ? (lq * W + i2) * 4u : OOB;
-                    f1[jn] = i1 == 0 ? ep.first : ep.base;
-                    f2[jn] = i2 == 0 ? ep.first : ep.base;
-                }
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned soff = (swm + 16 * i + 4 * r) * W * 4u;
-#pragma unroll
-                        for (int jn = 0; jn < NJ; ++jn) {
-                            float v1 = (float)acc1[i][jn][r], v2 = (float)acc2[i][jn][r];
-                            if (!plain) { v1 *= f1[jn]; v2 *= f2[jn]; }
-                            st(v1, vo1[jn], soff);
-                            st(v2, vo2[jn], soff);
-                        }
-                    }
-            } else if constexpr (EPI == EPI_INV_OT) {
-                // T[n1] = T2[n1] + a, T[n-1-n1] = T2[n1] - a as doubles (T lines: n doubles = W * 4 bytes, T2 lines half that)
-                // (n = W/2: the half-length transform E; n = W/4 at level 2: its even half T2 from the folded quarter)
-                const unsigned tregion = rows_valid * n * 8u;             // <= region: n <= W/2
-                const __amdgpu_buffer_rsrc_t irr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp + (size_t)m0 * (n / 2)), 0, tregion / 2, 0x00020000);
-                const __amdgpu_buffer_rsrc_t trr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp_out + (size_t)m0 * n), 0, tregion, 0x00020000);
-                unsigned vt[NJ][2], vp[NJ][2], vm[NJ][2];
-#pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) {
-                    const unsigned pair = p0 + wn + 16 * jn + li;
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
-                        const bool ok = pair < NP && nn < n / 2;
-                        vt[jn][h2] = ok ? (lq * (n / 2) + nn) * 8u : OOB;
-                        vp[jn][h2] = ok ? (lq * n + opos(nn, n)) * 8u : OOB;
-                        vm[jn][h2] = ok ? (lq * n + opos(n - 1 - nn, n)) * 8u : OOB;
-                    }
-                }
-                auto std64 = [&](double v, unsigned voff, unsigned soff) {
-                    const u32x2 raw = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
-                    __builtin_amdgcn_raw_buffer_store_b64(raw, trr, voff, soff, 0);
-                };
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    double e[4][NJ][2];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned soff = (swm + 16 * i + 4 * r) * (n / 2) * 8u;
-#pragma unroll
-                        for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) {
-                                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(irr, vt[jn][h2], soff, 0);
-                                e[r][jn][h2] = __hiloint2double((int)raw[1], (int)raw[0]);
-                            }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned soff = (swm + 16 * i + 4 * r) * n * 8u;
-#pragma unroll
-                        for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) {
-                                const double a = h2 ? acc2[i][jn][r] : acc1[i][jn][r];
-                                std64(e[r][jn][h2] + a, vp[jn][h2], soff);
-                                std64(e[r][jn][h2] - a, vm[jn][h2], soff);
-                            }
-                    }
-                }
-            } else {
-                // x[n1] = E[n1] + a1, x[n-1-n1] = E[n1] - a1, x[n2] = E[n2] + a2, x[n-1-n2] = E[n2] - a2; E read as doubles
-                const __amdgpu_buffer_rsrc_t trr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp + (size_t)m0 * (n / 2)), 0, (unsigned)region, 0x00020000);
-                unsigned vt[NJ][2], vp[NJ][2], vm[NJ][2];
-                float fp[NJ][2];
-#pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) {
-                    const unsigned pair = p0 + wn + 16 * jn + li;
-#pragma unroll
-                    for (int h2 = 0; h2 < 2; ++h2) {
-                        const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
-                        const bool ok = pair < NP && nn < n / 2;
-                        vt[jn][h2] = ok ? (lq * (n / 2) + opos(nn, n / 2)) * 8u : OOB;
-                        vp[jn][h2] = ok ? (lq * W + oposf(nn, n)) * 4u : OOB;
-                        vm[jn][h2] = ok ? (lq * W + oposf(n - 1 - nn, n)) * 4u : OOB;
-                        fp[jn][h2] = nn == 0 ? ep.first : ep.base;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    double e[4][NJ][2];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned soff = (swm + 16 * i + 4 * r) * (n / 2) * 8u;
-#pragma unroll
-                        for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) {
-                                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(trr, vt[jn][h2], soff, 0);
-                                e[r][jn][h2] = __hiloint2double((int)raw[1], (int)raw[0]);
-                            }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned soff = (swm + 16 * i + 4 * r) * W * 4u;
-#pragma unroll
-                        for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-                            for (int h2 = 0; h2 < 2; ++h2) {
-                                const double a = h2 ? acc2[i][jn][r] : acc1[i][jn][r];
-                                float vpl = (float)(e[r][jn][h2] + a), vmi = (float)(e[r][jn][h2] - a);
-                                if (!plain) { vpl *= fp[jn][h2]; vmi *= ep.base; }
-                                st(vpl, vp[jn][h2], soff);
-                                st(vmi, vm[jn][h2], soff);
-                            }
-                    }
-                }
-            }
-            trace_end();
-            return;
-        }
-    }
-    if constexpr (!COLS) {
-#pragma unroll
-        for (int jn = 0; jn < NJ; ++jn) {
-            const unsigned pair = p0 + wn + 16 * jn + li;
-            if (pair >= NP) continue;
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned row = m0 + wm + 16 * i + lq + 4 * r;
-                    if (row >= L) continue;
-                    emit(po.out + (size_t)row * W, po.tmp + (size_t)row * (n / 2), po.tmp_out + (size_t)row * n, 1, pair, acc1[i][jn][r], acc2[i][jn][r]);
-                }
-        }
-    } else if constexpr (EPI == EPI_INV_E) {
-      if (po.wide) {
-        // The even half E of a two-level inverse column pass leaves unrounded, as doubles: T[pair] = a1 + a2,
-        // T[n/2-1-pair] = a1 - a2.  Same idea as below with 8-byte elements: per round 16 result rows x CW columns of
-        // one sign go through LDS (pitch CW doubles: a 16-lane ds_write_b64 group covers one 128-byte bank window)
-        // and every lane stores two doubles: 512-byte row segments instead of 128-byte ones, half the stores.
-        constexpr int CW = 16 * NI, DPR = CW / 2, RPI = 64 / DPR, NRI = 16 / RPI;   // double pairs per row, rows per read
-        static_assert(4 * 16 * CW * 8 <= (int)sizeof(lds), "transpose area");
-        __syncthreads();
-        double* tw = lds + wave * (16 * CW);
-        const unsigned wr0 = lq * CW + li;                                 // + (4 r) * CW + 16 i
-        const unsigned dq = lane % DPR, rrow = lane / DPR;
-        const unsigned line = m0 + wm + 2 * dq;                            // = frame * W + column, even
-        const bool line_ok = line < L;
-        const unsigned z = line_ok ? line / W : 0, col = line_ok ? line - z * W : 0;
-        double* tbase = po.tmp + (size_t)z * (n / 2) * W + col;
-        const double* trd = tw + rrow * CW + 2 * dq;
-        auto lds_order = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-#pragma unroll
-        for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-            for (int sign = 0; sign < 2; ++sign) {
-                lds_order();
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        tw[wr0 + (4 * r) * CW + 16 * i] = sign ? acc1[i][jn][r] - acc2[i][jn][r] : acc1[i][jn][r] + acc2[i][jn][r];
-                lds_order();
-#pragma unroll
-                for (int t = 0; t < NRI; ++t) {
-                    const unsigned pair = p0 + wn + 16 * jn + t * RPI + rrow;
-                    const f64x2 v = *reinterpret_cast<const f64x2*>(trd + t * RPI * CW);
-                    if (!line_ok || pair >= NP) continue;
-                    const unsigned idx = sign ? n / 2 - 1 - pair : pair;
-                    *reinterpret_cast<f64x2*>(tbase + (size_t)idx * W) = v;
-                }
-            }
-        trace_end();
-        return;
-      }
-    } else if constexpr (EPI == EPI_INV_OT) {
-      if (po.wide) {
-        // Deep inverse column pass: the odd part of the half-length transform, combined with its even half T2 into T --
-        // doubles out, through the same LDS transpose as EPI_INV_E (16 result rows x CW columns per round).
-        constexpr int CW = 16 * NI, DPR = CW / 2, RPI = 64 / DPR, NRI = 16 / RPI;
-        static_assert(4 * 16 * CW * 8 <= (int)sizeof(lds), "transpose area");
-        __syncthreads();
-        double* tw = lds + wave * (16 * CW);
-        const unsigned wr0 = lq * CW + li;
-        const unsigned dq = lane % DPR, rrow = lane / DPR;
-        const unsigned line = m0 + wm + 2 * dq;
-        const bool line_ok = line < L;
-        const unsigned z = line_ok ? line / W : 0, col = line_ok ? line - z * W : 0;
-        double* tbase = po.tmp_out + (size_t)z * n * W + col;
-        const double* trd = tw + rrow * CW + 2 * dq;
-        auto lds_order = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-#pragma unroll
-        for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                double e[NI][4];
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const unsigned ln = m0 + wm + 16 * i + li;
-                    const unsigned lz = ln < L ? ln / W : 0, lc = ln < L ? ln - lz * W : 0;
-                    const double* tp2 = po.tmp + (size_t)lz * (n / 2) * W + lc;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
-                        const unsigned pcl = pair < NP ? pair : 1;
-                        const unsigned nn = h2 ? po.c2 + po.cs * p2(pcl) : po.c1 + po.cs * pcl;
-                        e[i][r] = tp2[(size_t)(nn < n / 2 ? nn : 0) * W];
-                    }
-                }
-#pragma unroll
-                for (int sign = 0; sign < 2; ++sign) {
-                    lds_order();
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double a = h2 ? acc2[i][jn][r] : acc1[i][jn][r];
-                            tw[wr0 + (4 * r) * CW + 16 * i] = sign ? e[i][r] - a : e[i][r] + a;
-                        }
-                    lds_order();
-#pragma unroll
-                    for (int t = 0; t < NRI; ++t) {
-                        const unsigned pair = p0 + wn + 16 * jn + t * RPI + rrow;
-                        const f64x2 v = *reinterpret_cast<const f64x2*>(trd + t * RPI * CW);
-                        if (!line_ok || pair >= NP) continue;
-                        const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
-                        if (nn >= n / 2) continue;
-                        const unsigned idx = sign ? n - 1 - nn : nn;
-                        *reinterpret_cast<f64x2*>(tbase + (size_t)idx * W) = v;
-                    }
-                }
-            }
-        trace_end();
-        return;
-      }
-    } else {
-      if (po.wide) {
-        // Column pass, wide stores.  A D tile has the image columns along the lanes, 16 at a time: stored as it is, a
-        // wave writes 64-byte pieces (half cache lines, measured: the write traffic of such an epilogue costs the
-        // co-resident block's main loop 4 % of a column pass).  Instead each wave transposes its results through LDS
-        // -- 32 result rows x CW columns per round -- and every lane stores 16 bytes of a row: whole lines, a
-        // quarter of the store instructions and of the address arithmetic.  Same values, same rounding points.
-        constexpr int CW = 16 * NI;                                        // image columns of this wave's sub-tile
-        constexpr int TPF = (CW % 32 == 0) ? CW + 16 : CW + 32;           // row pitch in floats: odd multiple of 16 banks
-        constexpr int QPR = CW / 4, RPI = 64 / QPR, NRI = 32 / RPI;        // quads per row, rows per read, reads per round
-        static_assert(4 * 32 * TPF * 4 <= (int)sizeof(lds), "transpose area");
-        __syncthreads();                      // every wave has read its last fragments: the operand tiles are free
-        float* tw = reinterpret_cast<float*>(lds) + wave * (32 * TPF);
-        const unsigned wr0 = lq * TPF + li;                                // + (16 jn + 4 r) * TPF + 16 i
-        const unsigned q = lane % QPR, rrow = lane / QPR;
-        const unsigned line = m0 + wm + 4 * q;                             // = frame * W + column, a multiple of 4
-        const bool line_ok = line < L;
-        const unsigned z = line_ok ? line / W : 0, col = line_ok ? line - z * W : 0;
-        const size_t fbase = (size_t)z * H * W + col;                      // (frame z, row 0, col) in elements
-        const float* trd = tw + rrow * TPF + 4 * q;
-        // LDS instructions of one wave execute in order, so a read sees the writes issued before it; the fences keep
-        // the compiler from moving one across the other (it cannot see that other lanes wrote what a lane reads)
-        auto lds_order = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        };
-        const bool plain = ep.first == 1.0f && ep.base == 1.0f;            // x * 1.0f is exact: skipping it changes nothing
-        auto put_quad = [&](unsigned idx, f32x4 v) {                       // 4 columns of output row idx
-            const float f = idx == 0 ? ep.first : ep.base;
-            float y[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) y[t] = plain ? v[t] : v[t] * f;
-            const size_t px = fbase + (size_t)idx * W;
-            if (EPI == EPI_INV_O_RGB) pair_store_rgb_quad<double>(po, px, y);
-            else *reinterpret_cast<f32x4*>(po.out + px) = (f32x4){y[0], y[1], y[2], y[3]};
-        };
-        if (EPI == EPI_FWD || EPI == EPI_INV) {
-#pragma unroll
-            for (int set = 0; set < 2; ++set) {
-                lds_order();
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double a1 = acc1[i][jn][r], a2 = acc2[i][jn][r];
-                            const float v = EPI == EPI_FWD ? (float)(set ? a2 : a1) : (float)(set ? a1 - a2 : a1 + a2);
-                            tw[wr0 + (16 * jn + 4 * r) * TPF + 16 * i] = v;
-                        }
-                lds_order();
-#pragma unroll
-                for (int t = 0; t < NRI; ++t) {
-                    const unsigned pair = p0 + wn + t * RPI + rrow;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
-                    if (!line_ok || pair >= NP) continue;
-                    const unsigned idx = EPI == EPI_FWD ? (set ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair) : (set ? n - 1 - pair : pair);
-                    if (EPI == EPI_FWD && (set ? (pair < po.p2lo || !second_out) : pair >= po.np1)) continue;
-                    put_quad(idx, v);
-                }
-            }
-        } else {
-            // EPI_INV_O / EPI_INV_O_RGB: x[n1] = E[n1] + a1, x[n-1-n1] = E[n1] - a1, x[n2] = E[n2] + a2, x[n-1-n2] = E[n2] - a2
-            // (n1 = pair, n2 = pair + n/4); a round = 16 pairs: the "+" rows in staging rows 0..15, the "-" rows in 16..31
-            const double* tpl = po.tmp + (size_t)z * (n / 2) * W + (m0 + wm - z * W);      // + row * W + 16 i + li, own frame only
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) {
-                    double e[NI][4];
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) {
-                        const unsigned ln = m0 + wm + 16 * i + li;
-                        const unsigned lz = ln < L ? ln / W : 0, lc = ln < L ? ln - lz * W : 0;
-                        const double* tp = po.tmp + (size_t)lz * (n / 2) * W + lc;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
-                            const unsigned pc = pair < NP ? pair : 0;
-                            const unsigned nn = half ? po.c2 + po.cs * p2(pc) : po.c1 + po.cs * pc;
-                            e[i][r] = tp[(size_t)(nn < n / 2 ? nn : 0) * W];
-                        }
-                    }
-                    (void)tpl;
-                    lds_order();
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const double a = half ? acc2[i][jn][r] : acc1[i][jn][r];
-                            tw[wr0 + (4 * r) * TPF + 16 * i] = (float)(e[i][r] + a);
-                            tw[wr0 + (16 + 4 * r) * TPF + 16 * i] = (float)(e[i][r] - a);
-                        }
-                    lds_order();
-#pragma unroll
-                    for (int t = 0; t < NRI; ++t) {
-                        const unsigned srow = t * RPI + rrow;                        // staging row: [0, 16) plus, [16, 32) minus
-                        const unsigned pair = p0 + wn + 16 * jn + (srow & 15);
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
-                        if (!line_ok || pair >= NP) continue;
-                        const unsigned nn = half ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
-                        if (nn >= n / 2) continue;
-                        put_quad(srow < 16 ? nn : n - 1 - nn, v);
-                    }
-                }
-        }
-        trace_end();
-        return;
-      }
-    }
-    if constexpr (COLS) {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const unsigned line = m0 + wm + 16 * i + li;       // = frame * W + column
-            if (line >= L) continue;
-            const unsigned z = line / W, col = line - z * W;
-            float* lp = po.out + (size_t)z * H * W + col;
-            double* tp = po.tmp + (size_t)z * (n / 2) * W + col;
-            if (EPI == EPI_INV_O_RGB) {
-                // Writer::result in the last pass: per pair, its 4 output rows -- the even-half values of two pairs, then
-                // I and Q of a pair's four pixels, are loaded together (deeper batches spill: 198 VGPRs as it is);
-                // offsets from the frame's pixel (row 0, col) address I, Q and RGB alike
-                const size_t base = (size_t)z * H * W + col;
-#pragma unroll
-                for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {
-                        double e1[2], e2[2];
-                        bool ok1[2], ok2[2];
-                        unsigned m1[2], m2[2];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const unsigned pair = p0 + wn + 16 * jn + lq + 4 * (r + q);
-                            const unsigned pc = pair < NP ? pair : 0;
-                            const unsigned n1 = po.c1 + po.cs * pc, n2 = po.c2 + po.cs * p2(pc);
-                            ok1[q] = pair < NP && n1 < n / 2;
-                            ok2[q] = pair < NP && n2 < n / 2;
-                            m1[q] = ok1[q] ? n1 : 0;
-                            m2[q] = ok2[q] ? n2 : 0;
-                            e1[q] = tp[(size_t)m1[q] * W];
-                            e2[q] = tp[(size_t)m2[q] * W];
-                        }
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const double a1 = acc1[i][jn][r + q], a2 = acc2[i][jn][r + q];
-                            const unsigned idx1[2] = {m1[q], n - 1 - m1[q]}, idx2[2] = {m2[q], n - 1 - m2[q]};
-                            const float v1[2] = {(float)(e1[q] + a1), (float)(e1[q] - a1)}, v2[2] = {(float)(e2[q] + a2), (float)(e2[q] - a2)};
-                            unsigned px1[2], px2[2];
-                            float y1[2], y2[2];
-#pragma unroll
-                            for (int o = 0; o < 2; ++o) {
-                                px1[o] = idx1[o] * W; y1[o] = apply_epilogue(ep, v1[o], idx1[o]);
-                                px2[o] = idx2[o] * W; y2[o] = apply_epilogue(ep, v2[o], idx2[o]);
-                            }
-                            pair_store_rgb_batch<double, 2>(po, base, px1, y1, ok1[q]);
-                            pair_store_rgb_batch<double, 2>(po, base, px2, y2, ok2[q]);
-                        }
-                    }
-                continue;
-            }
-#pragma unroll
-            for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const unsigned pair = p0 + wn + 16 * jn + lq + 4 * r;
-                    if (pair >= NP) continue;
-                    emit(lp, tp, po.tmp_out + (size_t)z * n * W + col, W, pair, acc1[i][jn][r], acc2[i][jn][r]);
-                }
-        }
-    }
-    trace_end();
-    };
-    // (a tail of at most 16 pairs -- 270 = 4 x 64 + 14 at full HD, the 16-pair classes of the pruned transform -- runs
-    // one 16-pair MFMA tile per wave instead of two)
-    // (row passes: a tail of 33 .. 48 pairs -- 240 = 3 x 64 + 48: every launch of a 4K row pass -- runs three per wave on
-    // the 4 x 1 grid: three quarters of a full tile's MFMAs)
-    using J1 = std::integral_constant<int, 1>;
-    using J2 = std::integral_constant<int, 2>;
-    using J3 = std::integral_constant<int, 3>;
-    if (NP - p0 <= 16)                 run(std::integral_constant<int, BM / 64>{}, J1{});
-    else if (NP - p0 <= 32 || po.bn32) run(std::integral_constant<int, BM / 64>{}, J2{});
-    else if (!COLS && BM == 128 && NP - p0 <= 48) run(std::integral_constant<int, BM / 64>{}, J3{});
-    else                               run(std::integral_constant<int, BM / 32>{}, J2{});
-}
+namespace ssw {
 
 
 // One launch of the operand-ready GEMM.  `kind` selects the epilogue:
@@ -875,11 +77,6 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
 // sub (forward only): the launch belongs to the transform of length len >> sub that a deeper folding level
 // applies to the even part (its frequencies are multiples of 2^sub of the full transform's).
 namespace {
-// what selects the template instance of a class: all classes of a launch must agree
-struct PairInstance {
-    int epi; bool samex; int subname;
-    bool operator==(const PairInstance& o) const { return epi == o.epi && samex == o.samex && subname == o.subname; }
-};
 
 // the per-class part of a launch: pair count, sum length, basis lines and the output map of (kind, sub)
 int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t len, bool class_major, bool with_sink, bool has_tmp_out,
@@ -1051,20 +248,7 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
         else if (inst.samex) SSW_LAUNCH_ROWCOL(EPI_FWD, true);
         else SSW_LAUNCH_ROWCOL(EPI_FWD, false);
         break;
-    case EPI_INV: SSW_LAUNCH_ROWCOL(EPI_INV, false); break;
-    case EPI_INV_E: SSW_LAUNCH_ROWCOL(EPI_INV_E, false); break;
-    case EPI_INV_OT:
-        if (inst.samex) { if (is_row) return SSW_ERR_BAD_ARG; SSW_LAUNCH_PAIR_SUB(true, EPI_INV_OT, true, 1); }
-        else if (is_row) SSW_LAUNCH_PAIR_SUB(false, EPI_INV_OT, false, 1);
-        else SSW_LAUNCH_PAIR_SUB(true, EPI_INV_OT, false, 1);
-        break;
-    case EPI_INV_O_RGB:
-        if (inst.samex) SSW_LAUNCH_PAIR_SUB(true, EPI_INV_O_RGB, true, 0); else SSW_LAUNCH_PAIR_SUB(true, EPI_INV_O_RGB, false, 0);
-        break;
-    case EPI_INV_O:
-        if (inst.samex) SSW_LAUNCH_ROWCOL(EPI_INV_O, true); else SSW_LAUNCH_ROWCOL(EPI_INV_O, false);
-        break;
-    default: return SSW_ERR_BAD_ARG;
+    default: return launch_pair_gemm_inverse_instances(st, ml, ep, inst, is_row, small, nblk);
     }
 #undef SSW_LAUNCH_ROWCOL
 #undef SSW_LAUNCH_PAIR

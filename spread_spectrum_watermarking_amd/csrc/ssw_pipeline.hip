@@ -185,6 +185,7 @@ size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames) 
         c = std::max<size_t>(1, ((size_t)1 << 30) / px);
         const size_t per_frame = dct_pair_operand_elems(true, 1, w, h) * sizeof(double);
         if (per_frame) c = std::max<size_t>(1, std::min(c, (size_t)0xFFFFFFFFull / per_frame));
+        if (c >= 16) c &= ~(size_t)7;              // whole groups of 8 frames (4K: 129 -> 128: the GEMM line tiles stay whole)
         c = std::min(c, std::max<size_t>(n_frames, 1));
         size_t free_b = 0, total_b = 0;
         DeviceGuard g(ctx->device);

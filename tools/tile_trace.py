@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Diagnostic (library built with -DSSW_TILE_TRACE): per-tile phase times of the operand-ready f64 GEMMs.
-usage: python tools/tile_trace.py [W H FRAMES forward|inverse]"""
+Build (in csrc/, next to the normal objects): compile dct_pair_f64.hip and ssw_lib.hip with the Makefile's flags plus
+-DSSW_TILE_TRACE into other object files and link them with the remaining objects EXCEPT dct_pair_f64.o, ssw_lib.o and
+dct_pair_f64_inv*.o (the diagnostic build keeps all GEMM instances in one unit) into e.g. build_tmp/libssw_trace.so; run with
+SSW_LIB_PATH pointing at it.
+usage: SSW_LIB_PATH=... python tools/tile_trace.py [W H FRAMES forward|inverse]"""
 import ctypes
 import os
 import sys
