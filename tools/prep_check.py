@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """A/B check of the LDS-staged deep pre-passes (csrc/dct_pair_prep_staged.hip, class-major tiles) against the r3 kernels
 (SSW_PREP_STAGED=0 SSW_CLASS_TILE=0): the same operations per operand element, so forward and inverse transforms of the
-same planes must agree bit for bit.  Each variant runs in its own process (the switches are read once).
+same planes must agree bit for bit.  Each variant runs in its own process (the switches are read once).  All variants run
+at LEVEL 1 (SSW_EFOLD_MIN / SSW_EFOLD_INV_MIN / SSW_EFOLD_COLS_MIN out of reach): the level-2 passes (r4b / r4c) exist in the
+staged form only and round differently (one more rotation); tools/level2_check.py holds them against the oracle.
 usage: python tools/prep_check.py            # compare
        python tools/prep_check.py dump       # one variant: sha256 of every result (internal)"""
 import hashlib
@@ -58,9 +60,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dump":
         dump()
         sys.exit(0)
-    new = run_variant({})
-    old = run_variant({"SSW_PREP_STAGED": "0", "SSW_CLASS_TILE": "0"})
-    mid = run_variant({"SSW_PREP_STAGED": "0"})          # r3 kernels on the tiled class-major order
+    l1 = {"SSW_EFOLD_MIN": "1000000", "SSW_EFOLD_INV_MIN": "1000000", "SSW_EFOLD_COLS_MIN": "1000000"}
+    new = run_variant(dict(l1))
+    old = run_variant(dict(l1, SSW_PREP_STAGED="0", SSW_CLASS_TILE="0"))
+    mid = run_variant(dict(l1, SSW_PREP_STAGED="0"))          # r3 kernels on the tiled class-major order
     bad = 0
     for k in new:
         flag = "ok" if new[k] == old[k] == mid[k] else "MISMATCH"
