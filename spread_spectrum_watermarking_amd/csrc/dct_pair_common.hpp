@@ -66,7 +66,8 @@ struct PairOutT {
     // n/8 -- whose outputs are acc1 (as the first output of pair 0) and -acc2 (as the second output of pair n/8)
     unsigned fold0 = 0;
     T* tmp_out = nullptr;     // EPI_INV_OT
-    unsigned cm = 0;          // inverse row pass: output line (and the E plane) in class-major order (inverse_class_pos)
+    unsigned cm = 0;          // inverse row pass: output line (and the E plane) in class-major order (inverse_class_pos): 1 mod 4, 2 mod 8
+    unsigned tcm = 0;         // EPI_INV_OT, row pass: `tmp` (T2) is read in the mod-4 class-major order (level 2: the launch that wrote it had cm = 1)
     unsigned cmt = 0;         // ... the output line inside tiles of cmt positions (the E planes: one tile)
     // forward row pass, class-major inside tiles of ft memory columns (ft != 0): entry e = pair (output 1) or
     // p2(pair) - e2off (output 2) of its class goes to column c + (e >> gsh) * ft + (e & ((1 << gsh) - 1)); gsh = log2 of the

@@ -132,7 +132,7 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
         // dct_pair_common.hpp) instead of 4-byte pieces 16 / 32 bytes apart -- the column pre-pass puts the columns back;
         // inverse: the split classes write (and read E) at one pair of residues mod 4 (po.cm, inverse_class_pos), the
         // quarter-length even half T2 (kind 1) keeps the natural order
-        if (!is_row || !((kind == 1 && sub >= 1) || split) || sub > 2 || (sub == 2 && kind != 1)) return SSW_ERR_BAD_ARG;
+        if (!is_row || !((kind == 1 && sub >= 1) || split) || sub > 2 || (sub == 2 && kind != 1 && !(inverse && kind == 9))) return SSW_ERR_BAD_ARG;
         if (!inverse) {
             // po.ft = the tile: entry e of a class -> column base + (e >> gsh) * ft + (e & (2^gsh - 1)); class E's second
             // output of pair p is entry p - 1 of its "-" class (frequency 8 p - 1)
@@ -226,6 +226,10 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)(inverse ? leff0 : len), 0, 1, 2};
     po.tmp_out = tmp_out;
     if (class_major && inverse && desc[0].kind >= 3 && desc[0].kind <= 8) { po.cm = dct_pair_efold_inv(len) ? 2u : 1u; po.cmt = dct_pair_class_tile(len); }
+    // level 2: T2 (written by kind 9, read by the half-length launches, kinds 3 / 4 sub 1) keeps the mod-4 class order, so
+    // that those launches read runs instead of two doubles of every four
+    if (class_major && inverse && desc[0].kind == 9) po.cm = 1;
+    if (class_major && inverse && is_row && dct_pair_efold_inv(len) && (desc[0].kind == 3 || desc[0].kind == 4) && desc[0].sub == 1) po.tcm = 1;
     if (class_major && !inverse) po.ft = dct_pair_class_tile(len);
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16)) && (!tmp_out || al(tmp_out, 16))) ? 1u : 0u;

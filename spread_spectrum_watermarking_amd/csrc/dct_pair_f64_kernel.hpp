@@ -377,6 +377,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     // element offsets idx * es stay below 2^32 (W * H < 2^32: indices are u32 throughout)
     // position of element m of a line of length len: natural, or class-major on the row pass of a deep inverse transform
     auto opos = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len, 0, po.cm == 2) : m; };
+    // ... of T2 as EPI_INV_OT reads it (length n/2): natural, or mod-4 class-major (po.tcm)
+    auto tpos = [&](unsigned m) { return (!COLS && po.tcm) ? inverse_class_pos(m, n / 2, 0, false) : m; };
     // ... of the f32 output line (class-major inside tiles of po.cmt positions; the E planes above: one tile)
     auto oposf = [&](unsigned m, unsigned len) { return (!COLS && po.cm) ? inverse_class_pos(m, len, po.cmt, po.cm == 2) : m; };
     // forward outputs of a pair: natural c + cs pair, or the class-major column of its entry (PairOutT::ft)
@@ -405,8 +407,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
             tp[(n / 2 - 1 - pair) * es] = a1 - a2;
         } else if (EPI == EPI_INV_OT) {
             const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * p2(pair);
-            if (n1 < n / 2) { const double e1 = tp[n1 * es]; to[opos(n1, n) * es] = e1 + a1; to[opos(n - 1 - n1, n) * es] = e1 - a1; }
-            if (n2 < n / 2) { const double e2 = tp[n2 * es]; to[opos(n2, n) * es] = e2 + a2; to[opos(n - 1 - n2, n) * es] = e2 - a2; }
+            if (n1 < n / 2) { const double e1 = tp[tpos(n1) * es]; to[opos(n1, n) * es] = e1 + a1; to[opos(n - 1 - n1, n) * es] = e1 - a1; }
+            if (n2 < n / 2) { const double e2 = tp[tpos(n2) * es]; to[opos(n2, n) * es] = e2 + a2; to[opos(n - 1 - n2, n) * es] = e2 - a2; }
         } else {
             const unsigned n1 = po.c1 + po.cs * pair, n2 = po.c2 + po.cs * p2(pair);      // positions in the odd part, < n/2
             if (n1 < n / 2) {
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                     for (int h2 = 0; h2 < 2; ++h2) {
                         const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
                         const bool ok = pair < NP && nn < n / 2;
-                        vt[jn][h2] = ok ? (lq * (n / 2) + nn) * 8u : OOB;
+                        vt[jn][h2] = ok ? (lq * (n / 2) + tpos(nn)) * 8u : OOB;
                         vp[jn][h2] = ok ? (lq * n + opos(nn, n)) * 8u : OOB;
                         vm[jn][h2] = ok ? (lq * n + opos(n - 1 - nn, n)) * 8u : OOB;
                     }

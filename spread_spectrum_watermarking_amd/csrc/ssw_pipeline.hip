@@ -545,7 +545,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 ch.push_back({false, [=](hipStream_t st) -> int {
                     StageTimer t(ctx, st_pass, st, f_all);
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &da, dst, (double*)A1, n, w, h, ep));
-                    SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &db, dst, (double*)A1, n, w, h, ep, nullptr, (double*)T2));
+                    SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &db, dst, (double*)A1, n, w, h, ep, nullptr, (double*)T2, rcm));
                     if (lines <= merge_max_lines()) {          // single frames: the classes of each dependent stage in one launch
                         SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d1, dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
                         return launch_dct_pair_gemm_multi_f64(st, is_row, true, 4, d0, dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm);
