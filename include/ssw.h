@@ -161,7 +161,9 @@ int ssw_ctx_get_prune_stats(ssw_ctx* ctx, uint64_t* stats);
 /* Top-k selection (the first k entries of the ordering of src/algorithm.rs:200-280): stats[0] frames selected, [1] of
    those whose sampled threshold left fewer than k or more than the candidate buffer's survivors, so that the finish ran
    the exact select over the whole plane (same result, one CU sorting the plane: a latency cliff; massive ties and
-   constant planes take it by design, images should not); since the last ssw_ctx_reset_timing.  Synchronises. */
+   constant planes take it by design, images should not); since the last ssw_ctx_reset_timing.  Synchronises.
+   stats[0] is counted when a call enqueues its selection (replays of a captured graph are not counted), stats[1] on
+   the device. */
 int ssw_ctx_get_select_stats(ssw_ctx* ctx, uint64_t* stats);
 
 /* Even/odd folding of the basis GEMMs (fewer multiply-adds for the same transform; exact in f64,
@@ -195,6 +197,25 @@ int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int level);
    (tests/test_gpu_parity.py::test_odd_split_matches_exact_operands).  Default on; 0 = every operand an exact sum
    (the round-2 arithmetic, 1.8x the multiply-adds). */
 int ssw_ctx_set_odd_split(ssw_ctx* ctx, int enable);
+
+/* Strategy thresholds and A/B switches of the transform, process-wide (csrc/tuning.hip).  They choose between kernels that
+   compute the same values (the strategies of src/dct2d.rs:83-219's one transform), never between results; tests lower a
+   threshold so that small shapes the oracle finishes in seconds take the kernels of the 4K path.  Names (default):
+     efold_min (1280), efold_inv_min (1280), efold_cols_min (720)   shortest forward row / inverse row / column pass at level 2
+     deep_min_rows (256), deep_min_cols (256)                       shortest pass that takes the deep pre-passes
+     class_tile (1)        class-major planes inside tiles of 128 columns (0: one tile per line)
+     prep_staged (1)       LDS-staged pre-passes (0: the r3 kernels)
+     merge_max_lines (8192) passes of at most this many lines run a stage's launches as one
+     bn32 (-1)             32-pair tiles for small single-class launches: -1 automatic, 0 / 1 forced
+     band_split (1)        single-image handles: row pass of the top half beside the upload of the bottom half
+     fuse_cols (1)         forward transform: the row GEMMs' epilogue writes the column operands (no f32 plane between the passes)
+   An entry never set reads its SSW_<NAME> environment variable at first use (the r4 behaviour), else the default.
+   ssw_tuning_set takes effect for the calls that follow; workspaces and cached plans of existing contexts were sized
+   under the old values, so change a value before creating the context that should see it (tests use a fresh context).
+   ssw_tuning_reset(NULL) returns every entry to environment / default.  Unknown name: SSW_ERR_BAD_ARG. */
+int ssw_tuning_set(const char* name, long long value);
+int ssw_tuning_get(const char* name, long long* value);
+int ssw_tuning_reset(const char* name);
 
 /* Per-stage device timers (hipEvent pairs on the context's stream).  DCT_ROW / DCT_COL cover the
    GEMM launches of a pass; at folding levels 3 / 4 the pre-passes are timed separately (DCT_PREP). */
@@ -356,9 +377,13 @@ int ssw_batch_extract_rgb16(ssw_ctx* ctx, const ssw_config* cfg, const uint16_t*
    into_rgb8) and :383-415 (`test`: per image Reader::base / derived -> extract -> Tester::similarity) -- as ONE call over
    n 8-bit host images [h][w][3] (frames[i]: one pointer per image; pinned buffers -- ssw_host_alloc, hipHostRegister --
    are the DMA source / target themselves, any other buffer goes through the context's staging ring): the images go
-   through ssw_batch_embed_rgb8 / ssw_batch_extract_rgb8 in groups of >= 8 frames, the upload of group g + 1, the
-   kernels of group g and the download of group g - 1 in flight together (csrc/ssw_stream.hip).  Bit-identical to the
-   single-image handles.  Host-buffer entry points: they return when every buffer is the caller's again.
+   through ssw_batch_embed_rgb8 / ssw_batch_extract_rgb8 in groups of frames (G = 8 4K frames by default; a call ramps
+   up through groups of G/4 and G/2 frames, embed ramps down again), the upload of group g + 1, the kernels of group g
+   and the download of group g - 1 in flight together (csrc/ssw_stream.hip).  The output side overlaps fully only
+   with pinned output buffers (a pageable buffer is filled by a blocking staged copy; it is issued after the next
+   group's kernels are queued, so the device keeps working, but the host thread sleeps in it).  The device ring of a
+   call (3 slots x 2 buffers of G frames) stays allocated until ssw_ctx_destroy or until an allocation of the context
+   runs short of device memory.  Bit-identical to the single-image handles.  Host-buffer entry points: they return when every buffer is the caller's again.
    host_marks: [n][k] f32 (mark i for frame i); extract: host_marks and host_sims both or neither (NULL). */
 int ssw_batch_embed_host_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* const* host_frames, size_t n_frames,
                               size_t w, size_t h, const float* host_marks, size_t k, uint8_t* const* host_out);

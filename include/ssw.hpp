@@ -345,7 +345,9 @@ inline ExtractedMany extract_many(Context& ctx, const std::vector<const ImageRgb
     std::vector<const uint8_t*> bp(n), dp(n);
     std::vector<float> m(marks.empty() ? 0 : n * k), ext(n * k), sims(marks.empty() ? 0 : n);
     for (size_t i = 0; i < n; ++i) {
-        if (base[i]->width != w || base[i]->height != h || derived[i]->width != w || derived[i]->height != h) throw Error(SSW_ERR_BAD_DIMS, "extract_many");
+        if (base[i]->width != w || base[i]->height != h || derived[i]->width != w || derived[i]->height != h ||
+            base[i]->data.size() != w * h * 3 || derived[i]->data.size() != w * h * 3)
+            throw Error(SSW_ERR_BAD_DIMS, "extract_many");
         bp[i] = base[i]->data.data(); dp[i] = derived[i]->data.data();
         if (!marks.empty()) {
             if (marks[i]->data().size() != k) throw Error(SSW_ERR_LENGTH_MISMATCH, "extract_many");

@@ -61,6 +61,9 @@ SIGNATURES = {
     "ssw_ctx_set_overlap": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_set_prune": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_set_odd_split": (C.c_int, [_vp, C.c_int]),
+    "ssw_tuning_set": (C.c_int, [C.c_char_p, C.c_longlong]),
+    "ssw_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_longlong)]),
+    "ssw_tuning_reset": (C.c_int, [C.c_char_p]),
     "ssw_ctx_get_prune_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ssw_ctx_get_select_stats": (C.c_int, [_vp, C.POINTER(C.c_uint64)]),
     "ssw_dev_mem_info": (C.c_int, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),

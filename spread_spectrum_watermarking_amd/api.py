@@ -196,6 +196,32 @@ class DeviceBuffer:
 _default_ctx: Optional[Context] = None
 
 
+class tuning:
+    """Process-wide strategy thresholds / A-B switches (include/ssw.h: ssw_tuning_set).  `with tuning(efold_min=256): ...`
+    sets them for the block and restores the previous state; use a fresh Context inside (workspaces and cached plans of an
+    existing context were built under the old values)."""
+
+    def __init__(self, **values):
+        self._values = values
+        self._lib = L.load()
+
+    @staticmethod
+    def get(name: str) -> int:
+        v = C.c_longlong()
+        check(L.load().ssw_tuning_get(name.encode(), C.byref(v)), "ssw_tuning_get")
+        return int(v.value)
+
+    def __enter__(self):
+        for name, v in self._values.items():
+            check(self._lib.ssw_tuning_set(name.encode(), int(v)), f"ssw_tuning_set({name})")
+        return self
+
+    def __exit__(self, *exc):
+        for name in self._values:
+            self._lib.ssw_tuning_reset(name.encode())
+        return False
+
+
 def default_context() -> Context:
     global _default_ctx
     if _default_ctx is None or _default_ctx.handle is None:
@@ -494,6 +520,9 @@ def mark_many(images, marks, config: Optional[WriteConfig] = None, ctx: Optional
         raise ValueError("one mark of equal length per image")
     if out is None:
         out = [np.empty((h, w, 3), np.uint8) for _ in arrs]
+    out = list(out)
+    if len(out) != len(arrs):                   # the C side reads one output pointer per input frame
+        raise ValueError("out: one output array per image")
     for o in out:
         if o.dtype != np.uint8 or o.shape != (h, w, 3) or not o.flags.c_contiguous:
             raise ValueError("out: contiguous u8 [H, W, 3] arrays")
@@ -510,9 +539,9 @@ def extract_many(base_images, derived_images, k: int, marks=None, config: Option
     ctx = ctx or default_context()
     config = config or ReadConfig.default()
     ba, bp, w, h = _frame_ptrs(base_images)
-    da, dp, _, _ = _frame_ptrs(derived_images, w, h)
-    if len(ba) != len(da):
+    if len(derived_images) != len(ba):          # checked before any pointer array is handed to the C side
         raise ValueError("one derived image per base image")
+    da, dp, _, _ = _frame_ptrs(derived_images, w, h)
     n = len(ba)
     ext = np.empty((n, k), np.float32)
     m = sims = None

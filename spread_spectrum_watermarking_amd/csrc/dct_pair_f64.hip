@@ -214,7 +214,7 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     // resident at once, so a launch takes as long as the fullest CU): balance = blocks / (256 * ceil(blocks / 256)); the
     // smaller tiles reuse their basis fragments less, hence the 8 % handicap
     if (small && n_classes == 1) {
-        static const int force = [] { const char* e = std::getenv("SSW_BN32"); return e ? std::atoi(e) : -1; }();
+        const int force = (int)tuning(TUNE_BN32);
         auto balance = [](unsigned long long n) { return (double)n / (256.0 * (double)((n + 255) / 256)); };
         const unsigned tn32 = (ml.c[0].NP + 31) / 32;
         const bool bn32 = force >= 0 ? force != 0 : 0.92 * balance((unsigned long long)tiles_m * tn32) > balance((unsigned long long)tiles_m * tiles_n);

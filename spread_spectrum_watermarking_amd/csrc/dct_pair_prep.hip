@@ -93,25 +93,25 @@ __global__ void make_rot_table_kernel(size_t n, double* out) {
 // class-major; in the natural order every launch writes 4-byte pieces 64 bytes apart (1080p before r4c: such launches took
 // 1.0 ms for 16 GFLOP).  SSW_EFOLD_MIN: A/B switch (minimum length).
 bool dct_pair_efold(size_t len) {
-    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_MIN"); return e ? (size_t)std::atoll(e) : (size_t)1280; }();
+    const size_t mn = (size_t)tuning(TUNE_EFOLD_MIN);
     return dct_pair_can_deep_rows(len) && len >= mn;
 }
 // Inverse row passes of 1280 columns or more run at level 2 as well (r4c): the odd part's classes and the
 // quarter-length even part fold / rotate once more (dct_pair_prep_staged.hip, prep16_inv_rows_l2_kernel).
 // SSW_EFOLD_INV_MIN: A/B switch (minimum length).
 bool dct_pair_efold_inv(size_t len) {
-    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_INV_MIN"); return e ? (size_t)std::atoll(e) : (size_t)1280; }();
+    const size_t mn = (size_t)tuning(TUNE_EFOLD_INV_MIN);
     return dct_pair_can_deep_inv_rows(len) && dct_pair_prep_staged_rows_ok() && len >= mn;      // (len % 128 == 0: can_deep_inv_rows)
 }
 // Column passes of 720 rows or more (a multiple of 16) run at level 2 in both directions (r4c; the staged pre-passes only):
 // launches of K = H/16 = 135 at 4K run at 50 TFLOP/s against 64 for K = 270, but do half the multiply-adds (measured a gain
 // from 1280 x 720 up).  SSW_EFOLD_COLS_MIN: A/B switch.
 bool dct_pair_efold_cols(size_t h, size_t w, bool class_major) {
-    static const size_t mn = [] { const char* e = std::getenv("SSW_EFOLD_COLS_MIN"); return e ? (size_t)std::atoll(e) : (size_t)720; }();
+    const size_t mn = (size_t)tuning(TUNE_EFOLD_COLS_MIN);
     return dct_pair_can_deep_cols(h) && dct_pair_prep_staged_cols_ok(w, class_major) && h >= mn;
 }
 unsigned dct_pair_class_tile(size_t len) {
-    static const int one_tile = [] { const char* e = std::getenv("SSW_CLASS_TILE"); return (e && std::atoi(e) == 0) ? 1 : 0; }();
+    const bool one_tile = tuning(TUNE_CLASS_TILE) == 0;
     return one_tile ? (unsigned)len : class_tile((unsigned)len);
 }
 bool dct_pair_can_split(size_t len, bool is_row) { (void)is_row; return len % 8 == 0 && len >= 128; }
@@ -1328,11 +1328,7 @@ int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t
 
 // deep forward row pre-pass: src_kind 0 = f32 plane, 1 / 2 = interleaved RGB f32 / u8 (ip / qp: I, Q planes out or null);
 // base: 6 planes of lines * K8 doubles (AS BD AD BS R1 R2) followed by 4 planes of lines * K16 (AS2 BD2 AD2 BS2)
-static size_t deep_min(const char* name, size_t dflt) {           // experiment switch: minimum length for the deep split
-    const char* e = std::getenv(name);
-    return e ? (size_t)std::atoll(e) : dflt;
-}
-bool dct_pair_can_deep_rows(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_ROWS", 256); return len % 64 == 0 && len >= mn; }
+bool dct_pair_can_deep_rows(size_t len) { const size_t mn = (size_t)tuning(TUNE_DEEP_MIN_ROWS); return len % 64 == 0 && len >= mn; }
 // 6 planes K8 wide + 4 K16 wide, or (forward row passes at level 2) 16 planes K16 wide
 size_t dct_pair_deep_elems(size_t lines, size_t len) {
     const size_t k8 = dct_pair_split_kpad(len), k16 = dct_pair_split_kpad(len / 2);
@@ -1375,9 +1371,9 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
 }
 
 // deep forward column pre-pass (H % 16 == 0): same plane order as the row version, lines = n_frames * w
-bool dct_pair_can_deep_cols(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_COLS", 256); return len % 16 == 0 && len >= mn; }
+bool dct_pair_can_deep_cols(size_t len) { const size_t mn = (size_t)tuning(TUNE_DEEP_MIN_COLS); return len % 16 == 0 && len >= mn; }
 // semi-deep: H % 8 == 0 but not % 16 (1080 rows): D split, SS folded a third time, SD left whole
-bool dct_pair_can_semi_deep_cols(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_COLS", 256); return len % 8 == 0 && len % 16 != 0 && len >= mn; }
+bool dct_pair_can_semi_deep_cols(size_t len) { const size_t mn = (size_t)tuning(TUNE_DEEP_MIN_COLS); return len % 8 == 0 && len % 16 != 0 && len >= mn; }
 size_t dct_pair_semi_deep_elems(size_t lines, size_t len) { return lines * (6 * dct_pair_split_kpad(len) + pair_kpad<double>(len / 2)); }
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                 const double* rot1, const double* rot2, bool class_major, const double* rot3) {
@@ -1411,7 +1407,7 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
 }
 
 // deep inverse pre-passes: same plane order (AS BD AD BS R1 R2 | AS2 BD2 AD2 BS2) with R1 = c[8q], R2 = c[8q+4]
-bool dct_pair_can_deep_inv_rows(size_t len) { static const size_t mn = deep_min("SSW_DEEP_MIN_ROWS", 256); return len % 128 == 0 && len >= mn && len <= 128 * 256; }
+bool dct_pair_can_deep_inv_rows(size_t len) { const size_t mn = (size_t)tuning(TUNE_DEEP_MIN_ROWS); return len % 128 == 0 && len >= mn && len <= 128 * 256; }
 static DeepPlanes deep_planes(double* base, size_t lines, size_t len) {
     const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
     DeepPlanes dp;

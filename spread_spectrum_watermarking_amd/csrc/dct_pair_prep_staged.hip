@@ -931,8 +931,7 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_l2_kernel(const float* __
 }
 
 bool staged_enabled() {
-    static const int on = [] { const char* e = std::getenv("SSW_PREP_STAGED"); return e ? std::atoi(e) : 1; }();
-    return on != 0;
+    return tuning(TUNE_PREP_STAGED) != 0;
 }
 
 DeepPlanes planes_of(double* base, size_t lines, unsigned K8, unsigned K16) {

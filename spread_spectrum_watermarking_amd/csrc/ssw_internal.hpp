@@ -141,6 +141,10 @@ int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1,
 // 2 cosO, 3 sinO), the rotation table of an axis, and the pass that turns an odd operand plane into AS | BD | AD | BS
 bool dct_pair_can_split(size_t len, bool is_row);
 size_t dct_pair_split_kpad(size_t len);
+// tuning.hip: the process-wide table of strategy thresholds / A-B switches (ssw_tuning_set, include/ssw.h)
+enum { TUNE_EFOLD_MIN, TUNE_EFOLD_INV_MIN, TUNE_EFOLD_COLS_MIN, TUNE_CLASS_TILE, TUNE_DEEP_MIN_ROWS, TUNE_DEEP_MIN_COLS, TUNE_PREP_STAGED,
+       TUNE_MERGE_MAX_LINES, TUNE_BN32, TUNE_BAND_SPLIT, TUNE_FUSE_COLS, TUNE_COUNT };
+long long tuning(int which);
 unsigned dct_pair_class_tile(size_t len);               // tile width of the class-major plane orders (dct_pair_common.hpp)
 bool dct_pair_efold(size_t len);                        // forward row passes of this length run at level 2 (r4b)
 bool dct_pair_efold_inv(size_t len);                    // inverse row passes of this length run at level 2 (r4c)
@@ -189,14 +193,15 @@ int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const f
 // v is in the class when v % mod == rem, or == rem2 (classes of the split odd half: there the output is the cosine
 // part MINUS the sine part and the gathered sine row is negated); basis row (v + radd) / mod
 constexpr unsigned PRUNE_NO_REM = 0xFFFFFFFFu;
-constexpr uint32_t PRUNE_NEG = 0x40000000u;
-constexpr unsigned SSW_PRUNE_INFO = 16;                  // u32 words of a chunk's info block: [0] overflow flag, [1 + c] members of class c              // rows[] flag: negate the gathered sine row
+constexpr uint32_t PRUNE_NEG = 0x40000000u;              // rows[] flag: negate the gathered sine row
+constexpr unsigned SSW_PRUNE_INFO = 16;                  // u32 words of a chunk's info block: [0] overflow flag, [1 + c] members of class c
 struct PruneClass { unsigned mod, rem, cap, off, rem2 = PRUNE_NO_REM, radd = 0; };
 struct PrunePlan {
     unsigned n_classes = 0;
     PruneClass c[9];        // info[] of launch_prune_build: SSW_PRUNE_INFO words, 1 + one per class
     unsigned W = 0, cap_total = 0;
 };
+static_assert(SSW_PRUNE_INFO >= 1 + sizeof(PrunePlan::c) / sizeof(PruneClass), "a chunk's info block holds the flag and one count per class");
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,
                        uint32_t* flag /*[W]*/, uint32_t* rows /*[cap_total]*/, uint32_t* pos /*[W]*/, uint32_t* info /*[SSW_PRUNE_INFO]*/);
 int launch_prune_gather_basis(hipStream_t st, const uint32_t* rows, unsigned cap, const void* src, size_t src_rows,
@@ -338,6 +343,7 @@ struct ssw_ctx {
         Buf in[NB], in2[NB], out[NB];     // frames of a group: input (base), second input (derived), output
         Buf marks, ext, sims;             // the whole call's marks / extracted marks / similarities
         hipEvent_t up_done[NB] = {}, k_done[NB] = {}, down_done[NB] = {};
+        bool active = false;              // a streaming call is running: the ring must stay (dev_malloc's give-back skips it)
     };
     HostStream hs;
     Buf small;                    // misc (mark offsets, sims, ...)

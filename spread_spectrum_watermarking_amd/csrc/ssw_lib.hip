@@ -126,7 +126,7 @@ int forward_from_host(ssw_ctx* ctx, const void* host_rgb, int u8, size_t w, size
         // (image rows are independent lines of a row pass: same values), then the column pass of the whole frame.
         ssw_ctx::FrameStage& fs = ctx->frame_stage[ctx->frame_stage_next & 1];
         SSW_TRY(grow(fs.buf, bytes));
-        static const bool no_split = std::getenv("SSW_NO_SPLIT") != nullptr;      // A/B switch
+        const bool no_split = tuning(TUNE_BAND_SPLIT) == 0;                     // A/B switch (tuning.hip)
         if (!no_split && bytes >= ((size_t)8 << 20) &&
             can_split_forward_rows(ctx, precision == SSW_PRECISION_F64, w, h, y, tmp, fs.buf.p, u8)) {
             ++ctx->frame_stage_next;
@@ -220,6 +220,15 @@ int ssw_ctx_create(int device_id, ssw_ctx** out) {
     if (e != hipSuccess) {
         (void)hipStreamDestroy(ctx->aux_stream); (void)hipStreamDestroy(ctx->own_stream);
         delete ctx; set_last_error(hipGetErrorString(e)); return SSW_ERR_HIP;
+    }
+    // the selection's fallback counter lives as long as the context (allocated here, not lazily inside a batch call:
+    // a first call under stream capture must not allocate)
+    if (hipMalloc((void**)&ctx->select_fallbacks, sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(ctx->select_fallbacks, 0, sizeof(uint32_t)) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->select_fallbacks) (void)hipFree(ctx->select_fallbacks);
+        (void)hipStreamDestroy(ctx->copy_stream); (void)hipStreamDestroy(ctx->aux_stream); (void)hipStreamDestroy(ctx->own_stream);
+        delete ctx; set_last_error("hipMalloc: selection counter"); return SSW_ERR_OUT_OF_MEMORY;
     }
     const char* ov = std::getenv("SSW_OVERLAP");
     if (ov) ctx->overlap = std::atoi(ov) != 0;
@@ -343,7 +352,11 @@ int ssw_ctx_reset_timing(ssw_ctx* ctx) {
     for (int s = 0; s < SSW_STAGE_COUNT; ++s) { ctx->stage_ms[s] = 0; ctx->stage_launches[s] = 0; ctx->stage_work[s] = 0; }
     ctx->pruned_chunks = ctx->redone_chunks = ctx->pruned_columns = 0;
     ctx->select_frames = 0;
-    if (ctx->select_fallbacks) SSW_HIP_CHECK(hipMemsetAsync(ctx->select_fallbacks, 0, sizeof(uint32_t), ctx->stream));
+    // the finish kernels of either lane add to the counter: both lane streams are idle before it is zeroed (a caller's
+    // stream set through ssw_ctx_set_stream IS ctx->stream)
+    SSW_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->aux_stream) SSW_HIP_CHECK(hipStreamSynchronize(ctx->aux_stream));
+    SSW_HIP_CHECK(hipMemset(ctx->select_fallbacks, 0, sizeof(uint32_t)));
     return SSW_OK;
 }
 

@@ -33,6 +33,18 @@ size_t plane_pool_flush(ssw_ctx* ctx) {
     return bytes;
 }
 
+// The device ring of the host-image streaming entry points (ssw_stream.hip: 3 slots x two buffers of a group of frames,
+// ~1.2 GB at the default group size) stays allocated between calls; under memory pressure it goes back like the plane pool.
+size_t host_stream_release(ssw_ctx* ctx) {
+    ssw_ctx::HostStream& hs = ctx->hs;
+    if (hs.active) return 0;
+    size_t bytes = 0;
+    for (int s = 0; s < ssw_ctx::HostStream::NB; ++s)
+        for (ssw_ctx::Buf* b : {&hs.in[s], &hs.in2[s], &hs.out[s]})
+            if (b->p) { bytes += b->bytes; (void)hipFree(b->p); b->p = nullptr; b->bytes = 0; }
+    return bytes;
+}
+
 int dev_malloc(void** p, size_t bytes) {
     *p = nullptr;
     hipError_t e = hipMalloc(p, bytes ? bytes : 16);
@@ -40,6 +52,11 @@ int dev_malloc(void** p, size_t bytes) {
     (void)hipGetLastError();
     if (tl_ctx && !tl_ctx->plane_pool.empty()) {                   // spare planes of destroyed handles: give them back first
         (void)plane_pool_flush(tl_ctx);
+        e = hipMalloc(p, bytes ? bytes : 16);
+        if (e == hipSuccess) return SSW_OK;
+        (void)hipGetLastError();
+    }
+    if (tl_ctx && host_stream_release(tl_ctx)) {                   // then the idle streaming ring
         e = hipMalloc(p, bytes ? bytes : 16);
         if (e == hipSuccess) return SSW_OK;
         (void)hipGetLastError();
@@ -238,8 +255,7 @@ size_t split_scratch_elems(size_t n, size_t w, size_t h) {
 // Passes of at most this many lines run the classes of a stage as ONE launch (a single frame's launches are too small alone).
 // SSW_MERGE_MAX_LINES: A/B switch.
 static size_t merge_max_lines() {
-    static const size_t v = [] { const char* e = std::getenv("SSW_MERGE_MAX_LINES"); return e ? (size_t)std::atoll(e) : (size_t)8192; }();
-    return v;
+    return (size_t)tuning(TUNE_MERGE_MAX_LINES);
 }
 
 // Can the column pre-pass of an `fh`-row plane read the class-major order a deep row pass leaves (dct_pair_common.hpp)?  The
@@ -802,10 +818,6 @@ int topk(ssw_ctx* ctx, hipStream_t st, SelectWorkspace& sel, const float* coef, 
         return launch_full_sort(st, coef, n, w, h, ordering, ctx->sort_scratch.p, ctx->sort_scratch.bytes, idx, k);
     }
     SSW_TRY(grow_select(st, sel, n, k));
-    if (!ctx->select_fallbacks) {
-        SSW_ALLOC(&ctx->select_fallbacks, sizeof(uint32_t));
-        SSW_HIP_CHECK(hipMemsetAsync(ctx->select_fallbacks, 0, sizeof(uint32_t), st));
-    }
     sel.fallbacks = ctx->select_fallbacks;
     ctx->select_frames += n;
     StageTimer t(ctx, SSW_STAGE_SELECT, st, bytes);

@@ -68,6 +68,7 @@ int stream_setup(ssw_ctx* ctx) {
 // whatever happens, nothing of this call may still be in flight when it returns (the caller's buffers are DMA
 // sources / targets): waits for the three streams
 int stream_drain(ssw_ctx* ctx, int rc) {
+    ctx->hs.active = false;
     const hipError_t a = hipStreamSynchronize(ctx->copy_stream), b = hipStreamSynchronize(ctx->stream), c = hipStreamSynchronize(ctx->down_stream);
     if (rc != SSW_OK) { (void)hipGetLastError(); return rc; }
     SSW_HIP_CHECK(a); SSW_HIP_CHECK(b); SSW_HIP_CHECK(c);
@@ -86,6 +87,7 @@ int stream_embed_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* const*
     CtxGuard guard(ctx);
     SSW_TRY(stream_setup(ctx));
     ssw_ctx::HostStream& hs = ctx->hs;
+    struct Active { bool& a; explicit Active(bool& x) : a(x) { a = true; } ~Active() { a = false; } } active_guard(hs.active);
     const size_t fb = w * h * 3, G = stream_group(w, h, n_frames);
     const std::vector<Group> groups = stream_groups(w, h, n_frames, true);
     const size_t n_groups = groups.size();
@@ -102,6 +104,14 @@ int stream_embed_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* const*
             SSW_HIP_CHECK(hipEventRecord(hs.up_done[s], ctx->copy_stream));
             return SSW_OK;
         };
+        auto d2h = [&](size_t g) -> int {
+            const int s = (int)(g % NB);
+            const size_t f0 = groups[g].f0, n = groups[g].n;
+            SSW_HIP_CHECK(hipStreamWaitEvent(ctx->down_stream, hs.k_done[s], 0));
+            for (size_t j = 0; j < n; ++j) SSW_TRY(download_nowait(ctx, host_out[f0 + j], (const char*)hs.out[s].p + j * fb, fb, ctx->down_stream, &as));
+            SSW_HIP_CHECK(hipEventRecord(hs.down_done[s], ctx->down_stream));
+            return SSW_OK;
+        };
         for (size_t g = 0; g + 1 < (size_t)NB && g < n_groups; ++g) SSW_TRY(h2d(g));
         for (size_t g = 0; g < n_groups; ++g) {
             const int s = (int)(g % NB);
@@ -111,10 +121,11 @@ int stream_embed_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* const*
             SSW_TRY(batch_embed_impl(ctx, cfg, hs.in[s].p, SSW_PIX_U8, n, w, h, (const float*)hs.marks.p + f0 * k, k, hs.out[s].p, true, nullptr, nullptr));
             SSW_HIP_CHECK(hipEventRecord(hs.k_done[s], ctx->stream));
             if (g + NB - 1 < n_groups) SSW_TRY(h2d(g + NB - 1));      // staged (pageable) frames: the host copies while group g computes
-            SSW_HIP_CHECK(hipStreamWaitEvent(ctx->down_stream, hs.k_done[s], 0));
-            for (size_t j = 0; j < n; ++j) SSW_TRY(download_nowait(ctx, host_out[f0 + j], (const char*)hs.out[s].p + j * fb, fb, ctx->down_stream, &as));
-            SSW_HIP_CHECK(hipEventRecord(hs.down_done[s], ctx->down_stream));
+            // the download of group g - 1 is issued AFTER the kernels of group g: a pageable output buffer makes
+            // download_nowait a blocking staged copy, and the device must have its next group queued before the host sleeps
+            if (g >= 1) SSW_TRY(d2h(g - 1));
         }
+        SSW_TRY(d2h(n_groups - 1));
         return SSW_OK;
     };
     return stream_drain(ctx, body());
@@ -132,6 +143,7 @@ int stream_extract_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* cons
     CtxGuard guard(ctx);
     SSW_TRY(stream_setup(ctx));
     ssw_ctx::HostStream& hs = ctx->hs;
+    struct Active { bool& a; explicit Active(bool& x) : a(x) { a = true; } ~Active() { a = false; } } active_guard(hs.active);
     const size_t fb = w * h * 3, G = stream_group(w, h, n_frames);
     const std::vector<Group> groups = stream_groups(w, h, n_frames, false);
     const size_t n_groups = groups.size();

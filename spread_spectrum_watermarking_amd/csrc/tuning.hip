@@ -1,0 +1,83 @@
+// Strategy thresholds and A/B switches of the transform: one process-wide table, settable at run time through the C ABI
+// (ssw_tuning_set / ssw_tuning_get, include/ssw.h) so that tests lower a threshold in-process instead of spawning a child
+// with an environment variable (sixteen getenv switches read once per process).  An entry that was never set
+// takes its SSW_* environment variable (read at first use, as before), else its default.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
+#include "ssw_internal.hpp"
+
+namespace ssw {
+namespace {
+
+struct Entry {
+    const char* name;
+    const char* env;
+    long long dflt;
+    std::atomic<long long> value{0};
+    std::atomic<int> state{0};             // 0: not read yet, 1: from the environment / default, 2: set through the ABI
+    Entry(const char* n, const char* e, long long d) : name(n), env(e), dflt(d) {}
+};
+
+Entry g_tune[TUNE_COUNT] = {
+    {"efold_min", "SSW_EFOLD_MIN", 1280},              // shortest forward row pass at level 2 (dct_pair_efold)
+    {"efold_inv_min", "SSW_EFOLD_INV_MIN", 1280},      // shortest inverse row pass at level 2 (dct_pair_efold_inv)
+    {"efold_cols_min", "SSW_EFOLD_COLS_MIN", 720},     // shortest column pass at level 2 (dct_pair_efold_cols)
+    {"class_tile", "SSW_CLASS_TILE", 1},               // class-major order inside tiles of 128 columns (0: one tile per line)
+    {"deep_min_rows", "SSW_DEEP_MIN_ROWS", 256},       // shortest row pass that takes the deep pre-passes
+    {"deep_min_cols", "SSW_DEEP_MIN_COLS", 256},       // ... column pass
+    {"prep_staged", "SSW_PREP_STAGED", 1},             // the LDS-staged pre-passes (0: the r3 kernels)
+    {"merge_max_lines", "SSW_MERGE_MAX_LINES", 8192},  // passes of at most this many lines run a stage's classes as one launch
+    {"bn32", "SSW_BN32", -1},                          // 32-pair tiles for small single-class launches: -1 automatic, 0 / 1 forced
+    {"band_split", "SSW_BAND_SPLIT", 1},               // single-image handles: row pass of the top half beside the upload of the bottom half
+    {"fuse_cols", "SSW_FUSE_COLS", 1},                 // forward: column operands straight from the row GEMMs' epilogue (r5)
+};
+
+}  // namespace
+
+long long tuning(int which) {
+    Entry& e = g_tune[which];
+    if (e.state.load(std::memory_order_acquire) == 0) {
+        const char* s = std::getenv(e.env);
+        long long v = s ? std::atoll(s) : e.dflt;
+        if (which == TUNE_BAND_SPLIT && std::getenv("SSW_NO_SPLIT")) v = 0;      // the r3 name of the switch
+        e.value.store(v, std::memory_order_relaxed);
+        int expect = 0;
+        e.state.compare_exchange_strong(expect, 1, std::memory_order_release);
+    }
+    return e.value.load(std::memory_order_relaxed);
+}
+
+}  // namespace ssw
+
+extern "C" {
+
+int ssw_tuning_set(const char* name, long long value) {
+    if (!name) return SSW_ERR_BAD_ARG;
+    for (int i = 0; i < ssw::TUNE_COUNT; ++i)
+        if (std::strcmp(ssw::g_tune[i].name, name) == 0) {
+            ssw::g_tune[i].value.store(value, std::memory_order_relaxed);
+            ssw::g_tune[i].state.store(2, std::memory_order_release);
+            return SSW_OK;
+        }
+    return SSW_ERR_BAD_ARG;
+}
+
+int ssw_tuning_get(const char* name, long long* value) {
+    if (!name || !value) return SSW_ERR_BAD_ARG;
+    for (int i = 0; i < ssw::TUNE_COUNT; ++i)
+        if (std::strcmp(ssw::g_tune[i].name, name) == 0) { *value = ssw::tuning(i); return SSW_OK; }
+    return SSW_ERR_BAD_ARG;
+}
+
+int ssw_tuning_reset(const char* name) {
+    for (int i = 0; i < ssw::TUNE_COUNT; ++i)
+        if (!name || std::strcmp(ssw::g_tune[i].name, name) == 0) {
+            ssw::g_tune[i].state.store(0, std::memory_order_release);
+            if (name) return SSW_OK;
+        }
+    return name ? SSW_ERR_BAD_ARG : SSW_OK;
+}
+
+}  // extern "C"

@@ -16,6 +16,22 @@ def ctx() -> Context:
     return _ctx
 
 
+class fresh_ctx:
+    """`with fresh_ctx(): ...` -- the helpers of this module run on a new Context inside the block (tests that change a
+    process-wide tuning value: an existing context's workspaces and plans were built under the old one)."""
+
+    def __enter__(self):
+        global _ctx
+        self._prev, _ctx = _ctx, Context(0)
+        return _ctx
+
+    def __exit__(self, *exc):
+        global _ctx
+        _ctx.close()
+        _ctx = self._prev
+        return False
+
+
 def lib():
     return L.load()
 

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """The level-2 row passes (forward: dct_pair_efold, inverse: dct_pair_efold_inv -- by default rows of 1280 columns or more)
-and column passes (dct_pair_efold_cols: 720 rows or more) on SMALL shapes the oracle finishes in seconds: run with
-SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 SSW_EFOLD_COLS_MIN=64 so that every row of a multiple of 64 (forward) / 256
-(inverse) columns and every column of a multiple of 16 rows takes them; tests/test_fuzz_gpu.py does, in a child process
-(the switches are read once per process).  Transforms against the oracle's correctly rounded one, and two batch pipelines
-(pruned + two lanes against full + one lane, both against the oracle).
-usage: SSW_EFOLD_MIN=256 SSW_EFOLD_INV_MIN=256 SSW_EFOLD_COLS_MIN=64 python tools/level2_check.py"""
+and column passes (dct_pair_efold_cols: 720 rows or more) on SMALL shapes the oracle finishes in seconds: the thresholds
+are lowered through ssw_tuning_set (efold_min = efold_inv_min = 256, efold_cols_min = 64) so that every row of a multiple of
+64 (forward) / 256 (inverse) columns and every column of a multiple of 16 rows takes them; tests/test_fuzz_gpu.py calls
+run() in-process.  Transforms against the oracle's correctly rounded one, and two batch pipelines (pruned + two lanes
+against full + one lane, both against the oracle).
+usage: python tools/level2_check.py"""
 import os
 import sys
 
@@ -23,18 +23,26 @@ SHAPES = [(128, 256, 1), (128, 512, 2), (256, 768, 1), (136, 1024, 3), (480, 128
           (1080, 256, 1), (64, 3840, 2), (272, 320, 2), (2160, 512, 1), (1104, 200, 2), (336, 132, 1), (72, 1920, 2), (1080, 1920, 1), (144, 384, 3), (80, 640, 1), (96, 896, 2)]
 BATCH = [(256, 512, 3, 150, 11, 21), (144, 1024, 2, 200, 12, 22)]      # (h, w, frames, k, frame seed, mark seed)
 
-if __name__ == "__main__":
+def run(out=print):
+    """All level-2 cases under lowered thresholds, on a fresh context; returns the number of failures."""
+    import gpu_util as G
+    from spread_spectrum_watermarking_amd import tuning
     bad = 0
-    for (h, w, n) in SHAPES:
-        for name in ("fwd", "ortho", "inv"):
-            same, err = fuzz_dct.check(h, w, n, 1234 + h + w, name)
-            ok = same >= fuzz_dct.BAR_IDENTICAL and err <= fuzz_dct.BAR_ERR
+    with tuning(efold_min=256, efold_inv_min=256, efold_cols_min=64), G.fresh_ctx():
+        for (h, w, n) in SHAPES:
+            for name in ("fwd", "ortho", "inv"):
+                same, err = fuzz_dct.check(h, w, n, 1234 + h + w, name)
+                ok = same >= fuzz_dct.BAR_IDENTICAL and err <= fuzz_dct.BAR_ERR
+                bad += not ok
+                out(f"{h:5d} x {w:5d} n={n} {name:5s} identical {same:.6f} err/ACmax {err:.2e}{'' if ok else '   <-- FAIL'}")
+        for case in BATCH:
+            r = fuzz_batch.check(*case)
+            ok = r["same"] and fuzz_batch.passes(r)
             bad += not ok
-            print(f"{h:5d} x {w:5d} n={n} {name:5s} identical {same:.6f} err/ACmax {err:.2e}{'' if ok else '   <-- FAIL'}", flush=True)
-    for case in BATCH:
-        r = fuzz_batch.check(*case)
-        ok = r["same"] and fuzz_batch.passes(r)
-        bad += not ok
-        print(f"batch {case}: {r}{'' if ok else '   <-- FAIL'}", flush=True)
-    print("level-2 checks:", "FAILED" if bad else "all good")
-    sys.exit(1 if bad else 0)
+            out(f"batch {case}: {r}{'' if ok else '   <-- FAIL'}")
+    out("level-2 checks: " + ("FAILED" if bad else "all good"))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(lambda s: print(s, flush=True)) else 0)
