@@ -140,6 +140,29 @@ def hbm_report(stage, names):
     return out
 
 
+def step_roofline(prec_name, stage, steps, wall_ms_per_step):
+    """What bounds the STEP (verdict r4 #3): algorithmic HBM bytes of every stage (the HBM-bound stages' own bytes, and for
+    the GEMM launches the operand planes in, the results out and the inverse's A1 / T2 / E exchange: ssw_ctx_get_traffic)
+    and the executed flop of every GEMM launch, each priced at its peak; a perfectly overlapped step would take the
+    larger of the two times, one with no overlap at all their sum.  `frac` = that larger time / the measured wall time."""
+    peak = PEAK_F64_MFMA_TFLOPS if prec_name == "f64" else PEAK_F32_MFMA_TFLOPS
+    names = [k for k in stage if not k.endswith("_main")]
+    by_stage = {k: stage[k]["bytes"] / steps for k in names if stage[k]["bytes"]}
+    total_bytes = sum(by_stage.values())
+    flop = (stage["dct_row"]["work"] + stage["dct_col"]["work"]) / steps
+    t_hbm = total_bytes / (PEAK_HBM_GBS * 1e9) * 1e3
+    t_mfma = flop / (peak * 1e12) * 1e3
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    return {"bound": bound, "algorithmic_bytes_per_step": total_bytes, "executed_flop_per_step": flop,
+            "ms_at_hbm_peak": round(t_hbm, 3), "ms_at_mfma_peak": round(t_mfma, 3), "ms_per_step": round(wall_ms_per_step, 3),
+            "frac": round(max(t_hbm, t_mfma) / wall_ms_per_step, 4) if wall_ms_per_step else None,
+            "frac_if_not_overlapped": round((t_hbm + t_mfma) / wall_ms_per_step, 4) if wall_ms_per_step else None,
+            "peak_hbm_gbs": PEAK_HBM_GBS, "peak_mfma_tflops": peak,
+            "bytes_per_step_by_stage": {k: round(v) for k, v in by_stage.items()},
+            "how": "max(algorithmic bytes / 8 TB/s, executed flop / MFMA peak) / measured ms per step; bytes counted per launch by "
+                   "the library (ssw_ctx_get_traffic), each byte once"}
+
+
 # The launch `roofline.best_launch` is about: ONE GEMM launch of a forward row pass, under its own template instance.
 #   f64 (default): rows of 3072 columns or more run at level 2 (csrc/ssw_pipeline.hip build_pass): eight launches that all
 #       sum W/16 terms over W/16 output pairs; the timed one is kind 7 -- class O of the split odd half rotated once more,
@@ -283,11 +306,31 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
 
     own, elapsed, stage, prune = timed_region(args, ctx, dist, step)
     sims_host = sims.cpu().numpy()
+    ext_host = extracted.cpu().numpy()
     ranks = rank_report(own)
-    dump(sims_host, extracted.cpu().numpy())
+    dump(sims_host, ext_host)
+    chunk_eff = ctx.pass_frames(B, W, H)
+    # the same step with one pass at a time on one stream: what each kernel does alone (verdict r4 #8)
+    serial = None
+    if not args.no_serial_leg:
+        keep = args.steps
+        args.steps = max(1, min(args.steps, 3))
+        ctx.set_overlap(False)
+        _, s_elapsed, s_stage, _ = timed_region(args, ctx, dist, step)
+        ctx.set_overlap(not args.no_overlap)
+        if rank == 0:
+            s_roofline, s_roofline_hbm = family_rooflines(args.precision, s_stage, args.steps, W, H, chunk_eff, B)
+            serial = {"value": round(float(total_frames) * W * H * args.steps / 1e6 / s_elapsed, 2), "unit": "Mpix/s",
+                      "ms_per_step": round(s_elapsed / args.steps * 1e3, 3), "steps": args.steps,
+                      "roofline_step": step_roofline(args.precision, s_stage, args.steps, s_elapsed / args.steps * 1e3),
+                      "roofline": s_roofline, "roofline_hbm": s_roofline_hbm,
+                      "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in s_stage.items()},
+                      "hbm_kernels": hbm_report(s_stage, ["rgb_to_yiq", "dct_prep", "select", "yiq_to_rgb", "resize"]),
+                      "bit_identical_to_overlapped": bool(np.array_equal(sims.cpu().numpy(), sims_host) and
+                                                          np.array_equal(extracted.cpu().numpy(), ext_host))}
+        args.steps = keep
     result = None
     if rank == 0:
-        chunk_eff = ctx.pass_frames(B, W, H)
         roofline, roofline_hbm = family_rooflines(args.precision, stage, args.steps, W, H, chunk_eff, B)
         result = {
             "metric": "Mpixels/sec embed + resize attack (12.5 %) + extract",
@@ -301,6 +344,7 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
                        "chunk_frames": chunk_eff, "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
+            "roofline_step": step_roofline(args.precision, stage, args.steps, elapsed / args.steps * 1e3),
             "stage_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in stage.items()},
             "hbm_kernels": hbm_report(stage, ["rgb_to_yiq", "dct_prep", "select", "yiq_to_rgb", "resize"]),
             "pruned_derived_transform": prune,
@@ -308,6 +352,8 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
             "sim_mean": round(float(sims_host.mean()), 4), "sim_min": round(float(sims_host.min()), 4),
             "sim_sigma_threshold_6_passed": bool((sims_host > 6.0).all()),
         }
+        if serial is not None:
+            result["serialized"] = serial
     if rank == 0 and not args.no_cpu_baseline:
         # tests/attack_resize.rs:17-66 on frame 0 with the oracle: timed in the reference's own arithmetic class
         # (f32 FFT DCT + full stable sort), then untimed with the exact (f64) backend as the parity checker
@@ -769,6 +815,7 @@ def main():
         s_kernels, (s_roofline, s_roofline_hbm), s_stage_ms = kernel_report(args.precision, s_stage, args.steps)
         serial = {"value": round(float(total_frames) * W * H * args.steps / 1e6 / s_elapsed, 2), "unit": "Mpix/s",
                   "ms_per_step": round(s_elapsed / args.steps * 1e3, 3), "steps": args.steps,
+                  "roofline_step": step_roofline(args.precision, s_stage, args.steps, s_elapsed / args.steps * 1e3),
                   "roofline": s_roofline, "roofline_hbm": s_roofline_hbm, "kernels": s_kernels, "stage_ms_per_step": s_stage_ms,
                   "bit_identical_to_overlapped": bool(np.array_equal(s_sims, sims_host) and np.array_equal(s_ext, ext_host))}
         args.steps = keep
@@ -844,6 +891,7 @@ def main():
                        "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
+            "roofline_step": step_roofline(args.precision, stage, steps, elapsed / steps * 1e3),
             "kernels": kernels,
             "stage_ms_per_step": stage_ms,
             "pruned_derived_transform": prune,

@@ -244,6 +244,12 @@ int ssw_ctx_get_timing(ssw_ctx* ctx, double* ms, uint64_t* launches);
    operations for the GEMM stages (DCT_ROW, DCT_COL and their *_MAIN launches), algorithmic bytes
    (what the stage must read and write once) for the HBM-bound ones. */
 int ssw_ctx_get_work(ssw_ctx* ctx, double* work);
+/* Algorithmic HBM bytes moved inside the timed regions, per stage (array of SSW_STAGE_COUNT): for the HBM-bound stages
+   the same figure as ssw_ctx_get_work; for the GEMM stages (DCT_ROW, DCT_COL) the operand planes read, the results
+   written and what the dependent launches of an inverse pass exchange (A1 / T2 / E out and in, I and Q in and RGB out in
+   the last pass of Writer::result, src/algorithm.rs:361-379) -- each byte once, bases not counted (cache-resident).
+   bench.py's `roofline_step` is built from it. */
+int ssw_ctx_get_traffic(ssw_ctx* ctx, double* bytes);
 
 /* Device memory helpers for hosts without their own allocator. */
 int ssw_dev_mem_info(ssw_ctx* ctx, size_t* free_bytes, size_t* total_bytes);

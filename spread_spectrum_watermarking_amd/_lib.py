@@ -58,6 +58,7 @@ SIGNATURES = {
     "ssw_ctx_reset_timing": (C.c_int, [_vp]),
     "ssw_ctx_get_timing": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "ssw_ctx_get_work": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "ssw_ctx_get_traffic": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "ssw_ctx_set_overlap": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_set_prune": (C.c_int, [_vp, C.c_int]),
     "ssw_ctx_set_odd_split": (C.c_int, [_vp, C.c_int]),

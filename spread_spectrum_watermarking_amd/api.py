@@ -92,7 +92,9 @@ class Context:
         work = (C.c_double * len(L.STAGES))()
         check(self._lib.ssw_ctx_get_timing(self.handle, ms, n), "ssw_ctx_get_timing")
         check(self._lib.ssw_ctx_get_work(self.handle, work), "ssw_ctx_get_work")
-        return {s: {"ms": ms[i], "launches": int(n[i]), "work": work[i]} for i, s in enumerate(L.STAGES)}
+        traffic = (C.c_double * len(L.STAGES))()
+        check(self._lib.ssw_ctx_get_traffic(self.handle, traffic), "ssw_ctx_get_traffic")
+        return {s: {"ms": ms[i], "launches": int(n[i]), "work": work[i], "bytes": traffic[i]} for i, s in enumerate(L.STAGES)}
 
     def set_overlap(self, on: bool = True):
         """Two chunks in flight on two streams in the batch entry points (default) or one at a time."""

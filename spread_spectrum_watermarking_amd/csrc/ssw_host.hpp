@@ -68,6 +68,9 @@ struct StageTimer {
     hipEvent_t a = nullptr, b = nullptr;
     StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work = 0.0);
     ~StageTimer();
+    // algorithmic HBM bytes of a GEMM stage (operands in, results and the inverse's E / T2 / A1 exchange out and in):
+    // the HBM-bound stages' bytes ARE their work and are counted by the constructor
+    void traffic(double bytes);
     StageTimer(const StageTimer&) = delete;
     StageTimer& operator=(const StageTimer&) = delete;
 };

@@ -355,6 +355,7 @@ struct ssw_ctx {
     bool timing = false;
     double stage_ms[SSW_STAGE_COUNT] = {0};
     uint64_t stage_launches[SSW_STAGE_COUNT] = {0};
+    double stage_bytes[SSW_STAGE_COUNT] = {0};    // algorithmic HBM bytes of every stage (ssw_ctx_get_traffic)
     double stage_work[SSW_STAGE_COUNT] = {0};     // executed flop (GEMM stages) / algorithmic bytes (HBM-bound stages)
     struct Pending {
         int stage;

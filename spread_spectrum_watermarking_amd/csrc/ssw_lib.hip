@@ -349,7 +349,7 @@ int ssw_ctx_reset_timing(ssw_ctx* ctx) {
     if (!ctx) return SSW_ERR_BAD_ARG;
     CtxGuard g(ctx);
     SSW_TRY(flush_timers(ctx));
-    for (int s = 0; s < SSW_STAGE_COUNT; ++s) { ctx->stage_ms[s] = 0; ctx->stage_launches[s] = 0; ctx->stage_work[s] = 0; }
+    for (int s = 0; s < SSW_STAGE_COUNT; ++s) { ctx->stage_ms[s] = 0; ctx->stage_launches[s] = 0; ctx->stage_work[s] = 0; ctx->stage_bytes[s] = 0; }
     ctx->pruned_chunks = ctx->redone_chunks = ctx->pruned_columns = 0;
     ctx->select_frames = 0;
     // the finish kernels of either lane add to the counter: both lane streams are idle before it is zeroed (a caller's
@@ -376,6 +376,14 @@ int ssw_ctx_get_work(ssw_ctx* ctx, double* work) {
     CtxGuard g(ctx);
     SSW_TRY(flush_timers(ctx));
     for (int s = 0; s < SSW_STAGE_COUNT; ++s) work[s] = ctx->stage_work[s];
+    return SSW_OK;
+}
+
+int ssw_ctx_get_traffic(ssw_ctx* ctx, double* bytes) {
+    if (!ctx || !bytes) return SSW_ERR_BAD_ARG;
+    CtxGuard g(ctx);
+    SSW_TRY(flush_timers(ctx));
+    for (int s = 0; s < SSW_STAGE_COUNT; ++s) bytes[s] = ctx->stage_bytes[s];
     return SSW_OK;
 }
 

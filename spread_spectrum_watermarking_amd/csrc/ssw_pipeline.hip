@@ -105,6 +105,8 @@ int grow_select(hipStream_t st, SelectWorkspace& s, size_t frames, size_t k) {
 StageTimer::StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work) : ctx(c), stage(s), st(stream) {
     if (!ctx->timing) return;
     ctx->stage_work[stage] += work;
+    const bool gemm = stage == SSW_STAGE_DCT_ROW || stage == SSW_STAGE_DCT_COL || stage == SSW_STAGE_DCT_ROW_MAIN || stage == SSW_STAGE_DCT_COL_MAIN;
+    if (!gemm) ctx->stage_bytes[stage] += work;
     auto get = [&]() {
         hipEvent_t e = nullptr;
         if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
@@ -113,6 +115,9 @@ StageTimer::StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work) : ctx
     };
     a = get(); b = get();
     if (a) (void)hipEventRecord(a, st);
+}
+void StageTimer::traffic(double bytes) {
+    if (ctx->timing) ctx->stage_bytes[stage] += bytes;
 }
 StageTimer::~StageTimer() {
     if (!ctx->timing || !a || !b) return;
@@ -288,6 +293,12 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
     // element per pixel in the GEMM's precision, whatever the number of folding levels) and I / Q out
     const double prep_bytes = from_rgb ? px * (3.0 * (double)pix_bytes(rgb_u8) + (iq_i ? 8.0 : 0.0) + esz) : px * (4.0 + esz);
     const int st_prep = from_rgb ? SSW_STAGE_RGB_TO_YIQ : SSW_STAGE_DCT_PREP;
+    // algorithmic bytes of the pass's GEMM launches (ssw_ctx_get_traffic): the operand planes in (one element per pixel), the
+    // f32 result out -- or, in the last pass of Writer::result, I and Q in and the RGB frame out -- plus `xch` bytes per
+    // pixel that the dependent launches of an inverse pass write and read back as doubles (A1: 1 + 1, T2: 2 + 2, E: 4 + 4)
+    const bool sink_pass = inverse && !first_pass && !is_row && x.rgb_out && x.iq_i && x.iq_q;
+    const double out_bpp = sink_pass ? 8.0 + 3.0 * (double)pix_bytes(x.rgb_out_u8) : 4.0;
+    auto gemm_bytes = [=](double xch) { return px * (esz + xch + out_bpp); };
     if (operand) {
         const size_t bytes = dct_pair_operand_elems(f64, n, w, h) * (size_t)esz;
         const bool two = ctx->fold_level >= 4 && (is_row ? dct_pair_can_fold2(len) : dct_pair_can_fold2_cols(len));
@@ -369,6 +380,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                             {7, 0, P(4), P(5), (const double*)t0, (const double*)t1}};         // O rotated, "+"
                 ch.push_back({false, [=](hipStream_t st) -> int {
                     StageTimer t(ctx, st_pass, st, f_all);
+                    t.traffic(gemm_bytes(0.0));
                     const bool rcm = cm && is_row;
                     if (merge) {
                         StageTimer tm(ctx, st_main, st, f_all);
@@ -387,6 +399,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                  pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
+                t.traffic(gemm_bytes(0.0));
                 const bool rcm = cm && is_row;
                 if (merge) {
                     const PairClassDesc d[5] = {{1, 1, sp + 4 * p8, sp + 5 * p8, (const double*)e0, (const double*)e1},
@@ -440,6 +453,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const bool merge = lines <= merge_max_lines();
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
+                t.traffic(gemm_bytes(0.0));
                 if (merge) {      // the SD launch shares its image operand between its two products: another template instance
                     SSW_TRY(pair_gemm(st, true, is_row, false, 2, 1, m, m, h1, (const char*)h1 + (len / 8) * 64, dst, nullptr, n, w, h, ep));
                     const PairClassDesc d[3] = {{1, 1, sp + 4 * p8, sp + 5 * p8, (const double*)e0, (const double*)e1},
@@ -486,6 +500,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                  pair_gemm_flop(is_row, 2, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
+                t.traffic(gemm_bytes(12.0));
                 SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
                 SSW_TRY(pair_gemm(st, true, is_row, true, 2, 1, m, m, h1, (const char*)h1 + (len / 8) * 64, dst, T2, n, w, h, ep, nullptr, TE));
                 if (lines <= merge_max_lines()) {
@@ -560,6 +575,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                              {8, 0, P(6), P(7), (const double*)t0, (const double*)t1}};        // O rotated, "-"
                 ch.push_back({false, [=](hipStream_t st) -> int {
                     StageTimer t(ctx, st_pass, st, f_all);
+                    t.traffic(gemm_bytes(14.0));
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &da, dst, (double*)A1, n, w, h, ep));
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &db, dst, (double*)A1, n, w, h, ep, nullptr, (double*)T2, rcm));
                     if (lines <= merge_max_lines()) {          // single frames: the classes of each dependent stage in one launch
@@ -578,6 +594,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                  pair_gemm_flop(is_row, 3, 1, n, w, h) + pair_gemm_flop(is_row, 4, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
+                t.traffic(gemm_bytes(12.0));
                 SSW_TRY(pair_gemm(st, true, is_row, true, 1, 1, sp + 4 * p8, sp + 5 * p8, e0, e1, dst, T2, n, w, h, ep));
                 if (lines <= merge_max_lines()) {          // single frames: the two classes of each dependent stage in one launch
                     const PairClassDesc d1[2] = {{3, 1, q, q + p16, (const double*)t0, (const double*)t1},
@@ -617,6 +634,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const double f_all = f_main + pair_gemm_flop(is_row, 1, 1, n, w, h) + pair_gemm_flop(is_row, 2, 1, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
+                t.traffic(gemm_bytes(0.0));
                 SSW_TRY(pair_gemm(st, f64, is_row, inverse, 1, 1, r1, r2, e0, e1, dst, nullptr, n, w, h, ep));
                 SSW_TRY(pair_gemm(st, f64, is_row, inverse, 2, 1, d2, d2, h1, (const char*)h1 + (len / 8) * 64, dst, nullptr, n, w, h, ep));
                 StageTimer tm(ctx, st_main, st, f_main);
@@ -633,6 +651,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const double f_main = pair_gemm_flop(is_row, 0, 0, n, w, h);
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_main);
+                t.traffic(gemm_bytes(0.0));
                 StageTimer tm(ctx, st_main, st, f_main);
                 return pair_gemm(st, f64, is_row, inverse, 0, 0, x1, x2, b0, b1, dst, nullptr, n, w, h, ep);
             }});
@@ -662,6 +681,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             const bool with_sink = sink.rgb != nullptr;
             ch.push_back({false, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_pass, st, f_all);
+                t.traffic(gemm_bytes(inverse ? esz : 0.0));          // inverse: the even half E out and in
                 // even half: a half-length transform of S (forward) / of the even coefficients (inverse), folded again
                 SSW_TRY(pair_gemm(st, f64, is_row, inverse, 1, 0, xx1, xx2, q0, q1, dst, tmpE, n, w, h, ep));
                 // odd half: full half-length sum, the odd basis split into two row blocks (second block:
@@ -684,6 +704,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
     if (is_row) {
         ch.push_back({false, [=](hipStream_t st) -> int {
             StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
+            t.traffic(px * 8.0);
             if (fold && f64) return launch_dct_rows_folded_f64(st, inverse, src, dst, n * h, w, (const double*)b0, (const double*)b1, ep);
             if (fold) return launch_dct_rows_folded_f32(st, inverse, src, dst, n * h, w, (const float*)b0, (const float*)b1, ep);
             return launch_dct_rows(st, precision, src, dst, n * h, w, b0, ep);
@@ -691,6 +712,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
     } else {
         ch.push_back({false, [=](hipStream_t st) -> int {
             StageTimer t(ctx, SSW_STAGE_DCT_COL, st, flop);
+            t.traffic(px * 8.0);
             if (fold && f64) return launch_dct_cols_folded_f64(st, inverse, src, dst, n, w, h, (const double*)b0, (const double*)b1, ep);
             if (fold) return launch_dct_cols_folded_f32(st, inverse, src, dst, n, w, h, (const float*)b0, (const float*)b1, ep);
             return launch_dct_cols(st, precision, src, dst, n, w, h, b0, ep);
@@ -1125,6 +1147,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
                                                             cs[c].kp / (64 / esz), gathered + goff2[c], true));
         }
         StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
+        t.traffic(px * (double)esz + (double)lines * (double)cap * 4.0);      // every operand plane once in, the compact plane out
         for (unsigned c = 0; c < plan.n_classes; ++c) {
             if (cs[c].x2) SSW_TRY(launch_dct_pair_gemm_rows_subset_split_f64(st, (const double*)cs[c].x, (const double*)cs[c].x2, (const double*)(gathered + goff[c]),
                                                                              (const double*)(gathered + goff2[c]), plan.c[c].cap, (unsigned)cs[c].kp, t_compact,

@@ -754,6 +754,98 @@ def test_4k_pipeline_parity_with_oracle():
     _whole_pipeline_vs_oracle(3840, 2160, 1000, 21, 3)
 
 
+def _frame_vs_oracle(rgb, mark, coef, idx, marked, ext, sim):
+    """The bars of _whole_pipeline_vs_oracle on one frame of a batch call's outputs."""
+    k = mark.size
+    ref_coef = O.dct2d(O.rgb_to_yiq(rgb)[0])
+    if coef is not None:
+        assert np.mean(coef == ref_coef) > 0.9995
+        assert np.abs(coef.astype(np.float64) - ref_coef).max() <= 2e-7 * ac_max(ref_coef)
+    assert np.array_equal(idx, O.indices(ref_coef, k=k).astype(np.uint32))
+    ref_marked = O.embed_frame(rgb, mark)
+    assert np.abs(marked - ref_marked).max() <= 2e-7 and np.mean(marked == ref_marked) > 0.999
+    ref_ext, ref_sim = O.extract_frame(rgb, ref_marked, mark)
+    assert np.abs(ext - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert abs(float(sim) - ref_sim) < 1e-4
+
+
+def test_4k_bench_configuration_equals_handles_and_oracle():
+    """The configuration bench.py times (BASELINE configs[3], per-GPU shard) in the shape GPUTEST owns: sixteen
+    3840x2160 frames in two passes of eight (set_chunk_frames(8): 17280 lines per pass > merge_max_lines, i.e. the
+    unmerged eight-launch passes on 128-line tiles, two lanes, the pruned derived transform) -- every frame's index list,
+    marked frame, extracted mark and similarity bit for bit against the single-image handles (full transforms, merged
+    single-frame launches), the first and the last frame against the oracle with the bars of
+    _whole_pipeline_vs_oracle.  Reference flow: src/algorithm.rs:295-379, :462-562, :696-714."""
+    w, h, k, n = 3840, 2160, 1000, 16
+    ctx = G.ctx()
+    rgb = G.synth(1, 0, n, w, h)                                 # bench.py's frames: seed 1, frames 0 .. n - 1
+    marks = np.random.default_rng(41).standard_normal((n, k)).astype(np.float32)
+    ctx.set_chunk_frames(8)
+    ctx.reset_timing()
+    try:
+        res = G.batch_embed(rgb, marks, want_idx=True)
+        ext, sims = G.batch_extract(rgb, res["rgb"], k, marks)
+    finally:
+        ctx.set_chunk_frames(0)
+    ps, ss = ctx.prune_stats(), ctx.select_stats()
+    assert ps["pruned_chunks"] == 2 and ps["redone_chunks"] == 0, ps
+    assert ss["exact_fallback_frames"] == 0, ss
+    for f in range(n):
+        rd = wm.Reader.base(rgb[f])
+        assert np.array_equal(res["idx"][f], rd.indices(k).astype(np.uint32)), f
+        e = rd.extract(wm.Reader.derived(res["rgb"][f]), k)
+        assert np.array_equal(ext[f], e), f
+        assert sims[f] == np.float32(wm.Tester(e).similarity(marks[f]).similarity), f
+        assert np.array_equal(res["rgb"][f], wm.Writer(rgb[f]).mark([marks[f]])), f
+    for f in (0, n - 1):
+        _frame_vs_oracle(rgb[f], marks[f], None, res["idx"][f], res["rgb"][f], ext[f], sims[f])
+
+
+def _mirror_tile(img_u8, w, h):
+    """A natural image mirror-tiled (no seams: every tile is the reflection of its neighbour) and cropped to w x h."""
+    ih, iw = img_u8.shape[:2]
+    row = np.concatenate([img_u8, img_u8[:, ::-1]], axis=1)
+    row = np.concatenate([row] * (w // (2 * iw) + 1), axis=1)[:, :w]
+    col = np.concatenate([row, row[::-1]], axis=0)
+    return np.ascontiguousarray(np.concatenate([col] * (h // (2 * ih) + 1), axis=0)[:h])
+
+
+@pytest.mark.parametrize("shape", [(1920, 1080), (3840, 2160)])
+def test_natural_image_at_level2_shapes_matches_the_oracle(shape, cat_images, marks):
+    """The reference's own photograph (tests/single_simple.rs:13, 640x444: dense column kernels) mirror-tiled to the
+    shapes whose default path is level 2 / pruned / sampled-threshold selection -- the 8-bit batch entry points against the
+    oracle on identical inputs (u8 -> f32 by v / 255 on both sides), with the reference's seed-1 mark.  A natural
+    spectrum must not push the selection to its exact fallback nor the pruned transform to a redo."""
+    w, h = shape
+    k = 1000
+    img = _mirror_tile(cat_images["cat"], w, h)
+    mark = marks["seed_1"][None, :k].astype(np.float32)
+    ctx = G.ctx()
+    ctx.reset_timing()
+    wm8 = G.batch_embed_rgb8(img[None], mark)
+    frame = u8_to_f32(img)
+    o_marked = O.embed_frame(frame, mark[0])
+    o_wm8 = f32_to_u8(o_marked)
+    assert np.mean(wm8[0] == o_wm8) > 0.9999 and np.abs(wm8[0].astype(np.int16) - o_wm8).max() <= 1
+    # identical 8-bit inputs on both sides: the oracle's own marked frame as the derived image
+    ext, sims = G.batch_extract_rgb8(img[None], o_wm8[None], k, mark)
+    o_ext, o_sim = O.extract_frame(frame, u8_to_f32(o_wm8), mark[0])
+    assert np.mean(ext[0] == o_ext) >= 0.999 and np.abs(ext[0] - o_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(o_ext)).max()
+    assert abs(float(sims[0]) - o_sim) < 1e-5 * abs(o_sim) + 1e-5
+    # the f32 entry points on the same frame: coefficients and the index list
+    res = G.batch_embed(frame[None], mark, want_coef=True, want_idx=True)
+    ref_coef = O.dct2d(O.rgb_to_yiq(frame)[0])
+    # (a mirror-tiled image is the even extension of its 640-pixel tile: only every third / sixth frequency column is
+    # non-zero mathematically, the others hold round-off on both sides -- bit-identity is asked of the real coefficients)
+    real = np.abs(ref_coef) > 1e-6 * ac_max(ref_coef)
+    assert real.mean() > 0.1 and np.mean(res["coef"][0][real] == ref_coef[real]) > 0.9995
+    assert np.abs(res["coef"][0].astype(np.float64) - ref_coef).max() <= 2e-7 * ac_max(ref_coef)
+    assert np.array_equal(res["idx"][0], O.indices(ref_coef, k=k).astype(np.uint32))
+    ps, ss = ctx.prune_stats(), ctx.select_stats()
+    assert ss["exact_fallback_frames"] == 0, ss
+    assert ps["pruned_chunks"] >= 1 and ps["redone_chunks"] == 0, ps
+
+
 def test_8k_pipeline_and_resize_attack_parity_with_oracle():
     """BASELINE configs[4]: a 7680x4320 frame with a 10000-coefficient mark -- coefficient, index, extracted
     mark and similarity parity; then the flow of tests/attack_resize.rs:17-66 at that size (embed ->

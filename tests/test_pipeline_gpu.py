@@ -506,6 +506,25 @@ def test_bench_under_torchrun_two_ranks(tmp_path):
     assert np.load(dumpf)["sims"].shape == (6,)
 
 
+def test_bench_eight_ranks_dry_run_on_one_gpu(tmp_path):
+    """SURVEY 8(e) / BASELINE configs[3]: the 8-rank launch of the driver's scaling sweep, rehearsed on this box's single
+    GPU (every rank on device 0, gloo coordination; NO throughput is claimed from it): eight processes, eight contexts,
+    eight streaming rings for the handle leg, the contiguous block split, rank 0's host legs (CPU baseline, parity,
+    handles) while seven ranks wait in the final barrier, one JSON line -- so that the first real 8-GPU run can only
+    fail for hardware reasons.  The gathered per-frame results equal a one-process run of the same 16 frames."""
+    eight, one = str(tmp_path / "eight.npz"), str(tmp_path / "one.npz")
+    small = ["--steps", "1", "--warmup", "1", "--width", "512", "--height", "256", "--k", "100", "--no-alt", "--no-serial-leg",
+             "--no-timers-off-leg"]
+    j8 = _bench(["--gpus", "8", "--batch", "2", "--dump", eight] + small, {"SSW_BENCH_SHARE_DEVICE": "1", "SSW_BENCH_DIST_BACKEND": "gloo"})
+    assert j8["n_gpus"] == 8 and j8["ranks"]["ranks_seen"] == list(range(8)) and len(j8["ranks"]["mpix_per_s_per_rank"]) == 8
+    assert j8["scaling"] == "weak" and j8["config"]["total_frames"] == 16 and j8["config"]["frames_per_gpu"] == 2
+    assert j8["cpu_baseline"]["value"] > 0 and j8["parity"]["frames"][0]["sim_delta_vs_cpu_exact"] < 1e-4
+    assert j8["handle_api"]["bit_identical_to_batch_rgb8"] is True
+    j1 = _bench(["--gpus", "1", "--batch", "16", "--dump", one, "--no-cpu-baseline", "--no-handle-leg", "--no-full-transform-leg"] + small)
+    a, b = np.load(eight), np.load(one)
+    assert a["sims"].shape == (16,) and np.array_equal(a["sims"], b["sims"]) and np.array_equal(a["extracted"], b["extracted"])
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     import torch
     n = torch.cuda.device_count()
