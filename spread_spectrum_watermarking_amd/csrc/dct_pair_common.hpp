@@ -35,7 +35,13 @@ __host__ __device__ inline size_t blk_index(size_t line, unsigned k, size_t rows
 //   EPI_INV_OT EPI_INV_O one level down (deep inverse): the odd part of the half-length transform E combined with ITS even
 //              half T2 (`tmp`, length n/2 per line) into E itself, unrounded: T[n1] = T2[n1] + acc, T[n-1-n1] = T2[n1] - acc
 //              (`tmp_out`, length n per line; n = the half-length transform's length)
-enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4, EPI_INV_O_RGB = 5, EPI_INV_OT = 6 };
+//   EPI_FWD_COLOP (r5; forward ROW pass of a rows-first transform whose two passes run at level 2, f64): EPI_FWD's values --
+//              rounded to f32 like the store between the passes (src/dct2d.rs:152-168), then the f32 per-index factor --
+//              are not stored: the operand lines are ordered (frame, unit of the column fold, line of the unit), a 16-line
+//              MFMA tile holds the sixteen rows of one unit, and the epilogue applies the column pre-pass's arithmetic
+//              (dct_pair_colops.hpp: col_l2_unit) to them and stores the sixteen k-blocked COLUMN operand planes directly.
+//              No f32 plane between the passes, no column pre-pass: 16 B/px of HBM traffic less per forward transform.
+enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4, EPI_INV_O_RGB = 5, EPI_INV_OT = 6, EPI_FWD_COLOP = 7 };
 
 template <typename T>
 struct PairOutT {
@@ -73,6 +79,16 @@ struct PairOutT {
     // p2(pair) - e2off (output 2) of its class goes to column c + (e >> gsh) * ft + (e & ((1 << gsh) - 1)); gsh = log2 of the
     // class's entries per tile (ft a power of two), or 31 for one tile over the whole line
     unsigned ft = 0, gsh = 31, e2off = 0;
+    // EPI_FWD_COLOP: the sixteen column-operand planes (k-blocked: [cop_k16 / 8][cop_lines][8] doubles each, plane a at
+    // cop + a * cop_lines * cop_k16), the rotation tables of axes of length H, H/2, H/4, and the units per frame of the
+    // row pass's line order (H/16 rounded up to whole k-blocks)
+    T* cop = nullptr;
+    unsigned cop_k16 = 0, cop_lines = 0, cop_hup = 0;
+    const double *crot1 = nullptr, *crot2 = nullptr, *crot3 = nullptr;
+    // column pass behind such a row pass: the operand lines of a 128-line tile are in the class-major order of the row
+    // launches' frequencies (fwd_cm128_pos); tile row j is staged from line m0 + fwd_cm128_pos(j), i.e. the tile's columns
+    // come out natural and the epilogue is unchanged
+    unsigned xperm = 0;
 };
 
 // Column order of the intermediate plane between the two passes of a deep forward transform (row pass first): the

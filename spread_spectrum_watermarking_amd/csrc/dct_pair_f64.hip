@@ -182,13 +182,33 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
 //           sine) rows 2i | 2i+1 of the quarter-length bases; outputs acc1 +/- acc2          pairs = len/8, K = len/8
 //           (class E's first and last pair share slot 0: its y2 is the launch variant of the sine basis, row 0 = row len/8)
 //   sub: the class belongs to the transform of length len >> sub that a deeper folding level applies to the even part.
+// r5: a forward transform of n frames whose row launches write the column operands themselves (EPI_FWD_COLOP).  Rows first,
+// both passes at level 2, 128-frequency class tiles, the column planes exactly as wide as the padded units, and both passes
+// on 128-line tiles (a tile of the row pass IS one k-block of the column operands; small batches keep the unfused path).
+static bool launch_is_small(size_t lines, size_t pairs) {
+    return (unsigned long long)((lines + 127) / 128) * ((pairs + 63) / 64) < 448;
+}
+bool dct_pair_can_fuse_cols(size_t n_frames, size_t w, size_t h) {
+    if (tuning(TUNE_FUSE_COLS) == 0 || n_frames == 0 || w < h || w % 128 != 0 || h % 16 != 0) return false;
+    if (dct_pair_class_tile(w) != 128 || !dct_pair_efold(w) || !dct_pair_efold_cols(h, w, true)) return false;
+    const size_t hup = dct_pair_fused_units(h);
+    if (pair_kpad<double>(h / 8) != hup) return false;
+    if (n_frames * 16 * hup > 0xFFFFFFFFull) return false;
+    return !launch_is_small(n_frames * 16 * hup, w / 16) && !launch_is_small(n_frames * w, h / 16);
+}
+
 int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, int n_classes, const PairClassDesc* desc, float* out,
                                    double* tmp, size_t n_frames, size_t w, size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out,
-                                   bool class_major) {
+                                   bool class_major, const FuseCols* fuse) {
     if (n_frames == 0 || n_classes == 0) return SSW_OK;
     if (n_classes < 0 || n_classes > 8 || !desc) return SSW_ERR_BAD_ARG;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const size_t lines = is_row ? n_frames * h : n_frames * w;
+    // fused forward transform: the row launches (fuse->cop set) run over the unit-ordered, padded lines and write the
+    // column operands; the column launches (fuse set, cop null) read their tiles in the row launches' class-major order
+    const bool fuse_rows = fuse && fuse->cop, fuse_cols = fuse && !fuse->cop;
+    if (fuse && (inverse || n_classes != 1 || sink || !dct_pair_can_fuse_cols(n_frames, w, h) || fuse_rows != is_row)) return SSW_ERR_BAD_ARG;
+    if (fuse_rows && (!class_major || !fuse->rot1 || !fuse->rot2 || !fuse->rot3)) return SSW_ERR_BAD_ARG;
+    const size_t lines = fuse_rows ? n_frames * 16 * dct_pair_fused_units(h) : is_row ? n_frames * h : n_frames * w;
     const size_t len = is_row ? w : h;
     if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     const unsigned L = (unsigned)lines;
@@ -208,6 +228,7 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     if (n_classes > 1) inst.subname = inverse ? inst.subname : 3;
     // 64-line tiles when 128-line ones would not fill the 512 block slots of the chip (2 per CU)
     const bool small = (unsigned long long)((L + 127) / 128) * tiles_n < 448;
+    if (fuse && small) return SSW_ERR_BAD_ARG;
     const unsigned BM = small ? 64 : 128;
     const unsigned tiles_m = (L + BM - 1) / BM;
     // ... and 32-pair tiles when that spreads such a (single-class) launch more evenly over the 256 CUs (all its blocks are
@@ -231,6 +252,14 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     if (class_major && inverse && desc[0].kind == 9) po.cm = 1;
     if (class_major && inverse && is_row && dct_pair_efold_inv(len) && (desc[0].kind == 3 || desc[0].kind == 4) && desc[0].sub == 1) po.tcm = 1;
     if (class_major && !inverse) po.ft = dct_pair_class_tile(len);
+    if (fuse_rows) {
+        if (po.ft != 128 || inst.epi != EPI_FWD || inst.samex) return SSW_ERR_BAD_ARG;
+        po.cop = fuse->cop; po.cop_k16 = (unsigned)pair_kpad<double>(h / 8); po.cop_lines = (unsigned)(n_frames * w);
+        po.cop_hup = (unsigned)dct_pair_fused_units(h);
+        po.crot1 = fuse->rot1; po.crot2 = fuse->rot2; po.crot3 = fuse->rot3;
+        inst.epi = EPI_FWD_COLOP;
+    }
+    if (fuse_cols) po.xperm = 1;
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16)) && (!tmp_out || al(tmp_out, 16))) ? 1u : 0u;
     if (with_sink && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;
@@ -245,6 +274,10 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
 #define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) do { if (inst.subname == 0) SSW_LAUNCH_PAIR_SUB(COLS, EPI, SAMEX, 0); else SSW_LAUNCH_PAIR_SUB(COLS, EPI, SAMEX, 1); } while (0)
 #define SSW_LAUNCH_ROWCOL(EPI, SAMEX) do { if (is_row) SSW_LAUNCH_PAIR(false, EPI, SAMEX); else SSW_LAUNCH_PAIR(true, EPI, SAMEX); } while (0)
     switch (inst.epi) {
+    case EPI_FWD_COLOP:
+        if (inst.subname == 4) SSW_LAUNCH_PAIR_BM(false, EPI_FWD_COLOP, false, 4, 128);
+        else SSW_LAUNCH_PAIR_BM(false, EPI_FWD_COLOP, false, 3, 128);
+        break;
     case EPI_FWD_ADJ: SSW_LAUNCH_PAIR(false, EPI_FWD_ADJ, false); break;
     case EPI_FWD:
         if (inst.subname == 4) SSW_LAUNCH_PAIR_SUB(false, EPI_FWD, false, 4);

@@ -36,6 +36,7 @@
 // Lane l: li = l & 15 (line / pair inside a 16x16 tile), lq = l >> 4: in half-step s lane group lq
 // supplies k = 4 s + lq (the same assignment on both operands).
 #include "dct_pair_common.hpp"
+#include "dct_pair_colops.hpp"
 
 #include <cstdlib>
 #include <type_traits>
@@ -121,7 +122,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     unsigned xoff[XQ];
 #pragma unroll
     for (int q = 0; q < XQ; ++q) {
-        unsigned r = m0 + srow + 64 * q;
+        // (column pass behind a fused row pass: the tile's lines are in class-major order, row j of the tile is line
+        // fwd_cm128_pos(j) -- a permutation inside the same contiguous 8 KB of a k-step, whole 128-line tiles only)
+        unsigned r = m0 + ((COLS && BM == 128 && po.xperm) ? fwd_cm128_pos(srow + 64 * q) : srow + 64 * q);
         r = r < L ? r : L - 1;
         xoff[q] = ((r - m0) * 8 + 2 * sc) * 8u;
     }
@@ -423,6 +426,100 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
             }
         }
     };
+    // r5: forward row pass whose results go straight into the COLUMN pass's operand planes (EPI_FWD_COLOP, see
+    // dct_pair_common.hpp).  Tile tm = (frame z, unit group g): its 128 lines are the units 8 g .. 8 g + 7 of frame z, MFMA
+    // line tile i of this wave is unit u0 + i, and the tile's pairs are 2 x 16 NJ frequencies ("items") per wave.
+    //   1. per unit: every lane puts its 4 x 2 NJ results (rounded to f32 = the store between the passes,
+    //      src/dct2d.rs:152-168; then the per-index f32 factor) into the wave's LDS area [item][line of the unit], pitch 20
+    //      floats (conflict-free both ways), and reads back the sixteen lines of ITS item (lane, lane + 64);
+    //   2. col_l2_unit (the column pre-pass's arithmetic, tables of the unit by scalar index) -> sixteen doubles per item and unit;
+    //   3. per item and plane the NI units are NI consecutive doubles of one k-block piece: one or two 16-byte stores; the
+    //      two waves that share a tile row complete the 64-byte pieces, the pairs of one MFMA tile complete runs of
+    //      16 lines x 64 bytes per (plane, 128-frequency tile).
+    if constexpr (!COLS && EPI == EPI_FWD_COLOP) {
+        constexpr int NIT = 32 * NJ, NC = (NIT + 63) / 64, PITCH = 20;
+        static_assert(4 * NIT * PITCH * 4 <= (int)sizeof(lds), "transpose area");
+        static_assert(BM == 128, "a tile is one k-block of eight units");
+        __syncthreads();                      // every wave has read its last fragments: the operand tiles are free
+        float* tw = reinterpret_cast<float*>(lds) + wave * (NIT * PITCH);
+        auto lds_order = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        const unsigned Hc = po.H, HU = Hc / 16;
+        const unsigned tpf = po.cop_hup / 8;                       // line tiles per frame
+        const unsigned z = tm / tpf, g = tm - z * tpf;
+        const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wm / 16));
+        const bool plain = ep.first == 1.0f && ep.base == 1.0f;
+        // this lane's items: item f = lane + 64 c -> pair tile jn = f / 32, output (f / 16) & 1, pair f & 15
+        bool it_ok[NC];
+        size_t it_line[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned f = lane + 64 * c;
+            const unsigned pair = p0 + wn + 16 * (f >> 5) + (f & 15u);
+            const bool second = ((f >> 4) & 1u) != 0;
+            it_ok[c] = f < (unsigned)NIT && pair < NP && (second ? (pair >= po.p2lo && second_out) : pair < po.np1);
+            const unsigned mc = second ? fpos2(pair) : fpos1(pair);          // memory column = operand line of the column pass
+            it_line[c] = ((size_t)g * po.cop_lines + (size_t)z * po.W + (it_ok[c] ? mc : 0u)) * 8u + u0;
+        }
+        // f32 factor of the frequencies this lane's accumulators belong to (EPI_FWD: first for index 0, else base)
+        float f1[NJ], f2[NJ];
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+            const unsigned pair = p0 + wn + 16 * jn + li;
+            f1[jn] = fpos1(pair) == 0 ? ep.first : ep.base;
+            f2[jn] = fpos2(pair) == 0 ? ep.first : ep.base;
+        }
+        double o[NC][NI][16];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            lds_order();
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v1 = (float)acc1[i][jn][r], v2 = (float)acc2[i][jn][r];
+                    if (!plain) { v1 *= f1[jn]; v2 *= f2[jn]; }
+                    tw[(32 * jn + li) * PITCH + lq + 4 * r] = v1;
+                    tw[(32 * jn + 16 + li) * PITCH + lq + 4 * r] = v2;
+                }
+            lds_order();
+            const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)(8 * g + u0 + i));
+            const bool unit_ok = e < HU;
+            const ColL2Tab tab = col_l2_tab(po.crot1, po.crot2, po.crot3, unit_ok ? e : 0u, Hc);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const unsigned f = (lane + 64 * c) < (unsigned)NIT ? lane + 64 * c : 0u;
+                float x[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(tw + f * PITCH + 4 * q);
+                    x[4 * q] = t4[0]; x[4 * q + 1] = t4[1]; x[4 * q + 2] = t4[2]; x[4 * q + 3] = t4[3];
+                }
+                col_l2_unit(x, tab, o[c][i]);
+                if (!unit_ok) {
+#pragma unroll
+                    for (int a = 0; a < 16; ++a) o[c][i][a] = 0.0;              // units beyond the axis: the planes' zero padding
+                }
+            }
+        }
+        const size_t pstride = (size_t)po.cop_lines * po.cop_k16;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (!it_ok[c]) continue;
+            double* dst0 = po.cop + it_line[c];
+#pragma unroll
+            for (int a = 0; a < 16; ++a) {
+                double* d = dst0 + (size_t)a * pstride;
+#pragma unroll
+                for (int i = 0; i < NI; i += 2) *reinterpret_cast<f64x2*>(d + i) = (f64x2){o[c][i][a], o[c][i + 1][a]};
+            }
+        }
+        trace_end();
+        return;
+    }
     // Row passes, EPI_FWD / EPI_INV_O.  While this wave stores its results the other resident block streams f64 MFMAs
     // on the same SIMD, and a VALU instruction of this wave then gets an issue slot about once per MFMA (64 cycles):
     // measured, the epilogue takes ~70 cycles per VALU instruction (tools/tile_trace.py) -- 36 us of a 125 us tile with

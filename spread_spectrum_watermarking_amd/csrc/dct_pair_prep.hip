@@ -3,6 +3,7 @@
 // MFMA consumes (T = double: every sum exact; T = float: one rounding per sum) and in the k-blocked
 // layout (dct_pair_common.hpp).  Also the half bases in that layout.
 #include "dct_pair_split.hpp"
+#include "dct_pair_colops.hpp"
 
 #include <cstdlib>
 
@@ -621,17 +622,31 @@ __global__ __launch_bounds__(256) void pair_prep16_rows_kernel(const void* __res
                                                               const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                               const double* __restrict__ rot3,
                                                               float* __restrict__ IP, float* __restrict__ QP,
-                                                              unsigned rows, unsigned W, unsigned K8, unsigned K16, unsigned tiles_e, unsigned efold) {
+                                                              unsigned rows, unsigned W, unsigned K8, unsigned K16, unsigned tiles_e, unsigned efold,
+                                                              unsigned unit_h, unsigned unit_hup) {
     const unsigned Nh = W / 2, Nq = W / 4, N8 = W / 8, N16 = W / 16;
     const unsigned e0 = (blockIdx.x % tiles_e) * 32 + (threadIdx.x & 7) * 4;
-    const unsigned row = (blockIdx.x / tiles_e) * 32 + (threadIdx.x >> 3);
-    if (row >= rows || e0 >= K16) return;
+    // operand line of this thread, and the image row it holds.  Natural order: the same number.  r5, fused forward
+    // transform (unit_h = H != 0, level 2 only): the lines of a frame are ordered (unit of the COLUMN fold, line of the unit)
+    // -- 16 * unit_hup lines per frame, unit_hup = H/16 rounded up to whole k-blocks of 8 -- so that a 16-line MFMA tile
+    // of the row GEMM holds the sixteen rows that meet in one unit of the column pre-pass (dct_pair_colops.hpp).  A block's
+    // 32 lines are then 32 rows of sixteen regions of the frame: the reads are 384-byte runs per row either way, the
+    // stores stay 2 KB runs.  `rows` counts operand lines (the planes' line stride).
+    const unsigned line = (blockIdx.x / tiles_e) * 32 + (threadIdx.x >> 3);
+    if (line >= rows || e0 >= K16) return;
+    unsigned row = line;
+    bool pad_line = false;
+    if (unit_h) {
+        const unsigned lpf = 16 * unit_hup, z = line / lpf, rem = line - z * lpf;
+        pad_line = (rem >> 4) >= unit_h / 16;
+        row = z * unit_h + (pad_line ? 0u : col_unit_row(rem >> 4, rem & 15u, unit_h));
+    }
     T* AD = static_cast<T*>(dp.ad); T* BS = static_cast<T*>(dp.bs);
     T* R1 = static_cast<T*>(dp.r1); T* R2 = static_cast<T*>(dp.r2);
     T* AS2 = static_cast<T*>(dp.as2); T* BD2 = static_cast<T*>(dp.bd2); T* AD2 = static_cast<T*>(dp.ad2); T* BS2 = static_cast<T*>(dp.bs2);
-    auto put = [&](T* plane, unsigned k, const vec4_t<T>& v) { *reinterpret_cast<vec4_t<T>*>(plane + blk_index<T>(row, k, rows)) = v; };
+    auto put = [&](T* plane, unsigned k, const vec4_t<T>& v) { *reinterpret_cast<vec4_t<T>*>(plane + blk_index<T>(line, k, rows)) = v; };
     const vec4_t<T> zero = {0, 0, 0, 0};
-    if (e0 >= N16) {                                              // padding of the n/16-wide planes
+    if (e0 >= N16 || pad_line) {                                  // padding of the n/16-wide planes; lines of the padding units
         put(AS2, e0, zero); put(BD2, e0, zero); put(AD2, e0, zero); put(BS2, e0, zero);
         if (efold) {
             void* const l2[12] = {dp.asp, dp.asm_, dp.bdp, dp.bdm, dp.oap, dp.obp, dp.oam, dp.obm, dp.r1p, dp.r1m, dp.r2a, dp.r2b};
@@ -1335,12 +1350,14 @@ size_t dct_pair_deep_elems(size_t lines, size_t len) {
     return lines * (6 * k8 + 4 * k16 > 16 * k16 ? 6 * k8 + 4 * k16 : 16 * k16);
 }
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
-                                const double* rot1, const double* rot2, const double* rot3, float* ip, float* qp) {
+                                const double* rot1, const double* rot2, const double* rot3, float* ip, float* qp, bool unit_order) {
     if (n_frames == 0) return SSW_OK;
     if (w > 0xFFFFFFull || h > 0xFFFFFFull || !dct_pair_can_deep_rows(w)) return SSW_ERR_BAD_DIMS;
     const unsigned K8 = (unsigned)dct_pair_split_kpad(w), K16 = (unsigned)dct_pair_split_kpad(w / 2);
     const unsigned tiles_e = (K16 + 31) / 32;
-    const size_t rows = n_frames * h;
+    if (unit_order && (h % 16 != 0 || !dct_pair_efold(w))) return SSW_ERR_BAD_ARG;
+    const unsigned unit_hup = unit_order ? (unsigned)dct_pair_fused_units(h) : 0u;
+    const size_t rows = unit_order ? n_frames * 16 * unit_hup : n_frames * h;       // operand lines
     const unsigned long long nblk = (unsigned long long)((rows + 31) / 32) * tiles_e;
     if (rows > 0xFFFFFFFFull || nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     DeepPlanes dp;
@@ -1360,7 +1377,7 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
     }
     const bool iq = ip && qp;
 #define SSW_PREP16(SRCV, IQV) pair_prep16_rows_kernel<double, SRCV, IQV><<<(unsigned)nblk, 256, 0, st>>>( \
-        src, dp, rot1, rot2, rot3, ip, qp, (unsigned)rows, (unsigned)w, K8, K16, tiles_e, efold)
+        src, dp, rot1, rot2, rot3, ip, qp, (unsigned)rows, (unsigned)w, K8, K16, tiles_e, efold, unit_order ? (unsigned)h : 0u, unit_hup)
     if (src_kind == 0) SSW_PREP16(0, false);
     else if (src_kind == 1) { if (iq) SSW_PREP16(1, true); else SSW_PREP16(1, false); }
     else if (src_kind == 2) { if (iq) SSW_PREP16(2, true); else SSW_PREP16(2, false); }

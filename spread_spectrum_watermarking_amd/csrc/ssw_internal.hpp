@@ -124,11 +124,14 @@ int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep, const RgbSink* sink = nullptr, double* tmp_out = nullptr, bool class_major = false);
+// r5, fused forward transform: the column operands a fused row launch writes (the sixteen planes) and the rotation tables
+// of H, H/2, H/4 its epilogue needs; a column launch behind it passes an empty FuseCols (its tiles are class-major)
+struct FuseCols { double* cop = nullptr; const double *rot1 = nullptr, *rot2 = nullptr, *rot3 = nullptr; };
 // several classes (same lines, same template instance) in one launch: single frames, whose launches are too small alone
 struct PairClassDesc { int kind, sub; const double *x1, *x2, *y1, *y2; };
 int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, int n_classes, const PairClassDesc* desc, float* out,
                                    double* tmp, size_t n_frames, size_t w, size_t h, Epilogue ep, const RgbSink* sink = nullptr,
-                                   double* tmp_out = nullptr, bool class_major = false);
+                                   double* tmp_out = nullptr, bool class_major = false, const FuseCols* fuse = nullptr);
 int launch_dct_pair_gemm_f32(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const float* x1, const float* x2,
                              const float* y1, const float* y2, float* out, float* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep, const RgbSink* sink = nullptr);
@@ -185,7 +188,12 @@ int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames
                                 const double* rot1, const double* rot2, bool class_major = false, const double* rot3 = nullptr);
 size_t dct_pair_deep_elems(size_t lines, size_t len);
 int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, size_t n_frames, size_t w, size_t h, double* base,
-                                const double* rot1, const double* rot2, const double* rot3, float* ip, float* qp);
+                                const double* rot1, const double* rot2, const double* rot3, float* ip, float* qp, bool unit_order = false);
+// r5, fused forward transform: units per frame of the row pass's line order (H/16 rounded up to whole k-blocks of 8) and
+// whether a transform of n frames takes it (dct_pair_f64.hip)
+inline size_t dct_pair_fused_units(size_t h) { return ((h / 16 + 7) / 8) * 8; }
+bool dct_pair_can_fuse_cols(size_t n_frames, size_t w, size_t h);
+
 int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const float* y, unsigned cap, unsigned Kp, float* out,
                                          unsigned out_stride, unsigned off, size_t lines);
 

@@ -183,7 +183,7 @@ int check_config(const ssw_config* cfg) {
 // frames, 514 full-HD ones, 32 8K ones -- capped where the f64 operand planes of a pass would pass 4 GB (the
 // operand-ready GEMMs walk them with 32-bit offsets).  The GEMM grids then run ~64 rounds of blocks: against
 // 2^28 pixels (16 rounds, the r1 default) the tails and first-tile latencies weigh 2.8 % less at 4K, 1.8 % at
-// full HD, 1.4 % at 8K.  Workspace: 36 B/px of a pass per lane (38.7 GB), sized for 288 GB of HBM -- and
+// full HD, 1.4 % at 8K.  Workspace: up to 44 B/px of a pass per lane (r5: the fused forward transform keeps row and column operands side by side), sized for 288 GB of HBM -- and
 // clamped to half of what the device can give right now (free memory + what the lanes already hold), so that
 // a smaller device or a co-tenant (torch's caching allocator) gets smaller passes instead of an
 // SSW_ERR_OUT_OF_MEMORY.
@@ -216,8 +216,8 @@ size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames) 
             // (dev_malloc gives those back before it fails).  A clamp can turn a one-pass call into several passes,
             // i.e. into two lanes: budget for one lane first, then for the lane count the clamped pass size implies.
             const size_t budget = (free_b + lane_bytes_held(ctx) + ctx->plane_pool_bytes) / 2;
-            size_t c1 = std::max<size_t>(1, std::min(c, budget / (36 * px)));
-            if (ctx->overlap && n_frames > c1) c1 = std::max<size_t>(1, std::min(c1, budget / (2 * 36 * px)));
+            size_t c1 = std::max<size_t>(1, std::min(c, budget / (44 * px)));
+            if (ctx->overlap && n_frames > c1) c1 = std::max<size_t>(1, std::min(c1, budget / (2 * 44 * px)));
             c = c1;
         } else {
             (void)hipGetLastError();
@@ -253,6 +253,7 @@ size_t split_scratch_elems(size_t n, size_t w, size_t h) {
     size_t e = dct_pair_split_elems(n, w, h);
     if (dct_pair_can_deep_rows(w) || dct_pair_can_deep_inv_rows(w)) e = std::max(e, dct_pair_deep_elems(n * h, w));
     if (dct_pair_can_deep_cols(h)) e = std::max(e, dct_pair_deep_elems(n * w, h));
+    if (dct_pair_can_fuse_cols(n, w, h)) e = std::max(e, dct_pair_deep_elems(n * 16 * dct_pair_fused_units(h), w));      // unit-ordered, padded lines
     if (dct_pair_can_semi_deep_cols(h)) e = std::max(e, dct_pair_semi_deep_elems(n * w, h));
     return e;
 }
@@ -348,14 +349,78 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 SSW_TRY(get_basis(ctx, len / 8, false, true, 3, &h0));
                 SSW_TRY(get_basis(ctx, len / 8, false, true, 4, &h1));
             }
-            const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
-            double* q = sp + 6 * p8;
             const void *sb0 = sb[0], *sb1 = sb[1], *sb2_ = sb[2], *sb3 = sb[3];
             const void *t0 = sb2[0], *t1 = sb2[1], *t2 = sb2[2], *t3 = sb2[3];
             // rows first and both passes deep: the row launches write class-major, the column pre-pass reads it back
             const size_t fh = x.full_h ? x.full_h : h;
             const bool cm = cm0;
             (void)fh;
+            // r5: FUSED forward transform (dct_pair_can_fuse_cols: rows first, both passes at level 2, batches on 128-line
+            // tiles).  The row pre-pass orders its lines (frame, unit of the column fold, line of the unit), the row launches'
+            // epilogue (EPI_FWD_COLOP) rounds to f32 -- the store between the passes, src/dct2d.rs:152-168 -- applies the column
+            // pre-pass's arithmetic to its accumulators and writes the sixteen column-operand planes; the column pass is its
+            // eight launches only.  The f32 plane between the passes and the column pre-pass are gone: 4 + 4 + 8 B/px become 8.
+            const bool fuse = l2 && cm && !x.full_h && dct_pair_can_fuse_cols(n, w, h);
+            if (fuse) {
+                const size_t k16h = dct_pair_split_kpad(h / 2), cplane = n * w * k16h;             // column operands: n w lines, K16(h) wide
+                SSW_TRY(grow(ws.operand[0], 16 * cplane * sizeof(double)));
+                double* cop = (double*)ws.operand[0].p;
+                auto CP = [=](int j) { return (const double*)(cop + (size_t)j * cplane); };
+                const double f_main = pair_gemm_flop(is_row, 7, 0, n, w, h), f_all = 8.0 * f_main;
+                if (is_row) {
+                    const void *crot1 = nullptr, *crot2 = nullptr, *crot3 = nullptr;
+                    SSW_TRY(get_basis(ctx, h, false, true, 9, &crot1));
+                    SSW_TRY(get_basis(ctx, h / 2, false, true, 9, &crot2));
+                    SSW_TRY(get_basis(ctx, h / 4, false, true, 9, &crot3));
+                    const size_t lpad = n * 16 * dct_pair_fused_units(h), p16r = lpad * dct_pair_split_kpad(len / 2);
+                    auto P = [=](int j) { return (const double*)(sp + (size_t)j * p16r); };
+                    const double pad = (double)lpad / (double)(n * h);                              // the padding units' share of the flop
+                    ch.push_back({true, [=](hipStream_t st) -> int {
+                        StageTimer t(ctx, st_prep, st, prep_bytes);
+                        return launch_dct_pair_prep16_rows(st, from_rgb ? pix_src_kind(rgb_u8) : 0, from_rgb ? rgb : (const void*)src, n, w, h, sp,
+                                                           (const double*)rot, (const double*)rot2, (const double*)rot3,
+                                                           from_rgb ? iq_i : nullptr, from_rgb ? iq_q : nullptr, true);
+                    }});
+                    const PairClassDesc d[8] = {{1, 2, P(8), P(9), (const double*)h0, (const double*)h1},
+                                                {9, 0, P(10), P(11), (const double*)t0, (const double*)t1},
+                                                {3, 1, P(12), P(13), (const double*)t0, (const double*)t1},
+                                                {4, 1, P(14), P(15), (const double*)t2, (const double*)t3},
+                                                {5, 0, P(0), P(3), (const double*)t0, (const double*)t1},
+                                                {6, 0, P(1), P(2), (const double*)t2, (const double*)t3},
+                                                {8, 0, P(6), P(7), (const double*)t0, (const double*)t1},
+                                                {7, 0, P(4), P(5), (const double*)t0, (const double*)t1}};
+                    const FuseCols fc{cop, (const double*)crot1, (const double*)crot2, (const double*)crot3};
+                    ch.push_back({false, [=](hipStream_t st) -> int {
+                        StageTimer t(ctx, st_pass, st, f_all * pad);
+                        t.traffic(px * (esz + 8.0));                     // row operands in, column operands out
+                        for (int c = 0; c < 7; ++c)
+                            SSW_TRY(launch_dct_pair_gemm_multi_f64(st, true, false, 1, &d[c], nullptr, nullptr, n, w, h, ep, nullptr, nullptr, true, &fc));
+                        StageTimer tm(ctx, st_main, st, f_main * pad);
+                        return launch_dct_pair_gemm_multi_f64(st, true, false, 1, &d[7], nullptr, nullptr, n, w, h, ep, nullptr, nullptr, true, &fc);
+                    }});
+                    return SSW_OK;
+                }
+                const PairClassDesc d[8] = {{1, 2, CP(8), CP(9), (const double*)h0, (const double*)h1},
+                                            {9, 0, CP(10), CP(11), (const double*)t0, (const double*)t1},
+                                            {3, 1, CP(12), CP(13), (const double*)t0, (const double*)t1},
+                                            {4, 1, CP(14), CP(15), (const double*)t2, (const double*)t3},
+                                            {5, 0, CP(0), CP(3), (const double*)t0, (const double*)t1},
+                                            {6, 0, CP(1), CP(2), (const double*)t2, (const double*)t3},
+                                            {8, 0, CP(6), CP(7), (const double*)t0, (const double*)t1},
+                                            {7, 0, CP(4), CP(5), (const double*)t0, (const double*)t1}};
+                const FuseCols fc{};
+                ch.push_back({false, [=](hipStream_t st) -> int {
+                    StageTimer t(ctx, st_pass, st, f_all);
+                    t.traffic(gemm_bytes(0.0));
+                    for (int c = 0; c < 7; ++c)
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, false, false, 1, &d[c], dst, nullptr, n, w, h, ep, nullptr, nullptr, false, &fc));
+                    StageTimer tm(ctx, st_main, st, f_main);
+                    return launch_dct_pair_gemm_multi_f64(st, false, false, 1, &d[7], dst, nullptr, n, w, h, ep, nullptr, nullptr, false, &fc);
+                }});
+                return SSW_OK;
+            }
+            const size_t p8 = lines * dct_pair_split_kpad(len), p16 = lines * dct_pair_split_kpad(len / 2);
+            double* q = sp + 6 * p8;
             ch.push_back({true, [=](hipStream_t st) -> int {
                 StageTimer t(ctx, st_prep, st, prep_bytes);
                 if (!is_row) return launch_dct_pair_prep16_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm, (const double*)rot3);

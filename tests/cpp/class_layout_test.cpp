@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <vector>
 #include "../../spread_spectrum_watermarking_amd/csrc/dct_pair_common.hpp"
+#include "../../spread_spectrum_watermarking_amd/csrc/dct_pair_colops.hpp"
 
 using namespace ssw;
 
@@ -88,6 +89,25 @@ int main() {
                         if (inverse_class_pos(m, n, t, true) != (2 * c + h) * (t / 8) + i) return fail("level-2 inverse run", n, m);
                         if ((n - 1 - m) % 8 != pairs[c][1 - h]) return fail("mirror leaves its class", n, m);
                     }
+        }
+    }
+    // r5, the fused forward transform (dct_pair_colops.hpp): the closed form of the 128-frequency level-2 tile equals the
+    // layout's pos(), and (unit, line) <-> frame row is a bijection whose line v mirrors line 15 - v
+    {
+        const ForwardClassLayout fl{3840, 128, true};
+        for (unsigned j = 0; j < 3840; ++j)
+            if (fl.natural((j / 128) * 128 + fwd_cm128_pos(j % 128)) != j) return fail("fwd_cm128_pos", 3840, j);
+        for (unsigned H : {144u, 720u, 2160u, 4320u}) {
+            std::vector<int> seen(H, 0);
+            for (unsigned e = 0; e < H / 16; ++e)
+                for (unsigned v = 0; v < 16; ++v) {
+                    const unsigned y = col_unit_row(e, v, H);
+                    unsigned e2 = 0, v2 = 0;
+                    if (y >= H || seen[y]++) return fail("col_unit_row not a bijection", H, y);
+                    col_unit_of_row(y, H, e2, v2);
+                    if (e2 != e || v2 != v) return fail("col_unit_of_row", H, y);
+                    if (col_unit_row(e, 15 - v, H) != H - 1 - y) return fail("line 15 - v is not the mirror row", H, y);
+                }
         }
     }
     std::printf("ok\n");

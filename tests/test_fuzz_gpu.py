@@ -49,6 +49,18 @@ def test_level2_row_passes_on_small_shapes():
     assert lines[-1] == "level-2 checks: all good"
 
 
+def test_fused_forward_transform_equals_the_unfused_one():
+    """r5 (csrc/dct_pair_f64_kernel.hpp, EPI_FWD_COLOP): the forward transform whose row launches write the column operands
+    themselves -- no f32 plane between the passes, src/dct2d.rs:152-168 stays the rounding point -- against the unfused path
+    (ssw_tuning_set fuse_cols = 0), coefficient planes bit for bit on six shapes from 144 x 256 to 8K (every tail mode of the
+    row launches), first / last frames against the oracle, two batch pipelines end to end: tools/fuse_check.py."""
+    import fuse_check
+    lines = []
+    bad = fuse_check.run(lines.append)
+    assert bad == 0, "\n".join(l for l in lines if "FAIL" in l)
+    assert lines[-1] == "fused forward transform: all good"
+
+
 def test_tuning_table_round_trip():
     """ssw_tuning_set / get / reset (include/ssw.h): defaults, a set value, reset, unknown names."""
     from spread_spectrum_watermarking_amd import _lib as L, tuning
