@@ -853,7 +853,10 @@ def main():
         args.steps = keep
 
     alt = None
-    if args.alt and not args.no_alt:
+    if args.alt and not args.no_alt and not L.all_strategies():
+        print("bench.py: --alt needs the diagnostic build (make ALL_STRATEGIES=1; SSW_LIB_PATH=.../libssw_hip_all.so): the default "
+              "library runs SSW_PRECISION_F32 on the dense kernels; leg skipped", file=sys.stderr)
+    elif args.alt and not args.no_alt:
         alt_name = "f32" if args.precision == "f64" else "f64"
         _, alt_elapsed, alt_stage, _, alt_sims, _ = measure(alt_name)
         alt_kernels, (alt_roofline, _), _ = kernel_report(alt_name, alt_stage, steps)

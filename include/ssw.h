@@ -93,6 +93,11 @@ typedef struct ssw_reader ssw_reader;
 
 /* ---- library / context ---------------------------------------------------- */
 const char* ssw_version(void);
+/* 1 when the loaded library is the diagnostic build (`make ALL_STRATEGIES=1`: lib/libssw_hip_all.so) that also carries the
+   superseded strategies of the transform (src/dct2d.rs:83-219) -- levels 1 / 2 of ssw_ctx_set_dct_folding (in-kernel folding)
+   and the f32 twin of the operand-ready GEMMs; 0 for the default library, where those requests run the dense kernels
+   (same results to their precision's bars, slower). */
+int ssw_build_all_strategies(void);
 const char* ssw_status_string(int status);
 /* Text of the last failing HIP call on this thread (empty string if none). */
 const char* ssw_last_error(void);
@@ -182,7 +187,9 @@ int ssw_ctx_get_select_stats(ssw_ctx* ctx, uint64_t* stats);
      6  level 5 without the size threshold (shorter rows lose more to the extra small launches than
         they save; for tests)
    In f64 all levels produce the same f64-accurate result rounded once to f32; in f32 each folding
-   level adds one rounding per operand sum (tests/test_gpu_parity.py holds both to their bars). */
+   level adds one rounding per operand sum (tests/test_gpu_parity.py holds both to their bars).
+   The default library carries levels 0 and 3 .. 6 in f64; levels 1 / 2 and every folded level in SSW_PRECISION_F32 are
+   part of the diagnostic build only (ssw_build_all_strategies) and run dense otherwise. */
 #define SSW_DCT_FOLDING_DEFAULT 5
 int ssw_ctx_set_dct_folding(ssw_ctx* ctx, int level);
 /* f64 precision, folding level 4 and up: the odd half of a folded transform (a DCT-IV of half the length, the one part

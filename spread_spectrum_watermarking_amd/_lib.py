@@ -41,6 +41,7 @@ _cfgp = C.POINTER(Config)
 # name -> (restype, argtypes); this table is also what tests check against include/ssw.h
 SIGNATURES = {
     "ssw_version": (C.c_char_p, []),
+    "ssw_build_all_strategies": (C.c_int, []),
     "ssw_status_string": (C.c_char_p, [C.c_int]),
     "ssw_last_error": (C.c_char_p, []),
     "ssw_config_default": (None, [_cfgp]),
@@ -141,6 +142,11 @@ def load() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def all_strategies() -> bool:
+    """True when the loaded library is the diagnostic build with every transform strategy (make ALL_STRATEGIES=1)."""
+    return bool(load().ssw_build_all_strategies())
 
 
 class SswError(RuntimeError):

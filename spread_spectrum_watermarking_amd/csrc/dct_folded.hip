@@ -56,6 +56,7 @@ __global__ void make_half_basis_f32_kernel(size_t n, bool inverse, int parity, s
 // Rows of the half bases are padded with zeros to a multiple of the k-step, so the GEMM main loops
 // need no tail predication: operand loads past the end of the sum axis are clamped to valid
 // addresses and multiply a zero basis entry.
+bool build_all_strategies() { return true; }        // this unit is only part of `make ALL_STRATEGIES=1`
 size_t half_basis_kpad(size_t n) { return ((n / 2 + FBK - 1) / FBK) * FBK; }
 
 int launch_make_half_basis_f32(hipStream_t st, size_t n, bool inverse, int parity, float* out) {

@@ -1190,6 +1190,7 @@ size_t dct_pair_operand_elems(bool f64, size_t n_frames, size_t w, size_t h) {
 
 bool dct_pair_can_run(bool f64, size_t n_frames, size_t w, size_t h, const float* in, const float* out) {
     // an operand plane must stay below 4 GB (32-bit scalar offsets walk its k-blocks)
+    if (!f64 && !build_all_strategies()) return false;          // the f32 twin (dct_pair_f32.hip) is part of the diagnostic build only
     return dct_rows_can_fold(w, in, out) && dct_cols_can_fold(w, h, in, out) && w % 8 == 0 && h % 8 == 0 &&
            dct_pair_operand_elems(f64, n_frames, w, h) * (f64 ? 8 : 4) <= 0xFFFFFFFFull;
 }

@@ -65,6 +65,9 @@ int launch_dct_cols(hipStream_t st, int precision, const float* in, float* out, 
 // Half bases: (N/2)x(N/2), layout [out][sum], parity 0 = even frequencies, 1 = odd.
 size_t half_basis_kpad(size_t n);   // row stride of a half basis: N/2 rounded up to the k-step, zero padded
 int launch_make_half_basis_f32(hipStream_t st, size_t n, bool inverse, int parity, float* out);
+// false in the default build: in-kernel folding (dct_folded*.hip) and the f32 operand-ready twin (dct_pair_f32.hip) are not
+// compiled in (dct_strategies_off.hip); `make ALL_STRATEGIES=1` builds the diagnostic library with every strategy
+bool build_all_strategies();
 bool dct_rows_can_fold(size_t w, const float* in, const float* out);
 bool dct_cols_can_fold(size_t w, size_t h, const float* in, const float* out);
 int launch_dct_rows_folded_f32(hipStream_t st, bool inverse, const float* in, float* out, size_t rows,

@@ -162,6 +162,7 @@ int forward_from_host(ssw_ctx* ctx, const void* host_rgb, int u8, size_t w, size
 extern "C" {
 
 const char* ssw_version(void) { return "ssw-hip 0.1.0 (gfx950)"; }
+int ssw_build_all_strategies(void) { return ssw::build_all_strategies() ? 1 : 0; }
 
 const char* ssw_status_string(int s) {
     switch (s) {

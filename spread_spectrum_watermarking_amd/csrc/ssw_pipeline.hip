@@ -280,8 +280,10 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
     const size_t len = is_row ? w : h;
     const double px = (double)n * (double)w * (double)h;
     const double esz = f64 ? 8.0 : 4.0;
-    const bool fold = ctx->fold && (is_row ? dct_rows_can_fold(w, src, dst) : dct_cols_can_fold(w, h, src, dst));
-    const bool operand = fold && ctx->fold_level >= 3 && dct_pair_can_run(f64, n, w, h, src, dst);
+    const bool can_fold = ctx->fold && (is_row ? dct_rows_can_fold(w, src, dst) : dct_cols_can_fold(w, h, src, dst));
+    const bool operand = can_fold && ctx->fold_level >= 3 && dct_pair_can_run(f64, n, w, h, src, dst);
+    // (default build: the in-kernel folding of dct_folded*.hip is not compiled in -- what the pair path does not take runs dense)
+    const bool fold = can_fold && (operand || build_all_strategies());
     const bool from_rgb = x.rgb && first_pass;
     if (from_rgb && !(operand && is_row && ctx->fold_level >= 4 && dct_pair_can_fold2(len)))
         return SSW_ERR_BAD_ARG;                                    // can_fuse_rgb() checks the same conditions

@@ -11,6 +11,21 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _all_strategies():
+    """Is the loaded library the diagnostic build (make ALL_STRATEGIES=1, SSW_LIB_PATH=.../libssw_hip_all.so)?  The default
+    library carries the f64 pair path and the dense kernels only; the strategy-matrix tests (in-kernel folding, the f32
+    operand-ready twin) parametrise over what is loaded."""
+    try:
+        from spread_spectrum_watermarking_amd import _lib as L
+        return L.all_strategies()
+    except Exception:
+        return False
+
+
+ALL_STRATEGIES = _all_strategies()
+needs_all_strategies = pytest.mark.skipif(not ALL_STRATEGIES, reason="needs the diagnostic build (make ALL_STRATEGIES=1; SSW_LIB_PATH)")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -14,6 +14,8 @@ from spread_spectrum_watermarking_amd import _lib as L
 
 pytestmark = pytest.mark.gpu
 F32, F64 = L.PRECISION_F32, L.PRECISION_F64
+from conftest import ALL_STRATEGIES  # noqa: E402
+PRECISIONS = [F32, F64] if ALL_STRATEGIES else [F64]      # f32: the diagnostic build's operand-ready twin (conftest.py)
 
 
 def _frame8(seed, w, h):
@@ -21,7 +23,7 @@ def _frame8(seed, w, h):
 
 
 @pytest.mark.parametrize("shape", [(192, 108), (208, 80), (1040, 144), (100, 75), (37, 64)])
-@pytest.mark.parametrize("precision", [F32, F64])
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_rgb8_handles_equal_batch_entry_points_and_f32_handles(shape, precision):
     """ssw_writer_create_rgb8 / ssw_writer_mark_rgb8 / ssw_reader_create_rgb8 (u8 host frames straight through)
     are bit-identical to ssw_batch_*_rgb8 with one frame and to the f32 handles fed with the host-converted frame
@@ -74,7 +76,7 @@ def test_rgb8_handles_equal_batch_entry_points_and_f32_handles(shape, precision)
 
 
 @pytest.mark.parametrize("shape", [(256, 144), (1024, 272), (208, 80), (100, 75), (37, 64)])
-@pytest.mark.parametrize("precision", [F32, F64])
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_rgb16_entry_points_equal_the_f32_ones_on_host_converted_frames(shape, precision):
     """SURVEY 8(f) rank 2, the 16-bit half: `into_rgb32f()` of an ImageRgb16 (src/algorithm.rs:308, :476: v / 65535) runs
     on the device -- ssw_writer_create_rgb16 / ssw_reader_create_rgb16 / ssw_batch_*_rgb16 are bit-identical to the f32
@@ -245,7 +247,7 @@ def test_handles_in_flight_do_not_disturb_each_other():
         assert wm.Tester(e, ctx).similarity(mark).similarity > 0.5 * np.linalg.norm(mark)
 
 
-@pytest.mark.parametrize("precision", [F32, F64])
+@pytest.mark.parametrize("precision", PRECISIONS)
 def test_derived_reader_is_transformed_on_use_and_only_where_it_is_read(precision):
     """Reader::derived (src/algorithm.rs:469-480) only uploads; Reader::extract (:529-562) then transforms the
     frequency columns the base reader's first k indices use (the batch path's pruned transform, n = 1).  Same values
