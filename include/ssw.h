@@ -216,6 +216,7 @@ int ssw_ctx_set_odd_split(ssw_ctx* ctx, int enable);
      bn32 (-1)             32-pair tiles for small single-class launches: -1 automatic, 0 / 1 forced
      band_split (1)        single-image handles: row pass of the top half beside the upload of the bottom half
      fuse_cols (1)         forward transform: the row GEMMs' epilogue writes the column operands (no f32 plane between the passes)
+     fuse_inv_cols (0)     inverse transform: the same (bit-identical, 8 B/px less traffic, measured no faster: off)
    An entry never set reads its SSW_<NAME> environment variable at first use (the r4 behaviour), else the default.
    ssw_tuning_set takes effect for the calls that follow; workspaces and cached plans of existing contexts were sized
    under the old values, so change a value before creating the context that should see it (tests use a fresh context).

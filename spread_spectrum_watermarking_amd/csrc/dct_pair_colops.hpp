@@ -78,6 +78,43 @@ __device__ inline void col_l2_unit(const float (&x)[16], const ColL2Tab& t, doub
     split_one_r(SD[0], SD[1], SD[2], SD[3], t.rc, o[12], o[13], o[14], o[15]);
 }
 
+// ---- the INVERSE column pass at level 2 (prep16_inv_cols_l2_kernel) ------------------------------------------------------
+// Coefficient row that line v of unit k (< H/16) holds, km = H/8 - 1 - k the unit's mirror:
+//   v = 0 .. 3   2k+1, H/2-1-2k, H/2+2k+1, H-1-2k          (the odd part's unit k)
+//   v = 4 .. 7   the same rows of unit km
+//   v = 8, 9     16k, 16k+8                                 (the eighth-length even part)
+//   v = 10, 11   8k+4, 8km+4                                (R2 at k and at its mirror)
+//   v = 12 .. 15 4k+2, H/2-2-4k, H/2+4k+2, H-2-4k           (the half-length odd part's unit k)
+__host__ __device__ inline unsigned inv_col_unit_row(unsigned k, unsigned v, unsigned H) {
+    const unsigned Hh = H / 2, km = H / 8 - 1 - k;
+    if (v < 8) {
+        const unsigned q = v < 4 ? k : km;
+        switch (v & 3u) { case 0: return 2 * q + 1; case 1: return Hh - 1 - 2 * q; case 2: return Hh + 2 * q + 1; default: return H - 1 - 2 * q; }
+    }
+    if (v < 12) return v == 8 ? 16 * k : v == 9 ? 16 * k + 8 : v == 10 ? 8 * k + 4 : 8 * km + 4;
+    switch (v & 3u) { case 0: return 4 * k + 2; case 1: return Hh - 2 - 4 * k; case 2: return Hh + 4 * k + 2; default: return H - 2 - 4 * k; }
+}
+// x[v]: the sixteen f32 values of the unit's rows (the inverse row pass's results, rounded like the store between the
+// passes, src/dct2d.rs:152-168); o[a]: entry k of the sixteen operand planes of prep16_inv_cols_l2_kernel, by number.
+// The map is block diagonal -- planes 0 .. 7 from lines 0 .. 7, planes 8 .. 15 from lines 8 .. 15 -- and the two halves are
+// separate functions so that a caller can hold one half at a time.  Tables: col_l2_tab (the same five as the forward fold).
+__device__ inline void inv_col_l2_unit_lo(const float (&x)[8], const ColL2Tab& t, double (&o)[8]) {
+    double as, bd, ad, bs, asm_, bdm, adm, bsm;
+    split_one_r((double)x[0], (double)x[1], (double)x[2], (double)x[3], t.ra, as, bd, ad, bs);
+    split_one_r((double)x[4], (double)x[5], (double)x[6], (double)x[7], t.rb, asm_, bdm, adm, bsm);
+    o[0] = as + asm_; o[1] = as - asm_; o[2] = bd + bdm; o[3] = bd - bdm;
+    const double c3 = t.c3, s3 = t.s3;
+    const double au = ad * c3 + adm * s3, bu = adm * c3 - ad * s3;
+    const double av = bsm * c3 + bs * s3, bv = bs * c3 - bsm * s3;
+    o[4] = au + av; o[5] = bu + bv; o[6] = au - av; o[7] = bu - bv;
+}
+__device__ inline void inv_col_l2_unit_hi(const float (&x)[8], const ColL2Tab& t, double (&o)[8]) {
+    o[0] = (double)x[0]; o[1] = (double)x[1];
+    const double q = (double)x[2], qm = (double)x[3];
+    o[2] = q * t.c3 + qm * t.s3; o[3] = qm * t.c3 - q * t.s3;
+    split_one_r((double)x[4], (double)x[5], (double)x[6], (double)x[7], t.rc, o[4], o[5], o[6], o[7]);
+}
+
 // memory column, inside a class-major tile of 128 frequencies at level 2 (ForwardClassLayout{n, 128, true}), of the tile's
 // natural frequency j: 8 * class(j mod 16) + j / 16
 __host__ __device__ inline unsigned fwd_cm128_pos(unsigned j) {

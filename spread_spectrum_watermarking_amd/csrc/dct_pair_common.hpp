@@ -41,7 +41,11 @@ __host__ __device__ inline size_t blk_index(size_t line, unsigned k, size_t rows
 //              MFMA tile holds the sixteen rows of one unit, and the epilogue applies the column pre-pass's arithmetic
 //              (dct_pair_colops.hpp: col_l2_unit) to them and stores the sixteen k-blocked COLUMN operand planes directly.
 //              No f32 plane between the passes, no column pre-pass: 16 B/px of HBM traffic less per forward transform.
-enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4, EPI_INV_O_RGB = 5, EPI_INV_OT = 6, EPI_FWD_COLOP = 7 };
+//   EPI_INV_O_COLOP (r5; the last launches of an inverse ROW pass, the same conditions): EPI_INV_O's four outputs per pair
+//              -- x[n1] = E[n1] + a1, x[n-1-n1] = E[n1] - a1, the same for n2; rounded to f32 like the store between the passes
+//              -- feed the inverse column pre-pass's arithmetic (inv_col_l2_unit_lo / _hi) and leave as column operands.
+enum { EPI_FWD = 0, EPI_FWD_ADJ = 1, EPI_INV = 2, EPI_INV_E = 3, EPI_INV_O = 4, EPI_INV_O_RGB = 5, EPI_INV_OT = 6, EPI_FWD_COLOP = 7,
+       EPI_INV_O_COLOP = 8 };
 
 template <typename T>
 struct PairOutT {
@@ -88,7 +92,7 @@ struct PairOutT {
     // column pass behind such a row pass: the operand lines of a 128-line tile are in the class-major order of the row
     // launches' frequencies (fwd_cm128_pos); tile row j is staged from line m0 + fwd_cm128_pos(j), i.e. the tile's columns
     // come out natural and the epilogue is unchanged
-    unsigned xperm = 0;
+    unsigned xperm = 0;       // 1: forward order (fwd_cm128_pos), 2: inverse order (inverse_class_pos at level 2 inside 128 positions)
 };
 
 // Column order of the intermediate plane between the two passes of a deep forward transform (row pass first): the

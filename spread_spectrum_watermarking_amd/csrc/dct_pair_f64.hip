@@ -196,6 +196,18 @@ bool dct_pair_can_fuse_cols(size_t n_frames, size_t w, size_t h) {
     if (n_frames * 16 * hup > 0xFFFFFFFFull) return false;
     return !launch_is_small(n_frames * 16 * hup, w / 16) && !launch_is_small(n_frames * w, h / 16);
 }
+// ... and the inverse transform of such frames (deep inverse rows need whole 128-column tiles anyway)
+// (measured at 4K, r5: the pre-pass it removes takes 2.6 ms per 128 frames, the four launches that take over its work grow by
+// 2.7 ms -- four output positions per pair instead of the forward launches' two frequencies, i.e. twice the operand bytes
+// per tile in 16-byte pieces and a second read of E: bit-identical, 8 B/px less HBM traffic, no faster.  Off by default.)
+bool dct_pair_can_fuse_inv_cols(size_t n_frames, size_t w, size_t h) {
+    if (tuning(TUNE_FUSE_INV_COLS) == 0 || n_frames == 0 || w < h || w % 128 != 0 || h % 16 != 0) return false;
+    if (dct_pair_class_tile(w) != 128 || !dct_pair_efold_inv(w) || !dct_pair_efold_cols(h, w, true)) return false;
+    const size_t hup = dct_pair_fused_units(h);
+    if (pair_kpad<double>(h / 8) != hup) return false;
+    if (n_frames * 16 * hup > 0xFFFFFFFFull) return false;
+    return !launch_is_small(n_frames * 16 * hup, w / 16) && !launch_is_small(n_frames * w, h / 16);
+}
 
 int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, int n_classes, const PairClassDesc* desc, float* out,
                                    double* tmp, size_t n_frames, size_t w, size_t h, Epilogue ep, const RgbSink* sink, double* tmp_out,
@@ -205,9 +217,11 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     if (w > 0xFFFFFFull || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
     // fused forward transform: the row launches (fuse->cop set) run over the unit-ordered, padded lines and write the
     // column operands; the column launches (fuse set, cop null) read their tiles in the row launches' class-major order
-    const bool fuse_rows = fuse && fuse->cop, fuse_cols = fuse && !fuse->cop;
-    if (fuse && (inverse || n_classes != 1 || sink || !dct_pair_can_fuse_cols(n_frames, w, h) || fuse_rows != is_row)) return SSW_ERR_BAD_ARG;
-    if (fuse_rows && (!class_major || !fuse->rot1 || !fuse->rot2 || !fuse->rot3)) return SSW_ERR_BAD_ARG;
+    const bool fuse_cop = fuse && fuse->mode == FUSE_ROWS_COP, fuse_rows = fuse_cop || (fuse && fuse->mode == FUSE_ROWS_LINES);
+    const bool fuse_cols = fuse && fuse->mode == FUSE_COLS;
+    if (fuse && (!(fuse_rows || fuse_cols) || n_classes != 1 || fuse_rows != is_row ||
+                 !(inverse ? dct_pair_can_fuse_inv_cols(n_frames, w, h) : dct_pair_can_fuse_cols(n_frames, w, h)))) return SSW_ERR_BAD_ARG;
+    if (fuse_cop && (!class_major || sink || !fuse->cop || !fuse->rot1 || !fuse->rot2 || !fuse->rot3)) return SSW_ERR_BAD_ARG;
     const size_t lines = fuse_rows ? n_frames * 16 * dct_pair_fused_units(h) : is_row ? n_frames * h : n_frames * w;
     const size_t len = is_row ? w : h;
     if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
@@ -252,14 +266,14 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     if (class_major && inverse && desc[0].kind == 9) po.cm = 1;
     if (class_major && inverse && is_row && dct_pair_efold_inv(len) && (desc[0].kind == 3 || desc[0].kind == 4) && desc[0].sub == 1) po.tcm = 1;
     if (class_major && !inverse) po.ft = dct_pair_class_tile(len);
-    if (fuse_rows) {
-        if (po.ft != 128 || inst.epi != EPI_FWD || inst.samex) return SSW_ERR_BAD_ARG;
+    if (fuse_cop) {
+        if (inst.samex || (inverse ? (inst.epi != EPI_INV_O || po.cm != 2 || po.cmt != 128) : (inst.epi != EPI_FWD || po.ft != 128))) return SSW_ERR_BAD_ARG;
         po.cop = fuse->cop; po.cop_k16 = (unsigned)pair_kpad<double>(h / 8); po.cop_lines = (unsigned)(n_frames * w);
         po.cop_hup = (unsigned)dct_pair_fused_units(h);
         po.crot1 = fuse->rot1; po.crot2 = fuse->rot2; po.crot3 = fuse->rot3;
-        inst.epi = EPI_FWD_COLOP;
+        inst.epi = inverse ? EPI_INV_O_COLOP : EPI_FWD_COLOP;
     }
-    if (fuse_cols) po.xperm = 1;
+    if (fuse_cols) po.xperm = inverse ? 2u : 1u;
     auto al = [](const void* p, unsigned a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; };
     po.wide = (!is_row && w % 4 == 0 && al(out, 16) && (n_frames * w) % 4 == 0 && (!tmp || al(tmp, 16)) && (!tmp_out || al(tmp_out, 16))) ? 1u : 0u;
     if (with_sink && !(al(sink->iq_i, 16) && al(sink->iq_q, 16) && al(sink->rgb, sink->u8 ? 4 : 16))) po.wide = 0;
@@ -274,6 +288,7 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
 #define SSW_LAUNCH_PAIR(COLS, EPI, SAMEX) do { if (inst.subname == 0) SSW_LAUNCH_PAIR_SUB(COLS, EPI, SAMEX, 0); else SSW_LAUNCH_PAIR_SUB(COLS, EPI, SAMEX, 1); } while (0)
 #define SSW_LAUNCH_ROWCOL(EPI, SAMEX) do { if (is_row) SSW_LAUNCH_PAIR(false, EPI, SAMEX); else SSW_LAUNCH_PAIR(true, EPI, SAMEX); } while (0)
     switch (inst.epi) {
+    case EPI_INV_O_COLOP: SSW_LAUNCH_PAIR_BM(false, EPI_INV_O_COLOP, false, 0, 128); break;
     case EPI_FWD_COLOP:
         if (inst.subname == 4) SSW_LAUNCH_PAIR_BM(false, EPI_FWD_COLOP, false, 4, 128);
         else SSW_LAUNCH_PAIR_BM(false, EPI_FWD_COLOP, false, 3, 128);

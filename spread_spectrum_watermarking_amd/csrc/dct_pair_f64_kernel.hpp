@@ -124,7 +124,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     for (int q = 0; q < XQ; ++q) {
         // (column pass behind a fused row pass: the tile's lines are in class-major order, row j of the tile is line
         // fwd_cm128_pos(j) -- a permutation inside the same contiguous 8 KB of a k-step, whole 128-line tiles only)
-        unsigned r = m0 + ((COLS && BM == 128 && po.xperm) ? fwd_cm128_pos(srow + 64 * q) : srow + 64 * q);
+        const unsigned j = srow + 64 * q;
+        unsigned r = m0 + ((COLS && BM == 128 && po.xperm) ? (po.xperm == 2 ? inverse_class_pos(j, 128, 128, true) : fwd_cm128_pos(j)) : j);
         r = r < L ? r : L - 1;
         xoff[q] = ((r - m0) * 8 + 2 * sc) * 8u;
     }
@@ -515,6 +516,141 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                 double* d = dst0 + (size_t)a * pstride;
 #pragma unroll
                 for (int i = 0; i < NI; i += 2) *reinterpret_cast<f64x2*>(d + i) = (f64x2){o[c][i][a], o[c][i + 1][a]};
+            }
+        }
+        trace_end();
+        return;
+    }
+    // r5: the last launches of an inverse row pass, fused with the inverse column pre-pass (EPI_INV_O_COLOP).  As above with
+    // four output positions per pair: sweep 0 takes the positions n1 / n2 ("+": E + a), sweep 1 their mirrors ("-": E - a);
+    // per sweep a wave has 32 NJ items.  The inverse column fold is block diagonal (planes 0 .. 7 from lines 0 .. 7 of a unit,
+    // planes 8 .. 15 from lines 8 .. 15): a lane holds eight planes of two units at a time and stores 16 bytes per plane.
+    // LDS: [unit of the pair][item][16 lines] floats, the four quads of an item XOR-swizzled by (item / 4) & 3 -- conflict-
+    // free for the ds_write_b32 of a lane group (16 items x one line) and the ds_read_b128 of 16 items alike.
+    if constexpr (!COLS && EPI == EPI_INV_O_COLOP) {
+        constexpr int NIT = 32 * NJ, NC = (NIT + 63) / 64;
+        static_assert(4 * 2 * NIT * 16 * 4 <= (int)sizeof(lds), "transpose area");
+        static_assert(BM == 128 && NI % 2 == 0, "a tile is one k-block of eight units");
+        __syncthreads();
+        float* tw = reinterpret_cast<float*>(lds) + wave * (2 * NIT * 16);
+        auto lds_order = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        const unsigned Hc = po.H, HU = Hc / 16;
+        const unsigned tpf = po.cop_hup / 8;
+        const unsigned z = tm / tpf, g = tm - z * tpf;
+        const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wm / 16));
+        const unsigned swm = __builtin_amdgcn_readfirstlane(wm);
+        const bool plain = ep.first == 1.0f && ep.base == 1.0f;
+        constexpr unsigned OOB = 0x80000000u;
+        const unsigned rows_valid = L - m0 < (unsigned)BM ? L - m0 : (unsigned)BM;
+        const unsigned eregion = rows_valid * (n / 2) * 8u;                  // this tile's lines of the E plane (n/2 doubles each)
+        const __amdgpu_buffer_rsrc_t trr = __builtin_amdgcn_make_buffer_rsrc((void*)(po.tmp + (size_t)m0 * (n / 2)), 0, eregion, 0x00020000);
+        // E of this lane's positions (read as doubles, like EPI_INV_O): lane offsets once per tile, rows through the scalar offset.
+        // Each sweep reads its units' E values again (the second time from L2) rather than keeping 128 more results in registers.
+        unsigned vt[NJ][2];
+        float fp[NJ][2];
+#pragma unroll
+        for (int jn = 0; jn < NJ; ++jn) {
+            const unsigned pair = p0 + wn + 16 * jn + li;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const unsigned nn = h2 ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
+                const bool ok = pair < NP && nn < n / 2;
+                vt[jn][h2] = ok ? (lq * (n / 2) + opos(nn, n / 2)) * 8u : OOB;
+                fp[jn][h2] = nn == 0 ? ep.first : ep.base;
+            }
+        }
+        const size_t pstride = (size_t)po.cop_lines * po.cop_k16;
+        // LDS position of line v of item f: quad (v / 4) ^ ((f / 4) & 3)
+        auto lpos = [&](unsigned f, unsigned v) { return f * 16u + 4u * ((v >> 2) ^ ((f >> 2) & 3u)) + (v & 3u); };
+#pragma unroll
+        for (int sweep = 0; sweep < 2; ++sweep) {
+            bool it_ok[NC];
+            size_t it_line[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const unsigned f = lane + 64 * c;
+                const unsigned pair = p0 + wn + 16 * (f >> 5) + (f & 15u);
+                const unsigned nn = ((f >> 4) & 1u) ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair;
+                it_ok[c] = f < (unsigned)NIT && pair < NP && nn < n / 2;
+                const unsigned pos = it_ok[c] ? (sweep ? n - 1 - nn : nn) : 0u;
+                it_line[c] = ((size_t)g * po.cop_lines + (size_t)z * po.W + oposf(pos, n)) * 8u + u0;
+            }
+#pragma unroll
+            for (int ip = 0; ip < NI; ip += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+                lds_order();
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = ip + u;
+                    double e[4][NJ][2];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned soff = (swm + 16 * i + 4 * r) * (n / 2) * 8u;
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                const u32x2 raw = __builtin_amdgcn_raw_buffer_load_b64(trr, vt[jn][h2], soff, 0);
+                                e[r][jn][h2] = __hiloint2double((int)raw[1], (int)raw[0]);
+                            }
+                    }
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double a = h2 ? acc2[i][jn][r] : acc1[i][jn][r];
+                                float v = sweep ? (float)(e[r][jn][h2] - a) : (float)(e[r][jn][h2] + a);
+                                if (!plain) v *= sweep ? ep.base : fp[jn][h2];
+                                tw[u * (NIT * 16) + lpos(32 * jn + 16 * h2 + li, lq + 4 * r)] = v;
+                            }
+                }
+                lds_order();
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned Hq = Hc / 4, H8 = Hc / 8;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    double o[NC][2][8];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        // the tables of one unit, only what this half needs, live for this unit only (two units' full sets as
+                        // vector registers next to the tile's 128 results spill)
+                        const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)(8 * g + u0 + ip + u));
+                        const bool unit_ok = e < HU;
+                        const unsigned ec = unit_ok ? e : 0u;
+                        ColL2Tab tab;
+                        tab.c3 = po.crot3[ec]; tab.s3 = po.crot3[HU + ec];
+                        if (half == 0) { tab.ra = rot_load(po.crot1, ec, Hq); tab.rb = rot_load(po.crot1, H8 - 1 - ec, Hq); tab.rc = Rot4{0, 0, 0, 0}; }
+                        else { tab.rc = rot_load(po.crot2, ec, H8); tab.ra = tab.rb = Rot4{0, 0, 0, 0}; }
+#pragma unroll
+                        for (int c = 0; c < NC; ++c) {
+                            const unsigned f = (lane + 64 * c) < (unsigned)NIT ? lane + 64 * c : 0u;
+                            float x[8];
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) {
+                                const f32x4 t4 = *reinterpret_cast<const f32x4*>(tw + u * (NIT * 16) + lpos(f, 8 * half + 4 * q));
+                                x[4 * q] = t4[0]; x[4 * q + 1] = t4[1]; x[4 * q + 2] = t4[2]; x[4 * q + 3] = t4[3];
+                            }
+                            if (half == 0) inv_col_l2_unit_lo(x, tab, o[c][u]); else inv_col_l2_unit_hi(x, tab, o[c][u]);
+                            if (!unit_ok) {
+#pragma unroll
+                                for (int a = 0; a < 8; ++a) o[c][u][a] = 0.0;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) {
+                        if (!it_ok[c]) continue;
+                        double* dst0 = po.cop + it_line[c] + ip + (size_t)(8 * half) * pstride;
+#pragma unroll
+                        for (int a = 0; a < 8; ++a) *reinterpret_cast<f64x2*>(dst0 + (size_t)a * pstride) = (f64x2){o[c][0][a], o[c][1][a]};
+                    }
+                }
             }
         }
         trace_end();

@@ -1436,13 +1436,15 @@ static DeepPlanes deep_planes(double* base, size_t lines, size_t len) {
     return dp;
 }
 int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                    const double* rot1, const double* rot2, const double* rot3) {
+                                    const double* rot1, const double* rot2, const double* rot3, bool unit_order) {
     if (n_frames == 0) return SSW_OK;
     if (!dct_pair_can_deep_inv_rows(w) || h > 0xFFFFFFull) return SSW_ERR_BAD_DIMS;
-    const size_t rows = n_frames * h;
+    if (unit_order && (h % 16 != 0 || !dct_pair_efold_inv(w))) return SSW_ERR_BAD_ARG;
+    const unsigned unit_hup = unit_order ? (unsigned)dct_pair_fused_units(h) : 0u;
+    const size_t rows = unit_order ? n_frames * 16 * unit_hup : n_frames * h;       // operand lines
     if (rows > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
     if (dct_pair_efold_inv(w))
-        return launch_prep16_inv_rows_l2(st, in, rows, w, base, rot1, rot2, rot3, (unsigned)dct_pair_split_kpad(w / 2));
+        return launch_prep16_inv_rows_l2(st, in, rows, w, base, rot1, rot2, rot3, (unsigned)dct_pair_split_kpad(w / 2), unit_order ? (unsigned)h : 0u, unit_hup);
     if (dct_pair_prep_staged_rows_ok())
         return launch_prep16_inv_rows_staged(st, in, rows, w, base, rot1, rot2, (unsigned)dct_pair_split_kpad(w), (unsigned)dct_pair_split_kpad(w / 2));
     unsigned tp = 1;

@@ -12,6 +12,7 @@
 // Reference: src/dct2d.rs:172-206 is the column pass whose strided gather / scatter these kernels replace; the f32
 // store between the two passes (:152-168) stays where it was (the input of the column kernels IS that f32 plane).
 #include "dct_pair_split.hpp"
+#include "dct_pair_colops.hpp"
 
 #include <cstdlib>
 
@@ -87,20 +88,7 @@ __device__ inline void zero_range(double* __restrict__ plane, size_t lines_total
     }
 }
 
-// split_one (dct_pair_split.hpp) with the four table values already in registers: {cos e, sin e, cos m, sin m} of the unit
-// and its rotation partner -- the table reads are issued with the data loads instead of after them
-struct Rot4 { double cc, ss, ccm, ssm; };
-__device__ inline Rot4 rot_load(const double* __restrict__ rot, unsigned e, unsigned Mh) {
-    return Rot4{rot[e], rot[Mh + e], rot[Mh - 1 - e], rot[2 * Mh - 1 - e]};
-}
-__device__ inline void split_one_r(double d0, double d1, double d2, double d3, const Rot4& r, double& as, double& bd, double& ad, double& bs) {
-    const double a = d0 * r.cc + d3 * r.ss, b = d3 * r.cc - d0 * r.ss;
-    const double am = d1 * r.ccm + d2 * r.ssm, bm = d2 * r.ccm - d1 * r.ssm;
-    as = a + am;
-    ad = a - am;
-    bs = b + bm;
-    bd = b - bm;
-}
+// (Rot4, rot_load, split_one_r: dct_pair_colops.hpp -- shared with the GEMMs' fused epilogues)
 
 // XCD-aware block order: blocks b, b + 8, ... run on one XCD; give each XCD a contiguous run of work ids, so that the
 // blocks that complete each other's partly written 128-byte lines (neighbouring unit groups) share an L2
@@ -750,7 +738,8 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_staged_kernel(const float
 __global__ __launch_bounds__(256) void prep16_inv_rows_l2_kernel(const float* __restrict__ X, double* __restrict__ base,
                                                                  const double* __restrict__ rot1, const double* __restrict__ rot2,
                                                                  const double* __restrict__ rot3,
-                                                                 unsigned rows, unsigned W, unsigned K16, unsigned tblocks) {
+                                                                 unsigned rows, unsigned W, unsigned K16, unsigned tblocks,
+                                                                 unsigned unit_h, unsigned unit_hup) {
     __shared__ __attribute__((aligned(16))) double lds[RNS * RSL];
     __shared__ double* s_plane[RNS];
     __shared__ unsigned s_piece[RNS], s_mask[RNS];
@@ -772,8 +761,18 @@ __global__ __launch_bounds__(256) void prep16_inv_rows_l2_kernel(const float* __
     auto plane = [&](unsigned a) { return base + (size_t)a * rows * K16; };
     const unsigned g[4] = {R, Nh - 16 - R, Nh + R, W - 16 - R};
     f32x4 c[4][4];
-    if (ok) {
-        const float* xr = X + (row_base + lr) * W;
+    // r5, fused inverse transform (unit_h = H != 0): the operand lines of a frame are ordered (unit of the column fold, line
+    // of the unit; 16 * unit_hup lines per frame, dct_pair_colops.hpp inv_col_unit_row) -- a line reads the coefficient row it
+    // holds (512-byte runs per region either way); the lines of the padding units hold zeros.  `rows` counts operand lines.
+    size_t src_row = row_base + lr;
+    bool src_ok = ok;
+    if (unit_h) {
+        const unsigned line = (unsigned)(row_base + lr), lpf = 16 * unit_hup, z = line / lpf, rem = line - z * lpf;
+        src_ok = ok && (rem >> 4) < unit_h / 16;
+        src_row = (size_t)z * unit_h + (src_ok ? inv_col_unit_row(rem >> 4, rem & 15u, unit_h) : 0u);
+    }
+    if (src_ok) {
+        const float* xr = X + src_row * W;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1013,12 +1012,12 @@ int launch_prep16_inv_cols_l2(hipStream_t st, const float* in, size_t n_frames, 
 }
 
 int launch_prep16_inv_rows_l2(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
-                               const double* rot1, const double* rot2, const double* rot3, unsigned K16) {
+                               const double* rot1, const double* rot2, const double* rot3, unsigned K16, unsigned unit_h, unsigned unit_hup) {
     if (w % 128 != 0 || !rot3) return SSW_ERR_BAD_ARG;
     const unsigned NT = (unsigned)(w / 64), tblocks = (NT / 2 + 3) / 4;
     const unsigned long long nblk = (unsigned long long)((rows + RL - 1) / RL) * tblocks;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
-    prep16_inv_rows_l2_kernel<<<(unsigned)nblk, 256, 0, st>>>(in, base, rot1, rot2, rot3, (unsigned)rows, (unsigned)w, K16, tblocks);
+    prep16_inv_rows_l2_kernel<<<(unsigned)nblk, 256, 0, st>>>(in, base, rot1, rot2, rot3, (unsigned)rows, (unsigned)w, K16, tblocks, unit_h, unit_hup);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

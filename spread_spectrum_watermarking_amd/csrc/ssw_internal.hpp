@@ -127,9 +127,14 @@ int launch_dct_pair_prep8_cols(hipStream_t st, bool f64, const float* in, size_t
 int launch_dct_pair_gemm_f64(hipStream_t st, bool is_row, bool inverse, int kind, int sub, const double* x1, const double* x2,
                              const double* y1, const double* y2, float* out, double* tmp, size_t n_frames, size_t w,
                              size_t h, Epilogue ep, const RgbSink* sink = nullptr, double* tmp_out = nullptr, bool class_major = false);
-// r5, fused forward transform: the column operands a fused row launch writes (the sixteen planes) and the rotation tables
-// of H, H/2, H/4 its epilogue needs; a column launch behind it passes an empty FuseCols (its tiles are class-major)
-struct FuseCols { double* cop = nullptr; const double *rot1 = nullptr, *rot2 = nullptr, *rot3 = nullptr; };
+// r5, fused transforms (both directions): how a launch takes part.
+//   FUSE_ROWS_COP    row launch over the unit-ordered, padded lines whose epilogue writes the sixteen column-operand planes
+//                    `cop` (forward: every launch; inverse: the four launches of the odd part); needs the rotation tables of
+//                    H, H/2, H/4
+//   FUSE_ROWS_LINES  row launch over the same lines with its usual epilogue (inverse: the launches that exchange A1 / T2 / E)
+//   FUSE_COLS        column launch behind such a row pass: its 128-line tiles are in the row launches' class-major order
+enum { FUSE_ROWS_COP = 1, FUSE_ROWS_LINES = 2, FUSE_COLS = 3 };
+struct FuseCols { int mode = 0; double* cop = nullptr; const double *rot1 = nullptr, *rot2 = nullptr, *rot3 = nullptr; };
 // several classes (same lines, same template instance) in one launch: single frames, whose launches are too small alone
 struct PairClassDesc { int kind, sub; const double *x1, *x2, *y1, *y2; };
 int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, int n_classes, const PairClassDesc* desc, float* out,
@@ -149,7 +154,7 @@ bool dct_pair_can_split(size_t len, bool is_row);
 size_t dct_pair_split_kpad(size_t len);
 // tuning.hip: the process-wide table of strategy thresholds / A-B switches (ssw_tuning_set, include/ssw.h)
 enum { TUNE_EFOLD_MIN, TUNE_EFOLD_INV_MIN, TUNE_EFOLD_COLS_MIN, TUNE_CLASS_TILE, TUNE_DEEP_MIN_ROWS, TUNE_DEEP_MIN_COLS, TUNE_PREP_STAGED,
-       TUNE_MERGE_MAX_LINES, TUNE_BN32, TUNE_BAND_SPLIT, TUNE_FUSE_COLS, TUNE_COUNT };
+       TUNE_MERGE_MAX_LINES, TUNE_BN32, TUNE_BAND_SPLIT, TUNE_FUSE_COLS, TUNE_FUSE_INV_COLS, TUNE_COUNT };
 long long tuning(int which);
 unsigned dct_pair_class_tile(size_t len);               // tile width of the class-major plane orders (dct_pair_common.hpp)
 bool dct_pair_efold(size_t len);                        // forward row passes of this length run at level 2 (r4b)
@@ -167,7 +172,7 @@ int launch_prep16_cols_staged(hipStream_t st, const float* in, size_t n_frames, 
 int launch_prep16_inv_cols_staged(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                   const double* rot1, const double* rot2, bool class_major, bool semi, unsigned K8, unsigned K16, bool l2);
 int launch_prep16_inv_rows_l2(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
-                              const double* rot1, const double* rot2, const double* rot3, unsigned K16);
+                              const double* rot1, const double* rot2, const double* rot3, unsigned K16, unsigned unit_h = 0, unsigned unit_hup = 0);
 int launch_prep16_inv_rows_staged(hipStream_t st, const float* in, size_t rows, size_t w, double* base,
                                   const double* rot1, const double* rot2, unsigned K8, unsigned K16);
 size_t dct_pair_split_elems(size_t n_frames, size_t w, size_t h);
@@ -184,7 +189,7 @@ bool dct_pair_can_semi_deep_cols(size_t len);            // H % 8 == 0, not % 16
 size_t dct_pair_semi_deep_elems(size_t lines, size_t len);
 // deep inverse pre-passes (coefficient plane -> the same ten planes; R1 = c[8q], R2 = c[8q+4])
 int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
-                                    const double* rot1, const double* rot2, const double* rot3 = nullptr);
+                                    const double* rot1, const double* rot2, const double* rot3 = nullptr, bool unit_order = false);
 int launch_dct_pair_prep16_inv_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
                                     const double* rot1, const double* rot2, bool class_major = false, const double* rot3 = nullptr);
 int launch_dct_pair_prep16_cols(hipStream_t st, const float* in, size_t n_frames, size_t w, size_t h, double* base,
@@ -196,6 +201,7 @@ int launch_dct_pair_prep16_rows(hipStream_t st, int src_kind, const void* src, s
 // whether a transform of n frames takes it (dct_pair_f64.hip)
 inline size_t dct_pair_fused_units(size_t h) { return ((h / 16 + 7) / 8) * 8; }
 bool dct_pair_can_fuse_cols(size_t n_frames, size_t w, size_t h);
+bool dct_pair_can_fuse_inv_cols(size_t n_frames, size_t w, size_t h);
 
 int launch_dct_pair_gemm_rows_subset_f32(hipStream_t st, const float* x, const float* y, unsigned cap, unsigned Kp, float* out,
                                          unsigned out_stride, unsigned off, size_t lines);
@@ -343,6 +349,9 @@ struct ssw_ctx {
     // three 4K planes cost more than the transform); all reuse is ordered on the context's stream
     std::multimap<size_t, void*> plane_pool;
     size_t plane_pool_bytes = 0;
+    // workspace buffers that grew while a chain of stages was being built: stages built earlier captured the old pointer, so
+    // the old allocation stays valid until the next entry into the library frees it (grow(), CtxGuard; r5)
+    std::vector<void*> retired;
     uint32_t* select_fallbacks = nullptr; // device counter: frames whose candidate count fell outside [k, capacity]
     uint64_t select_frames = 0;           // frames selected since the last ssw_ctx_reset_timing
     ssw::host::Transfer* xfer = nullptr;  // pinned staging ring + copy threads (transfer.hip)

@@ -254,6 +254,8 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
         for (hipEvent_t e : {ctx->hs.up_done[s], ctx->hs.k_done[s], ctx->hs.down_done[s]}) if (e) (void)hipEventDestroy(e);
     }
     release(ctx->hs.marks); release(ctx->hs.ext); release(ctx->hs.sims);
+    for (void* p : ctx->retired) (void)hipFree(p);
+    ctx->retired.clear();
     for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);
     for (auto& fs : ctx->frame_stage) {
         release(fs.buf);

@@ -22,7 +22,15 @@ namespace host {
 
 // ---- small helpers ------------------------------------------------------------------------------------
 namespace { thread_local ssw_ctx* tl_ctx = nullptr; }
-CtxGuard::CtxGuard(ssw_ctx* ctx) : dg(ctx->device), prev(tl_ctx) { tl_ctx = ctx; }
+CtxGuard::CtxGuard(ssw_ctx* ctx) : dg(ctx->device), prev(tl_ctx) {
+    tl_ctx = ctx;
+    // buffers retired by grow() during the previous call: nothing built then is still to be enqueued (hipFree waits for
+    // work in flight); nested guards (prev == ctx) leave them to the outermost one
+    if (prev != ctx && !ctx->retired.empty()) {
+        for (void* p : ctx->retired) (void)hipFree(p);
+        ctx->retired.clear();
+    }
+}
 CtxGuard::~CtxGuard() { tl_ctx = prev; }
 
 size_t plane_pool_flush(ssw_ctx* ctx) {
@@ -68,7 +76,15 @@ int dev_malloc(void** p, size_t bytes) {
 
 int grow(ssw_ctx::Buf& b, size_t bytes) {
     if (b.bytes >= bytes && b.p) return SSW_OK;
-    if (b.p) { SSW_HIP_CHECK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }   // hipFree waits for work in flight
+    // A buffer that grows in the middle of a call may already be captured by stages built earlier in the same chain (a
+    // row pass that exchanges A1 through operand[2], then a column pass that asks for a larger operand[2]): the old
+    // allocation is retired, not freed -- those stages keep working on it, the later ones use the new one -- and the next
+    // entry into the library frees it (CtxGuard).  Without a context in scope: free now (hipFree waits for work in flight).
+    if (b.p) {
+        if (tl_ctx) tl_ctx->retired.push_back(b.p);
+        else SSW_HIP_CHECK(hipFree(b.p));
+        b.p = nullptr; b.bytes = 0;
+    }
     SSW_ALLOC(&b.p, bytes);
     b.bytes = bytes ? bytes : 16;
     return SSW_OK;
@@ -253,7 +269,8 @@ size_t split_scratch_elems(size_t n, size_t w, size_t h) {
     size_t e = dct_pair_split_elems(n, w, h);
     if (dct_pair_can_deep_rows(w) || dct_pair_can_deep_inv_rows(w)) e = std::max(e, dct_pair_deep_elems(n * h, w));
     if (dct_pair_can_deep_cols(h)) e = std::max(e, dct_pair_deep_elems(n * w, h));
-    if (dct_pair_can_fuse_cols(n, w, h)) e = std::max(e, dct_pair_deep_elems(n * 16 * dct_pair_fused_units(h), w));      // unit-ordered, padded lines
+    if (dct_pair_can_fuse_cols(n, w, h) || dct_pair_can_fuse_inv_cols(n, w, h))
+        e = std::max(e, dct_pair_deep_elems(n * 16 * dct_pair_fused_units(h), w));                                      // unit-ordered, padded lines
     if (dct_pair_can_semi_deep_cols(h)) e = std::max(e, dct_pair_semi_deep_elems(n * w, h));
     return e;
 }
@@ -391,7 +408,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                                 {6, 0, P(1), P(2), (const double*)t2, (const double*)t3},
                                                 {8, 0, P(6), P(7), (const double*)t0, (const double*)t1},
                                                 {7, 0, P(4), P(5), (const double*)t0, (const double*)t1}};
-                    const FuseCols fc{cop, (const double*)crot1, (const double*)crot2, (const double*)crot3};
+                    const FuseCols fc{FUSE_ROWS_COP, cop, (const double*)crot1, (const double*)crot2, (const double*)crot3};
                     ch.push_back({false, [=](hipStream_t st) -> int {
                         StageTimer t(ctx, st_pass, st, f_all * pad);
                         t.traffic(px * (esz + 8.0));                     // row operands in, column operands out
@@ -410,7 +427,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                             {6, 0, CP(1), CP(2), (const double*)t2, (const double*)t3},
                                             {8, 0, CP(6), CP(7), (const double*)t0, (const double*)t1},
                                             {7, 0, CP(4), CP(5), (const double*)t0, (const double*)t1}};
-                const FuseCols fc{};
+                const FuseCols fc{FUSE_COLS};
                 ch.push_back({false, [=](hipStream_t st) -> int {
                     StageTimer t(ctx, st_pass, st, f_all);
                     t.traffic(gemm_bytes(0.0));
@@ -589,8 +606,10 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             SSW_TRY(get_basis(ctx, len / 4, true, true, 4, &e1));
             for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, len / 2, true, true, b == 1 ? 10 : 5 + b, &sb2[b]));
             SSW_TRY(get_basis(ctx, len / 2, false, true, 9, &rot2));
-            SSW_TRY(grow(ws.operand[1], bytes));
-            SSW_TRY(grow(ws.operand[4], bytes));
+            // (fused inverse transform, r5: the row pass runs over unit-ordered lines padded to whole k-blocks of units)
+            const size_t xlines = (is_row && dct_pair_can_fuse_inv_cols(n, w, h)) ? n * 16 * dct_pair_fused_units(h) : lines;
+            SSW_TRY(grow(ws.operand[1], std::max<size_t>(bytes, xlines * (len / 4) * sizeof(double))));
+            SSW_TRY(grow(ws.operand[4], std::max<size_t>(bytes, xlines * (len / 2) * sizeof(double))));
             // Row passes of 1280 columns or more (a multiple of 256) run at LEVEL 2 (r4c, dct_pair_efold_inv), the transpose of
             // the forward pass's: every launch sums len/16 coefficients --
             //   the quarter-length even part T2 = (its even half A1: kind 1 sub 2, folded) +/- (its odd half: R2 rotated, kind 9)
@@ -606,7 +625,7 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 SSW_TRY(get_basis(ctx, len / 4, false, true, 9, &rot3));
                 SSW_TRY(get_basis(ctx, len / 8, true, true, 3, &h0));
                 SSW_TRY(get_basis(ctx, len / 8, true, true, 4, &h1));
-                SSW_TRY(grow(ws.operand[2], lines * (len / 8) * sizeof(double)));
+                SSW_TRY(grow(ws.operand[2], std::max<size_t>(bytes, xlines * (len / 8) * sizeof(double))));      // (>= what any other pass asks of it)
                 A1 = ws.operand[2].p;             // the eighth-length even part, unrounded: len/8 doubles per line
             }
             void* T2 = ws.operand[1].p;       // quarter-length even half, unrounded
@@ -618,17 +637,86 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
             // rows first and both passes deep: the row pass's split launches write (and exchange E) class-major
             const bool cm = cm0;
             const bool rcm = cm && is_row;
-            ch.push_back({true, [=](hipStream_t st) -> int {
-                StageTimer t(ctx, st_prep, st, prep_bytes);
-                if (!is_row) return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm, (const double*)rot3);
-                return launch_dct_pair_prep16_inv_rows(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, (const double*)rot3);
-            }});
             RgbSink sink;
             if (!first_pass && !is_row && x.rgb_out && x.iq_i && x.iq_q) {
                 sink.iq_i = x.iq_i; sink.iq_q = x.iq_q; sink.rgb = x.rgb_out; sink.u8 = x.rgb_out_u8;
                 if (fused_rgb) *fused_rgb = true;
             }
             const bool with_sink = sink.rgb != nullptr;
+            // r5: FUSED inverse transform (dct_pair_can_fuse_inv_cols), the mirror image of the forward one: the row pre-pass
+            // orders its lines by unit of the inverse column fold, the four launches of the odd part (EPI_INV_O_COLOP) round
+            // their results to f32 -- the store between the passes -- and write the column operands; the column pass is its
+            // eight launches.  A1 / T2 / E are exchanged per line as before (their planes are indexed by operand line).
+            const bool fuse_inv = il2 && cm && !x.full_h && dct_pair_can_fuse_inv_cols(n, w, h);
+            if (fuse_inv) {
+                const size_t k16h = dct_pair_split_kpad(h / 2), cplane = n * w * k16h;
+                SSW_TRY(grow(ws.operand[0], 16 * cplane * sizeof(double)));
+                double* cop = (double*)ws.operand[0].p;
+                const double f_all = 8.0 * pair_gemm_flop(is_row, 7, 0, n, w, h);
+                if (is_row) {
+                    const void *crot1 = nullptr, *crot2 = nullptr, *crot3 = nullptr;
+                    SSW_TRY(get_basis(ctx, h, false, true, 9, &crot1));
+                    SSW_TRY(get_basis(ctx, h / 2, false, true, 9, &crot2));
+                    SSW_TRY(get_basis(ctx, h / 4, false, true, 9, &crot3));
+                    const size_t lpad = n * 16 * dct_pair_fused_units(h), p16r = lpad * dct_pair_split_kpad(len / 2);
+                    double *A1p = (double*)A1, *T2p = (double*)T2, *TEp = (double*)TE;      // sized for the padded lines above
+                    auto P = [=](int j) { return (const double*)(sp + (size_t)j * p16r); };
+                    const double pad = (double)lpad / (double)(n * h);
+                    ch.push_back({true, [=](hipStream_t st) -> int {
+                        StageTimer t(ctx, st_prep, st, prep_bytes);
+                        return launch_dct_pair_prep16_inv_rows(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, (const double*)rot3, true);
+                    }});
+                    const PairClassDesc da = {1, 2, P(8), P(9), (const double*)h0, (const double*)h1};
+                    const PairClassDesc db = {9, 2, P(10), P(11), (const double*)t0, (const double*)t1};
+                    const PairClassDesc d1[2] = {{3, 1, P(12), P(13), (const double*)t0, (const double*)t1},
+                                                 {4, 1, P(14), P(15), (const double*)t2, (const double*)t3}};
+                    const PairClassDesc d0[4] = {{5, 0, P(0), P(3), (const double*)t0, (const double*)t1},
+                                                 {6, 0, P(1), P(2), (const double*)t2, (const double*)t3},
+                                                 {7, 0, P(4), P(5), (const double*)t0, (const double*)t1},
+                                                 {8, 0, P(6), P(7), (const double*)t0, (const double*)t1}};
+                    const FuseCols fl{FUSE_ROWS_LINES};
+                    const FuseCols fc{FUSE_ROWS_COP, cop, (const double*)crot1, (const double*)crot2, (const double*)crot3};
+                    ch.push_back({false, [=](hipStream_t st) -> int {
+                        StageTimer t(ctx, st_pass, st, f_all * pad);
+                        t.traffic(px * (esz + 14.0 + 8.0));              // operands in, A1 / T2 / E out and in, column operands out
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, true, true, 1, &da, dst, A1p, n, w, h, ep, nullptr, nullptr, false, &fl));
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, true, true, 1, &db, dst, A1p, n, w, h, ep, nullptr, T2p, true, &fl));
+                        for (int c = 0; c < 2; ++c)
+                            SSW_TRY(launch_dct_pair_gemm_multi_f64(st, true, true, 1, &d1[c], dst, T2p, n, w, h, ep, nullptr, TEp, true, &fl));
+                        for (int c = 0; c < 4; ++c)
+                            SSW_TRY(launch_dct_pair_gemm_multi_f64(st, true, true, 1, &d0[c], nullptr, TEp, n, w, h, ep, nullptr, nullptr, true, &fc));
+                        return SSW_OK;
+                    }});
+                    return SSW_OK;
+                }
+                auto CP = [=](int j) { return (const double*)(cop + (size_t)j * cplane); };
+                const PairClassDesc da = {1, 2, CP(8), CP(9), (const double*)h0, (const double*)h1};
+                const PairClassDesc db = {9, 2, CP(10), CP(11), (const double*)t0, (const double*)t1};
+                const PairClassDesc d1[2] = {{3, 1, CP(12), CP(13), (const double*)t0, (const double*)t1},
+                                             {4, 1, CP(14), CP(15), (const double*)t2, (const double*)t3}};
+                const PairClassDesc d0[4] = {{5, 0, CP(0), CP(3), (const double*)t0, (const double*)t1},
+                                             {6, 0, CP(1), CP(2), (const double*)t2, (const double*)t3},
+                                             {7, 0, CP(4), CP(5), (const double*)t0, (const double*)t1},
+                                             {8, 0, CP(6), CP(7), (const double*)t0, (const double*)t1}};
+                const FuseCols fcc{FUSE_COLS};
+                ch.push_back({false, [=](hipStream_t st) -> int {
+                    StageTimer t(ctx, st_pass, st, f_all);
+                    t.traffic(gemm_bytes(14.0));
+                    SSW_TRY(launch_dct_pair_gemm_multi_f64(st, false, true, 1, &da, dst, (double*)A1, n, w, h, ep, nullptr, nullptr, false, &fcc));
+                    SSW_TRY(launch_dct_pair_gemm_multi_f64(st, false, true, 1, &db, dst, (double*)A1, n, w, h, ep, nullptr, (double*)T2, false, &fcc));
+                    for (int c = 0; c < 2; ++c)
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, false, true, 1, &d1[c], dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, false, &fcc));
+                    for (int c = 0; c < 4; ++c)
+                        SSW_TRY(launch_dct_pair_gemm_multi_f64(st, false, true, 1, &d0[c], dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, false, &fcc));
+                    return SSW_OK;
+                }});
+                return SSW_OK;
+            }
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, st_prep, st, prep_bytes);
+                if (!is_row) return launch_dct_pair_prep16_inv_cols(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, cm, (const double*)rot3);
+                return launch_dct_pair_prep16_inv_rows(st, src, n, w, h, sp, (const double*)rot, (const double*)rot2, (const double*)rot3);
+            }});
             if (il2) {
                 auto P = [=](int j) { return (const double*)(sp + (size_t)j * p16); };      // the planes of prep16_inv_rows_l2_kernel
                 const double f_all = 8.0 * pair_gemm_flop(is_row, 7, 0, n, w, h);

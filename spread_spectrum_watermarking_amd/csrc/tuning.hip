@@ -32,6 +32,7 @@ Entry g_tune[TUNE_COUNT] = {
     {"bn32", "SSW_BN32", -1},                          // 32-pair tiles for small single-class launches: -1 automatic, 0 / 1 forced
     {"band_split", "SSW_BAND_SPLIT", 1},               // single-image handles: row pass of the top half beside the upload of the bottom half
     {"fuse_cols", "SSW_FUSE_COLS", 1},                 // forward: column operands straight from the row GEMMs' epilogue (r5)
+    {"fuse_inv_cols", "SSW_FUSE_INV_COLS", 0},         // inverse: the same (r5; bit-identical, measured no faster: off by default)
 };
 
 }  // namespace

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """r5: the FUSED forward transform (csrc/dct_pair_f64_kernel.hpp EPI_FWD_COLOP: the row GEMMs' epilogue applies the column
 pre-pass's arithmetic to its accumulators and writes the column operands; no f32 plane between the passes,
-src/dct2d.rs:152-168 stays the rounding point) against the unfused path (tuning fuse_cols = 0: row launches -> f32 plane ->
-prep16_cols_l2_kernel): coefficient planes of ssw_dct2d bit for bit, forward and orthonormal, on shapes that cover every
+src/dct2d.rs:152-168 stays the rounding point) and its mirror image for the inverse transform (EPI_INV_O_COLOP) against the unfused path (tuning fuse_cols = 0: row
+launches -> f32 plane -> prep16_cols_l2_kernel / prep16_inv_cols_l2_kernel): planes of ssw_dct2d bit for bit, forward,
+orthonormal and inverse, on shapes that cover every
 tail mode of the row launches (16 / 32 / 48 / 64 pairs in the last tile column) and frames whose units do not fill their
 last k-block; the first and the last frame also against the oracle's correctly rounded transform; then whole batch pipelines
 (embed + extract) fused against unfused.  Small shapes take the level-2 kernels through lowered thresholds (ssw_tuning_set).
@@ -19,7 +20,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 # (h, w, frames): frames chosen so that both passes run on 128-line tiles (dct_pair_can_fuse_cols)
-SHAPES = [(144, 256, 224), (272, 512, 150), (720, 1280, 46), (1088, 2048, 25), (2160, 3840, 8), (4320, 7680, 2)]
+SHAPES = [(256, 256, 224), (272, 512, 150), (720, 1280, 46), (1088, 2048, 25), (2160, 3840, 8), (4320, 7680, 2)]
 BATCH = [(720, 1280, 48, 300), (2160, 3840, 8, 1000)]           # (h, w, frames, k)
 LOW = dict(efold_min=256, efold_inv_min=256, efold_cols_min=64)
 
@@ -32,26 +33,35 @@ def run(out=print, shapes=SHAPES, batch=BATCH):
     bad = 0
     for (h, w, n) in shapes:
         x = np.random.default_rng(h * 7 + w).random((n, h, w)).astype(np.float32)
-        for name, kind in (("fwd", L.DCT2), ("ortho", L.DCT2_ORTHOGONAL)):
-            with tuning(fuse_cols=1, **LOW), G.fresh_ctx():
-                a = G.dct2d(x, kind, L.PRECISION_F64)
-            with tuning(fuse_cols=0, **LOW), G.fresh_ctx():
-                b = G.dct2d(x, kind, L.PRECISION_F64)
-            same = bool(np.array_equal(a, b))
+        for name, kind in (("fwd", L.DCT2), ("ortho", L.DCT2_ORTHOGONAL), ("inv", L.DCT3)):
+            preps = []
+            for fuse in (1, 0):
+                with tuning(fuse_cols=fuse, fuse_inv_cols=fuse, **LOW), G.fresh_ctx() as c:
+                    c.enable_timing(True)
+                    c.reset_timing()
+                    r = G.dct2d(x, kind, L.PRECISION_F64)
+                    preps.append(c.timing()["dct_prep"]["launches"])
+                    c.enable_timing(False)
+                if fuse:
+                    a = r
+                else:
+                    b = r
+            # the fused transform has ONE pre-pass stage (rows), the unfused one two (rows, columns): the path under test ran
+            same = bool(np.array_equal(a, b)) and preps == [1, 2]
             worst = 1.0
             for f in (0, n - 1):
                 worst = min(worst, float(np.mean(a[f] == O.dct2d(x[f], kind))))
             ok = same and worst >= fuzz_dct.BAR_IDENTICAL
             bad += not ok
             out(f"{h:5d} x {w:5d} n={n:3d} {name:5s} fused == unfused: {same}  identical to the oracle {worst:.6f}"
-                f"{'' if ok else '   <-- FAIL (' + str(int(np.sum(a != b))) + ' coefficients differ)'}")
+                f"{'' if ok else '   <-- FAIL (' + str(int(np.sum(a != b))) + ' coefficients differ; pre-pass stages ' + str(preps) + ')'}")
         del x
     for (h, w, n, k) in batch:
         rgb = G.synth(5, 0, n, w, h)
         marks = np.random.default_rng(k).standard_normal((n, k)).astype(np.float32)
         res = []
         for fuse in (1, 0):
-            with tuning(fuse_cols=fuse, **LOW), G.fresh_ctx():
+            with tuning(fuse_cols=fuse, fuse_inv_cols=fuse, **LOW), G.fresh_ctx():
                 cfg = G.default_config(L.PRECISION_F64)
                 r = G.batch_embed(rgb, marks, cfg, want_coef=True, want_idx=True)
                 ext, sims = G.batch_extract(rgb, r["rgb"], k, marks, cfg)
