@@ -185,8 +185,11 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
 // r5: a forward transform of n frames whose row launches write the column operands themselves (EPI_FWD_COLOP).  Rows first,
 // both passes at level 2, 128-frequency class tiles, the column planes exactly as wide as the padded units, and both passes
 // on 128-line tiles (a tile of the row pass IS one k-block of the column operands; small batches keep the unfused path).
+// (the launcher's own test, launch_dct_pair_gemm_multi_f64: a pass of at most merge_max_lines lines runs its eight classes as
+// ONE launch, whose tile columns add up)
 static bool launch_is_small(size_t lines, size_t pairs) {
-    return (unsigned long long)((lines + 127) / 128) * ((pairs + 63) / 64) < 448;
+    const unsigned long long classes = lines <= (size_t)tuning(TUNE_MERGE_MAX_LINES) ? 8 : 1;
+    return (unsigned long long)((lines + 127) / 128) * ((pairs + 63) / 64) * classes < 448;
 }
 bool dct_pair_can_fuse_cols(size_t n_frames, size_t w, size_t h) {
     if (tuning(TUNE_FUSE_COLS) == 0 || n_frames == 0 || w < h || w % 128 != 0 || h % 16 != 0) return false;
@@ -206,7 +209,9 @@ bool dct_pair_can_fuse_inv_cols(size_t n_frames, size_t w, size_t h) {
     const size_t hup = dct_pair_fused_units(h);
     if (pair_kpad<double>(h / 8) != hup) return false;
     if (n_frames * 16 * hup > 0xFFFFFFFFull) return false;
-    return !launch_is_small(n_frames * 16 * hup, w / 16) && !launch_is_small(n_frames * w, h / 16);
+    // (the inverse pass's dependent launches run one class each: every one must fill 128-line tiles by itself)
+    auto small1 = [](size_t lines, size_t pairs) { return (unsigned long long)((lines + 127) / 128) * ((pairs + 63) / 64) < 448; };
+    return !small1(n_frames * 16 * hup, w / 16) && !small1(n_frames * w, h / 16);
 }
 
 int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, int n_classes, const PairClassDesc* desc, float* out,
@@ -219,7 +224,7 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     // column operands; the column launches (fuse set, cop null) read their tiles in the row launches' class-major order
     const bool fuse_cop = fuse && fuse->mode == FUSE_ROWS_COP, fuse_rows = fuse_cop || (fuse && fuse->mode == FUSE_ROWS_LINES);
     const bool fuse_cols = fuse && fuse->mode == FUSE_COLS;
-    if (fuse && (!(fuse_rows || fuse_cols) || n_classes != 1 || fuse_rows != is_row ||
+    if (fuse && (!(fuse_rows || fuse_cols) || fuse_rows != is_row ||
                  !(inverse ? dct_pair_can_fuse_inv_cols(n_frames, w, h) : dct_pair_can_fuse_cols(n_frames, w, h)))) return SSW_ERR_BAD_ARG;
     if (fuse_cop && (!class_major || sink || !fuse->cop || !fuse->rot1 || !fuse->rot2 || !fuse->rot3)) return SSW_ERR_BAD_ARG;
     const size_t lines = fuse_rows ? n_frames * 16 * dct_pair_fused_units(h) : is_row ? n_frames * h : n_frames * w;

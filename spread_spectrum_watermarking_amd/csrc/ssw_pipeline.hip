@@ -409,9 +409,14 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                                 {8, 0, P(6), P(7), (const double*)t0, (const double*)t1},
                                                 {7, 0, P(4), P(5), (const double*)t0, (const double*)t1}};
                     const FuseCols fc{FUSE_ROWS_COP, cop, (const double*)crot1, (const double*)crot2, (const double*)crot3};
+                    const bool merge_r = lpad <= merge_max_lines();       // a single frame: the eight classes in one launch
                     ch.push_back({false, [=](hipStream_t st) -> int {
                         StageTimer t(ctx, st_pass, st, f_all * pad);
                         t.traffic(px * (esz + 8.0));                     // row operands in, column operands out
+                        if (merge_r) {
+                            StageTimer tm(ctx, st_main, st, f_all * pad);
+                            return launch_dct_pair_gemm_multi_f64(st, true, false, 8, d, nullptr, nullptr, n, w, h, ep, nullptr, nullptr, true, &fc);
+                        }
                         for (int c = 0; c < 7; ++c)
                             SSW_TRY(launch_dct_pair_gemm_multi_f64(st, true, false, 1, &d[c], nullptr, nullptr, n, w, h, ep, nullptr, nullptr, true, &fc));
                         StageTimer tm(ctx, st_main, st, f_main * pad);
@@ -428,9 +433,14 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                             {8, 0, CP(6), CP(7), (const double*)t0, (const double*)t1},
                                             {7, 0, CP(4), CP(5), (const double*)t0, (const double*)t1}};
                 const FuseCols fc{FUSE_COLS};
+                const bool merge_c = lines <= merge_max_lines();
                 ch.push_back({false, [=](hipStream_t st) -> int {
                     StageTimer t(ctx, st_pass, st, f_all);
                     t.traffic(gemm_bytes(0.0));
+                    if (merge_c) {
+                        StageTimer tm(ctx, st_main, st, f_all);
+                        return launch_dct_pair_gemm_multi_f64(st, false, false, 8, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, false, &fc);
+                    }
                     for (int c = 0; c < 7; ++c)
                         SSW_TRY(launch_dct_pair_gemm_multi_f64(st, false, false, 1, &d[c], dst, nullptr, n, w, h, ep, nullptr, nullptr, false, &fc));
                     StageTimer tm(ctx, st_main, st, f_main);
@@ -966,6 +976,7 @@ int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, cons
 }
 int build_forward_cols_after_rows(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, size_t w, size_t h, float* tmp, float* y, Chain& ch) {
     Xform x{SSW_DCT2, precision, 1, w, h, y, tmp};
+    x.full_h = h;            // the row pass ran band by band through the f32 plane: the column pass reads it back (no fused operands)
     return build_pass(ctx, ws, x, false, false, tmp, y, Epilogue{1.f, 1.f}, ch);
 }
 
