@@ -170,12 +170,21 @@ def step_roofline(prec_name, stage, steps, wall_ms_per_step):
 #       (csrc/dct_pair_prep.hip pair_prep16_rows_kernel); its own template instance (SUB = 4).  Shorter rows (level 1): class O
 #       of the split odd half itself, W/8 pairs x W/8 terms.
 #   f32: the unsplit odd half (the f32 twin keeps exact-operand folding)
+FUSED_FORWARD = False      # set by main() from ssw_ctx_transform_plan: the row launches of this workload write the column operands (r5)
+
+
 def main_kernel_label(prec_name):
-    return "pair_gemm_f64_kernel<rows, split odd half, class O (level 2: rotated, '+' launch)>" if prec_name == "f64" else "pair_gemm_f32_kernel<rows, odd half>"
+    if prec_name != "f64":
+        return "pair_gemm_f32_kernel<rows, odd half>"
+    if FUSED_FORWARD:
+        return "pair_gemm_f64_kernel<rows, fused column operands, class O rotated '+' launch>"
+    return "pair_gemm_f64_kernel<rows, split odd half, class O (level 2: rotated, '+' launch)>"
 
 
 def main_kernel_instance(prec_name):
-    return "ssw::pair_gemm_f64_kernel<false, 0, false, 4>" if prec_name == "f64" else "ssw::pair_gemm_f32_kernel<false, 0, true, 0>"
+    if prec_name != "f64":
+        return "ssw::pair_gemm_f32_kernel<false, 0, true, 0>"
+    return "ssw::pair_gemm_f64_kernel<false, 7, false, 4>" if FUSED_FORWARD else "ssw::pair_gemm_f64_kernel<false, 0, false, 4>"
 
 
 MAIN_KERNEL_NOTE = {
@@ -688,6 +697,9 @@ def main():
         total_frames = B * world
         first_frame = rank * B                   # global frame index of this rank's shard (weak scaling)
     chunk_eff = ctx.pass_frames(B, W, H)          # frames per internal pass (automatic: ~2^30 pixels)
+    global FUSED_FORWARD
+    plan = ctx.transform_plan(min(chunk_eff, B), W, H)
+    FUSED_FORWARD = plan["fused_cols"]
     workload_tag = (f"configs[{args.config or 3}] of BASELINE.json: \"{preset['quote']}\"" if (args.config is not None or
                     (B, W, H, K) == (preset["batch"], preset["width"], preset["height"], preset["k"])) else "custom shape")
 
@@ -889,6 +901,7 @@ def main():
                                    f" {W}x{H} f32 frames, {K}-coeff mark, {flow}; {workload_tag}",
                        "frames_per_gpu": B, "total_frames": total_frames, "width": W, "height": H, "k": K, "alpha": 0.1,
                        "method": "Option2", "ordering": "Energy", "chunk_frames": chunk_eff,
+                       "transform_plan": {k: v for k, v in plan.items()},
                        "dct_folding_level": fold_level, "dct_odd_split": "on (f64: odd halves as rotated quarter-length cosine + sine pairs, deep pre-passes; DESIGN.md 4.1)" if args.precision == "f64" else "off (f32 twin: exact-operand folding)",
                        "overlap": "one chunk at a time on one stream" if args.no_overlap else "two chunks in flight on two streams",
                        "parallelism": f"frame-sharded x{world}, no collectives"},

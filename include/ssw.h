@@ -98,6 +98,17 @@ const char* ssw_version(void);
    and the f32 twin of the operand-ready GEMMs; 0 for the default library, where those requests run the dense kernels
    (same results to their precision's bars, slower). */
 int ssw_build_all_strategies(void);
+/* Which strategy of the 2-D transform (src/dct2d.rs:83-219) a batch of n_frames frames of w x h takes in the canonical (f64)
+   precision under the context's current settings, as flags -- introspection for bench.py, DESIGN.md and the tests; every
+   strategy computes the same values:
+     PAIR_F64     operand-ready f64 GEMMs (otherwise the dense kernels)
+     ROWS_DEEP / COLS_DEEP       one pre-pass per pass writes the operands of all launches (split odd halves)
+     ROWS_LEVEL2 / COLS_LEVEL2   every launch of the pass sums len/16 terms (eight launches per pass)
+     CLASS_MAJOR  the plane (or operand lines) between the passes in class-major order inside tiles of 128 columns
+     FUSED_COLS   r5: no f32 plane between the passes -- the row launches' epilogue writes the column operands */
+enum { SSW_PLAN_PAIR_F64 = 1, SSW_PLAN_ROWS_DEEP = 2, SSW_PLAN_COLS_DEEP = 4, SSW_PLAN_ROWS_LEVEL2 = 8, SSW_PLAN_COLS_LEVEL2 = 16,
+       SSW_PLAN_CLASS_MAJOR = 32, SSW_PLAN_FUSED_COLS = 64 };
+int ssw_ctx_transform_plan(ssw_ctx* ctx, size_t n_frames, size_t w, size_t h, int dct_type, uint32_t* flags);
 const char* ssw_status_string(int status);
 /* Text of the last failing HIP call on this thread (empty string if none). */
 const char* ssw_last_error(void);

@@ -28,6 +28,7 @@ PRECISION_F32, PRECISION_F64 = 0, 1
 STAGES = ["rgb_to_yiq", "dct_row", "dct_col", "select", "embed", "extract", "similarity", "yiq_to_rgb",
           "resize", "convert", "dct_prep", "dct_row_main", "dct_col_main"]
 DCT_FOLDING_DEFAULT = 5
+PLAN_FLAGS = {"pair_f64": 1, "rows_deep": 2, "cols_deep": 4, "rows_level2": 8, "cols_level2": 16, "class_major": 32, "fused_cols": 64}
 TRANSFER_STATS = ["h2d_bytes", "d2h_bytes", "h2d_seconds", "d2h_seconds", "staged_bytes", "direct_bytes"]
 
 
@@ -42,6 +43,7 @@ _cfgp = C.POINTER(Config)
 SIGNATURES = {
     "ssw_version": (C.c_char_p, []),
     "ssw_build_all_strategies": (C.c_int, []),
+    "ssw_ctx_transform_plan": (C.c_int, [_vp, _sz, _sz, _sz, C.c_int, C.POINTER(C.c_uint32)]),
     "ssw_status_string": (C.c_char_p, [C.c_int]),
     "ssw_last_error": (C.c_char_p, []),
     "ssw_config_default": (None, [_cfgp]),

@@ -96,6 +96,12 @@ class Context:
         check(self._lib.ssw_ctx_get_traffic(self.handle, traffic), "ssw_ctx_get_traffic")
         return {s: {"ms": ms[i], "launches": int(n[i]), "work": work[i], "bytes": traffic[i]} for i, s in enumerate(L.STAGES)}
 
+    def transform_plan(self, n_frames: int, w: int, h: int, dct_type: int = L.DCT2) -> dict:
+        """Which strategy of the 2-D transform a batch of this shape takes (include/ssw.h: ssw_ctx_transform_plan)."""
+        f = C.c_uint32()
+        check(self._lib.ssw_ctx_transform_plan(self.handle, n_frames, w, h, dct_type, C.byref(f)), "ssw_ctx_transform_plan")
+        return {name: bool(f.value & bit) for name, bit in L.PLAN_FLAGS.items()}
+
     def set_overlap(self, on: bool = True):
         """Two chunks in flight on two streams in the batch entry points (default) or one at a time."""
         check(self._lib.ssw_ctx_set_overlap(self.handle, int(on)), "ssw_ctx_set_overlap")

@@ -164,6 +164,31 @@ extern "C" {
 const char* ssw_version(void) { return "ssw-hip 0.1.0 (gfx950)"; }
 int ssw_build_all_strategies(void) { return ssw::build_all_strategies() ? 1 : 0; }
 
+int ssw_ctx_transform_plan(ssw_ctx* ctx, size_t n_frames, size_t w, size_t h, int dct_type, uint32_t* flags) {
+    if (!ctx || !flags || w == 0 || h == 0) return SSW_ERR_BAD_ARG;
+    const bool inverse = dct_type == SSW_DCT3;
+    const bool pair = ctx->fold && ctx->fold_level >= 3 && w % 8 == 0 && h % 8 == 0 && w >= 16 && h >= 16 && ctx->split;
+    uint32_t f = 0;
+    if (pair) {
+        f |= SSW_PLAN_PAIR_F64;
+        const bool rows_first = w >= h;
+        const bool deep_r = inverse ? ssw::dct_pair_can_deep_inv_rows(w) : ssw::dct_pair_can_deep_rows(w);
+        const bool deep_c = ssw::dct_pair_can_deep_cols(h) && w % 4 == 0;
+        if (deep_r) f |= SSW_PLAN_ROWS_DEEP;
+        if (deep_c) f |= SSW_PLAN_COLS_DEEP;
+        const bool l2r = deep_r && (inverse ? ssw::dct_pair_efold_inv(w) : ssw::dct_pair_efold(w));
+        const bool cm = rows_first && deep_r && w % 4 == 0 && (deep_c || (ssw::dct_pair_can_semi_deep_cols(h) && ssw::dct_pair_prep_staged_cols_ok(w, true)));
+        const bool l2c = deep_c && ssw::dct_pair_efold_cols(h, w, cm);
+        if (l2r) f |= SSW_PLAN_ROWS_LEVEL2;
+        if (l2c) f |= SSW_PLAN_COLS_LEVEL2;
+        if (cm) f |= SSW_PLAN_CLASS_MAJOR;
+        if (l2r && l2c && cm && (inverse ? ssw::dct_pair_can_fuse_inv_cols(n_frames, w, h) : ssw::dct_pair_can_fuse_cols(n_frames, w, h)))
+            f |= SSW_PLAN_FUSED_COLS;
+    }
+    *flags = f;
+    return SSW_OK;
+}
+
 const char* ssw_status_string(int s) {
     switch (s) {
     case SSW_OK: return "ok";

@@ -61,6 +61,27 @@ def test_fused_forward_transform_equals_the_unfused_one():
     assert lines[-1] == "fused forward transform: all good"
 
 
+def test_transform_plan_reports_the_default_path():
+    """ssw_ctx_transform_plan (include/ssw.h): what a batch of a given shape runs -- the bench configuration takes the fused
+    level-2 path, full HD has level-2 rows over semi-deep columns (no fusion), the reference's 640 x 444 photograph
+    (tests/single_simple.rs:13) the dense kernels; fuse_cols = 0 switches the fusion off and nothing else."""
+    import gpu_util as G
+    from spread_spectrum_watermarking_amd import _lib as L, tuning
+    c = G.ctx()
+    p = c.transform_plan(128, 3840, 2160)
+    assert all(p[k] for k in ("pair_f64", "rows_deep", "cols_deep", "rows_level2", "cols_level2", "class_major", "fused_cols")), p
+    assert c.transform_plan(1, 3840, 2160)["fused_cols"] and not c.transform_plan(2, 3840, 2160)["fused_cols"]      # one merged launch / too few tiles
+    assert not c.transform_plan(128, 3840, 2160, L.DCT3)["fused_cols"]                  # the inverse's fusion is opt-in
+    p = c.transform_plan(256, 1920, 1080)
+    assert p["pair_f64"] and p["rows_level2"] and p["class_major"] and not p["cols_deep"] and not p["fused_cols"], p
+    assert not c.transform_plan(1, 640, 444)["pair_f64"]
+    with tuning(fuse_cols=0):
+        q = c.transform_plan(128, 3840, 2160)
+        assert not q["fused_cols"] and q["cols_level2"] and q["rows_level2"]
+    with tuning(fuse_inv_cols=1):
+        assert c.transform_plan(128, 3840, 2160, L.DCT3)["fused_cols"]
+
+
 def test_tuning_table_round_trip():
     """ssw_tuning_set / get / reset (include/ssw.h): defaults, a set value, reset, unknown names."""
     from spread_spectrum_watermarking_amd import _lib as L, tuning

@@ -3,9 +3,9 @@
 #   bench JSON lines of the four BASELINE configs, rocprofv3 kernel-trace stats of the same commands, and the
 #   PMC passes (HBM traffic, VALU / LDS activity) of a short 4K run -- separate --pmc passes, never combined with
 #   trace domains other than the kernel trace (MI355X_MICROARCH.md, rocprofv3 section).
-# usage (in the container, so that the commit is recorded): git rev-parse --short HEAD > .commit_stamp; gpurun -- bash tools/collect_profiles.sh r4
+# usage (in the container, so that the commit is recorded): git rev-parse --short HEAD > .commit_stamp; gpurun -- bash tools/collect_profiles.sh r5
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"

@@ -44,6 +44,7 @@ try:        # MFMA pipe occupancy in cycles (independent of the clock the chip h
 except OSError:
     mfma = {}
 lines_r, lines_c = chunk * H, chunk * W
+lines_p = chunk * 16 * (-(-(H // 16) // 8) * 8) if H % 16 == 0 else lines_r      # unit-ordered, padded lines of a fused row pass
 esz = 8
 K8 = lambda n: -(-(n // 8) // 16) * 16        # padded sum length of the n/8-wide operand planes
 K16 = lambda n: -(-(n // 16) // 16) * 16      # ... of the n/16-wide ones
@@ -56,6 +57,14 @@ names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESI
     "pair_gemm_f64_kernel<false, 0, false, 4>": ("pair_gemm_f64_kernel<rows, split odd half, class O (level 2: rotated, '+' launch)>",
         2 * lines_r * KR * esz + 2 * (PR + 1) * KR * esz + lines_r * (2 * PR) * 4,
         "two operand planes (k-blocked f64) x cosine / sine rows -> two frequencies per pair (f32); level 2: W/16 + 1 pairs in W/16 slots"),
+    # r5: the fused forward transform -- the row launches' epilogue writes the column operands (EPI_FWD_COLOP = 7): operand lines
+    # are the frame's rows in unit order, padded to whole k-blocks of units (H/16 -> a multiple of 8)
+    "pair_gemm_f64_kernel<false, 7, false, 4>": ("pair_gemm_f64_kernel<rows, fused column operands, class O rotated '+' launch>",
+        2 * lines_p * KR * esz + 2 * (PR + 1) * KR * esz + lines_r * (2 * PR) * esz,
+        "r5: two row operand planes in, the launch's two frequencies of every line out as entries of the sixteen f64 column-operand planes (8 B per output instead of 4)"),
+    "pair_gemm_f64_kernel<false, 7, false, 3>": ("pair_gemm_f64_kernel<rows, fused column operands, other classes>",
+        2 * lines_p * KR * esz + 2 * PR * KR * esz + lines_r * (2 * PR) * esz,
+        "r5: the other seven launches of a fused forward row pass: mean over launches"),
     "pair_gemm_f64_kernel<false, 0, false, 3>": ("pair_gemm_f64_kernel<rows, split odd halves, other classes>",
         2 * lines_r * KR * esz + 2 * PR * KR * esz + lines_r * (2 * PR) * 4,
         "the other split classes of the forward row pass (level 2: six launches of the same size) and the gathered launches of the pruned transform: mean over launches"),
@@ -137,7 +146,22 @@ out["families"] = {"_unit": f"one step = embed + extract of one {chunk}-frame pa
 # algorithmic bytes of the pre-pass family per step: writer frame RGB f32 -> operands + I, Q (28 B/px),
 # base and derived frames (20 B/px each), forward columns x 2, inverse rows, inverse columns (12 B/px each); the
 # column pre-passes of the pruned derived transform work on compact planes (a few percent of a frame, not counted)
-out["families"]["prepass"]["algorithmic_bytes_per_step"] = int(px_step * (28 + 20 + 20 + 4 * 12))
-out["families"]["prepass"]["traffic_over_algorithmic"] = round(out["families"]["prepass"]["hbm_bytes_per_step"] / (px_step * (28 + 20 + 20 + 4 * 12)), 3)
+# r5: a fused forward transform has no column pre-pass (its launches are absent from the profile): count what ran
+n_fwd_cols = out["families"]["prepass"]["members_launches_per_step"].get("prep16_cols_l2_kernel<1>", 0) + \
+             out["families"]["prepass"]["members_launches_per_step"].get("prep16_cols_staged_kernel<1, true>", 0)
+pre_alg = px_step * (28 + 20 + 20 + (n_fwd_cols + 2) * 12)
+out["families"]["prepass"]["algorithmic_bytes_per_step"] = int(pre_alg)
+out["families"]["prepass"]["traffic_over_algorithmic"] = round(out["families"]["prepass"]["hbm_bytes_per_step"] / pre_alg, 3)
+# the GEMM family's algorithmic bytes per step, as ssw_ctx_get_traffic counts them (csrc/ssw_pipeline.hip build_pass): per
+# pixel of a pass -- operand planes in (8) + result out (f32: 4; fused forward rows: the column operands, 8) + what the
+# dependent launches of an inverse pass exchange (A1 1 + 1, T2 2 + 2, E 4 + 4 = 14); the last pass of Writer::result reads
+# I, Q (8) and writes RGB f32 (12) instead of 4; the pruned derived row pass reads its operands (8) and writes a compact plane
+fused = any(k.startswith("pair_gemm_f64_kernel<false, 7") for k in out["families"]["gemm"]["members_launches_per_step"])
+fwd_rows = 16 if fused else 12
+gemm_alg = px_step * (2 * (fwd_rows + 12)            # writer and base reader: forward rows + columns
+                      + 8                             # derived frame: operands of the gathered row launches (the compact planes are a few percent)
+                      + (8 + 14 + 4) + (8 + 14 + 8 + 12))      # inverse rows; inverse columns with the RGB epilogue
+out["families"]["gemm"]["algorithmic_bytes_per_step"] = int(gemm_alg)
+out["families"]["gemm"]["traffic_over_algorithmic"] = round(out["families"]["gemm"]["hbm_bytes_per_step"] / gemm_alg, 3)
 json.dump(out, sys.stdout, indent=1)
 print()
