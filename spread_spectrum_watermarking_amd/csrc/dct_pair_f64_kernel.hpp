@@ -438,11 +438,12 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     //      two waves that share a tile row complete the 64-byte pieces, the pairs of one MFMA tile complete runs of
     //      16 lines x 64 bytes per (plane, 128-frequency tile).
     if constexpr (!COLS && EPI == EPI_FWD_COLOP) {
-        constexpr int NIT = 32 * NJ, NC = (NIT + 63) / 64, PITCH = 20;
-        static_assert(4 * NIT * PITCH * 4 <= (int)sizeof(lds), "transpose area");
+        constexpr int NIT = 32 * NJ, NC = (NIT + 63) / 64;
+        constexpr int NPT = FULL ? 64 : 16 * NJ, NLT = 2 * NPT;            // pairs / column-operand lines of the whole tile
+        static_assert(4 * NIT * 16 * 4 <= (int)sizeof(lds) && 4 * NLT * 64 <= (int)sizeof(lds), "transpose area, store slabs");
         static_assert(BM == 128, "a tile is one k-block of eight units");
         __syncthreads();                      // every wave has read its last fragments: the operand tiles are free
-        float* tw = reinterpret_cast<float*>(lds) + wave * (NIT * PITCH);
+        float* tw = reinterpret_cast<float*>(lds) + wave * (NIT * 16);
         auto lds_order = [&]() {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -453,18 +454,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
         const unsigned z = tm / tpf, g = tm - z * tpf;
         const unsigned u0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(wm / 16));
         const bool plain = ep.first == 1.0f && ep.base == 1.0f;
-        // this lane's items: item f = lane + 64 c -> pair tile jn = f / 32, output (f / 16) & 1, pair f & 15
-        bool it_ok[NC];
-        size_t it_line[NC];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const unsigned f = lane + 64 * c;
-            const unsigned pair = p0 + wn + 16 * (f >> 5) + (f & 15u);
-            const bool second = ((f >> 4) & 1u) != 0;
-            it_ok[c] = f < (unsigned)NIT && pair < NP && (second ? (pair >= po.p2lo && second_out) : pair < po.np1);
-            const unsigned mc = second ? fpos2(pair) : fpos1(pair);          // memory column = operand line of the column pass
-            it_line[c] = ((size_t)g * po.cop_lines + (size_t)z * po.W + (it_ok[c] ? mc : 0u)) * 8u + u0;
-        }
+        // LDS position of line v of item f in the wave's transpose area: 16 floats per item, the four quads of an item
+        // XOR-swizzled by (item / 4) & 3 -- conflict-free for the ds_write_b32 of a lane group and the ds_read_b128 of 16 items
+        auto lpos = [&](unsigned f, unsigned v) { return f * 16u + 4u * ((v >> 2) ^ ((f >> 2) & 3u)) + (v & 3u); };
         // f32 factor of the frequencies this lane's accumulators belong to (EPI_FWD: first for index 0, else base)
         float f1[NJ], f2[NJ];
 #pragma unroll
@@ -473,6 +465,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
             f1[jn] = fpos1(pair) == 0 ? ep.first : ep.base;
             f2[jn] = fpos2(pair) == 0 ? ep.first : ep.base;
         }
+        // phase A: this lane's items (item f = lane + 64 c of the wave: pair tile f / 32, output (f / 16) & 1, pair f & 15),
+        // all sixteen planes of the wave's NI units
         double o[NC][NI][16];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -483,8 +477,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                 for (int r = 0; r < 4; ++r) {
                     float v1 = (float)acc1[i][jn][r], v2 = (float)acc2[i][jn][r];
                     if (!plain) { v1 *= f1[jn]; v2 *= f2[jn]; }
-                    tw[(32 * jn + li) * PITCH + lq + 4 * r] = v1;
-                    tw[(32 * jn + 16 + li) * PITCH + lq + 4 * r] = v2;
+                    tw[lpos(32 * jn + li, lq + 4 * r)] = v1;
+                    tw[lpos(32 * jn + 16 + li, lq + 4 * r)] = v2;
                 }
             lds_order();
             const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)(8 * g + u0 + i));
@@ -496,7 +490,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                 float x[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(tw + f * PITCH + 4 * q);
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(tw + lpos(f, 4 * q));
                     x[4 * q] = t4[0]; x[4 * q + 1] = t4[1]; x[4 * q + 2] = t4[2]; x[4 * q + 3] = t4[3];
                 }
                 col_l2_unit(x, tab, o[c][i]);
@@ -506,16 +500,59 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                 }
             }
         }
-        const size_t pstride = (size_t)po.cop_lines * po.cop_k16;
+        // phase B: the results leave through LDS slabs that are images of the stored runs.  (Stored straight from the lanes --
+        // 16 bytes of 64 different pieces per instruction -- every piece was a partial write that made the L2 fetch its line
+        // first: PMC FETCH_SIZE of a launch 2.17 GB against 1.07 GB of operands, profiles/r5_pmc_traffic.json.)  Tile line
+        // T = 16 (pair / 8) + 8 output + pair % 8 of the tile's pairs: eight pairs' first outputs and their second outputs
+        // are sixteen consecutive column-operand lines (ForwardClassLayout: two neighbouring classes, eight entries per
+        // 128-column tile).  A slab = one plane x the tile's 2 NPT lines x the k-block's eight units (64 bytes per line; the
+        // four 16-byte chunks of a line XOR-swizzled by (T / 4) & 3); four planes per round, four rounds.  Store sweep: thread
+        // = (line, chunk), four lanes complete a 64-byte piece, a wave writes 1 KB of sixteen consecutive lines.
+        double* slab = lds;
+        unsigned tl[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            if (!it_ok[c]) continue;
-            double* dst0 = po.cop + it_line[c];
+            const unsigned f = lane + 64 * c, pl = wn + 16 * (f >> 5) + (f & 15u);      // pair inside the tile
+            tl[c] = f < (unsigned)NIT ? 16u * (pl >> 3) + 8u * ((f >> 4) & 1u) + (pl & 7u) : 0u;
+        }
+        constexpr int NSW = (NLT * 4 + 255) / 256;                 // (line, chunk) items per thread of the store sweep
+        bool st_ok[NSW];
+        size_t st_off[NSW];
+        unsigned st_lds[NSW];
 #pragma unroll
-            for (int a = 0; a < 16; ++a) {
-                double* d = dst0 + (size_t)a * pstride;
+        for (int j = 0; j < NSW; ++j) {
+            const unsigned idx = tid + 256 * j, T = idx >> 2, p4 = idx & 3u;
+            const unsigned pl = ((T >> 4) << 3) | (T & 7u), pair = p0 + pl;
+            const bool second = ((T >> 3) & 1u) != 0;
+            st_ok[j] = T < (unsigned)NLT && pair < NP && (second ? (pair >= po.p2lo && second_out) : pair < po.np1);
+            const unsigned mc = st_ok[j] ? (second ? fpos2(pair) : fpos1(pair)) : 0u;   // memory column = operand line of the column pass
+            st_off[j] = ((size_t)g * po.cop_lines + (size_t)z * po.W + mc) * 8u + 2u * p4;
+            st_lds[j] = (T < (unsigned)NLT ? T : 0u) * 8u + 2u * (p4 ^ ((T >> 2) & 3u));
+        }
+        const size_t pstride = (size_t)po.cop_lines * po.cop_k16;
 #pragma unroll
-                for (int i = 0; i < NI; i += 2) *reinterpret_cast<f64x2*>(d + i) = (f64x2){o[c][i][a], o[c][i + 1][a]};
+        for (int rnd = 0; rnd < 4; ++rnd) {
+            __syncthreads();                  // the transpose areas (round 0) / the previous round's slabs have been read
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                if ((lane + 64 * c) >= (unsigned)NIT) continue;
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int i = 0; i < NI; i += 2) {
+                        const unsigned ch = ((u0 + i) >> 1) ^ ((tl[c] >> 2) & 3u);
+                        *reinterpret_cast<f64x2*>(slab + (a * NLT + tl[c]) * 8 + 2 * ch) = (f64x2){o[c][i][4 * rnd + a], o[c][i + 1][4 * rnd + a]};
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < NSW; ++j) {
+                if (!st_ok[j]) continue;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f64x2 v = *reinterpret_cast<const f64x2*>(slab + a * NLT * 8 + st_lds[j]);
+                    *reinterpret_cast<f64x2*>(po.cop + (size_t)(4 * rnd + a) * pstride + st_off[j]) = v;
+                }
             }
         }
         trace_end();
