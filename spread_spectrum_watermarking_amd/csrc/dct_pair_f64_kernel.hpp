@@ -551,6 +551,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const f64x2 v = *reinterpret_cast<const f64x2*>(slab + a * NLT * 8 + st_lds[j]);
+                    // (non-temporal stores here: measured, no change in time or in FETCH_SIZE)
                     *reinterpret_cast<f64x2*>(po.cop + (size_t)(4 * rnd + a) * pstride + st_off[j]) = v;
                 }
             }
