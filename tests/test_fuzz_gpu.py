@@ -70,10 +70,11 @@ def test_transform_plan_reports_the_default_path():
     c = G.ctx()
     p = c.transform_plan(128, 3840, 2160)
     assert all(p[k] for k in ("pair_f64", "rows_deep", "cols_deep", "rows_level2", "cols_level2", "class_major", "fused_cols")), p
-    # up to three 4K frames run a pass's eight classes as one launch (128-line tiles fill the chip); four to six frames launch
-    # the classes one by one on 64-line tiles and keep the f32 plane
-    assert c.transform_plan(1, 3840, 2160)["fused_cols"] and c.transform_plan(3, 3840, 2160)["fused_cols"]
-    assert not c.transform_plan(5, 3840, 2160)["fused_cols"] and c.transform_plan(7, 3840, 2160)["fused_cols"]
+    # one or two 4K frames run a pass's eight classes as one launch (both passes stay below merge_max_lines: 128-line tiles
+    # fill the chip); three to six frames launch the classes one by one on 64-line tiles and keep the f32 plane
+    assert c.transform_plan(1, 3840, 2160)["fused_cols"] and c.transform_plan(2, 3840, 2160)["fused_cols"]
+    assert not c.transform_plan(3, 3840, 2160)["fused_cols"] and not c.transform_plan(5, 3840, 2160)["fused_cols"]
+    assert c.transform_plan(7, 3840, 2160)["fused_cols"]
     assert not c.transform_plan(128, 3840, 2160, L.DCT3)["fused_cols"]                  # the inverse's fusion is opt-in
     p = c.transform_plan(256, 1920, 1080)
     assert p["pair_f64"] and p["rows_level2"] and p["class_major"] and not p["cols_deep"] and not p["fused_cols"], p

@@ -508,6 +508,33 @@ def test_bench_under_torchrun_two_ranks(tmp_path):
     assert np.load(dumpf)["sims"].shape == (6,)
 
 
+def test_custom_closure_hybrid_through_the_low_level_entry_points():
+    """INTEGRATION.md 3b: `OrderingMethod::Custom` / `Insertion::Custom` closures (src/algorithm.rs:24-64) run on the host, the
+    transforms around them on the device through ssw_rgb_to_yiq / ssw_dct2d / ssw_yiq_to_rgb.  With closures that restate the
+    built-in Energy ordering (:214-221) and Option2 insertion (:414-432) the hybrid must reproduce Writer::mark bit for bit."""
+    w, h, k = 1280, 720, 500
+    rgb = G.synth(17, 0, 1, w, h)[0]
+    mark = np.random.default_rng(5).standard_normal(k).astype(np.float32)
+    y, i, q = G.rgb_to_yiq(rgb)
+    coef = G.dct2d(y[0], L.DCT2, F64)
+
+    def ordering(c):                         # the caller's closure: stable descending sort of c * c, DC skipped (:200-221)
+        e = (c.reshape(-1) * c.reshape(-1))[1:]
+        return 1 + np.argsort(-e.astype(np.float64), kind="stable")
+
+    def insert(c, m):                        # Option2 with alpha 0.1, f32 arithmetic, un-fused (:420-424)
+        return c * (np.float32(1.0) + np.float32(0.1) * m)
+
+    order = ordering(coef)[:k]
+    flat = coef.reshape(-1).copy()
+    flat[order] = insert(flat[order], mark)
+    back = G.dct2d(flat.reshape(h, w), L.DCT3, F64)
+    marked = G.yiq_to_rgb(back, i[0], q[0])[0]
+    ref = wm.Writer(rgb).mark([mark])
+    assert np.array_equal(order.astype(np.uint32), wm.Reader.base(rgb).indices(k).astype(np.uint32))
+    assert np.array_equal(marked, ref)
+
+
 def test_bench_eight_ranks_dry_run_on_one_gpu(tmp_path):
     """SURVEY 8(e) / BASELINE configs[3]: the 8-rank launch of the driver's scaling sweep, rehearsed on this box's single
     GPU (every rank on device 0, gloo coordination; NO throughput is claimed from it): eight processes, eight contexts,

@@ -21,7 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
 
 # (h, w, frames): frames chosen so that both passes run on 128-line tiles (dct_pair_can_fuse_cols)
 SHAPES = [(256, 256, 224), (272, 512, 150), (720, 1280, 46), (1088, 2048, 25), (2160, 3840, 8), (4320, 7680, 2),
-          (2160, 3840, 1), (4320, 7680, 1), (2160, 3840, 3)]           # single frames: the eight classes of a pass in ONE launch
+          (2160, 3840, 1), (4320, 7680, 1), (2160, 3840, 2)]           # single frames: the eight classes of a pass in ONE launch
 BATCH = [(720, 1280, 48, 300), (2160, 3840, 8, 1000)]           # (h, w, frames, k)
 LOW = dict(efold_min=256, efold_inv_min=256, efold_cols_min=64)
 
@@ -38,6 +38,8 @@ def run(out=print, shapes=SHAPES, batch=BATCH):
             preps = []
             for fuse in (1, 0):
                 with tuning(fuse_cols=fuse, fuse_inv_cols=fuse, **LOW), G.fresh_ctx() as c:
+                    if fuse:
+                        planned = c.transform_plan(n, w, h, kind)["fused_cols"]
                     c.enable_timing(True)
                     c.reset_timing()
                     r = G.dct2d(x, kind, L.PRECISION_F64)
@@ -48,8 +50,9 @@ def run(out=print, shapes=SHAPES, batch=BATCH):
                 else:
                     b = r
             # the fused transform has ONE pre-pass stage (rows), the unfused one two (rows, columns): the path under test ran
-            # (a single frame's inverse stays unfused: its dependent launches run one class each on 64-line tiles)
-            same = bool(np.array_equal(a, b)) and preps == ([2, 2] if (kind == L.DCT3 and n <= 3) else [1, 2])
+            # every forward case of the list must take the fused path; the inverse of one or two 4K frames stays unfused (its
+            # dependent launches run one class each, on 64-line tiles) -- ssw_ctx_transform_plan says which, the stage count confirms
+            same = bool(np.array_equal(a, b)) and preps == ([1, 2] if planned else [2, 2]) and (planned or kind == L.DCT3)
             worst = 1.0
             for f in (0, n - 1):
                 worst = min(worst, float(np.mean(a[f] == O.dct2d(x[f], kind))))
