@@ -774,13 +774,14 @@ def _frame_vs_oracle(rgb, mark, coef, idx, marked, ext, sim):
 
 
 def test_4k_bench_configuration_equals_handles_and_oracle():
-    """The configuration bench.py times (BASELINE configs[3], per-GPU shard) in the shape GPUTEST owns: sixteen
-    3840x2160 frames in two passes of eight (set_chunk_frames(8): 17280 lines per pass > merge_max_lines, i.e. the
-    unmerged eight-launch passes on 128-line tiles, two lanes, the pruned derived transform) -- every frame's index list,
-    marked frame, extracted mark and similarity bit for bit against the single-image handles (full transforms, merged
-    single-frame launches), the first and the last frame against the oracle with the bars of
+    """The configuration bench.py times (BASELINE configs[3], per-GPU shard) in the shape GPUTEST owns: twenty
+    3840x2160 frames in passes of eight, eight and four (set_chunk_frames(8): 17280 lines per pass > merge_max_lines, i.e.
+    the unmerged eight-launch passes on 128-line tiles with the fused forward transform, two lanes, the pruned derived
+    transform; the ragged last pass of four frames takes the unfused path on 64-line tiles through the same lanes) -- every
+    frame's index list, marked frame, extracted mark and similarity bit for bit against the single-image handles (full
+    transforms, merged single-frame launches), the first and the last frame against the oracle with the bars of
     _whole_pipeline_vs_oracle.  Reference flow: src/algorithm.rs:295-379, :462-562, :696-714."""
-    w, h, k, n = 3840, 2160, 1000, 16
+    w, h, k, n = 3840, 2160, 1000, 20
     ctx = G.ctx()
     rgb = G.synth(1, 0, n, w, h)                                 # bench.py's frames: seed 1, frames 0 .. n - 1
     marks = np.random.default_rng(41).standard_normal((n, k)).astype(np.float32)
@@ -792,7 +793,8 @@ def test_4k_bench_configuration_equals_handles_and_oracle():
     finally:
         ctx.set_chunk_frames(0)
     ps, ss = ctx.prune_stats(), ctx.select_stats()
-    assert ps["pruned_chunks"] == 2 and ps["redone_chunks"] == 0, ps
+    assert ps["pruned_chunks"] == 3 and ps["redone_chunks"] == 0, ps
+    assert ctx.transform_plan(8, w, h)["fused_cols"] and not ctx.transform_plan(4, w, h)["fused_cols"]
     assert ss["exact_fallback_frames"] == 0, ss
     for f in range(n):
         rd = wm.Reader.base(rgb[f])
