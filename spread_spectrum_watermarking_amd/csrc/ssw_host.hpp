@@ -66,7 +66,9 @@ struct StageTimer {
     int stage;
     hipStream_t st;
     hipEvent_t a = nullptr, b = nullptr;
-    StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work = 0.0);
+    bool armed = false;
+    int alias = -1;              // a second stage that this region IS (a pass that runs as its one "main" launch): same time, no events of its own
+    StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work = 0.0, int alias_stage = -1);
     ~StageTimer();
     // algorithmic HBM bytes of a GEMM stage (operands in, results and the inverse's E / T2 / A1 exchange out and in):
     // the HBM-bound stages' bytes ARE their work and are counted by the constructor

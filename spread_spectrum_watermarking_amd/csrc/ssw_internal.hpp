@@ -380,7 +380,11 @@ struct ssw_ctx {
     struct Pending {
         int stage;
         hipEvent_t a, b;
+        int alias = -1;
     };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> free_events;
+    hipEvent_t tail_event = nullptr;      // last event a stage timer recorded; shared with the next timer while tail_fresh
+    hipStream_t tail_stream = nullptr;
+    bool tail_fresh = false;
 };

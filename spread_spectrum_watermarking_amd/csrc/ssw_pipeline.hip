@@ -24,6 +24,7 @@ namespace host {
 namespace { thread_local ssw_ctx* tl_ctx = nullptr; }
 CtxGuard::CtxGuard(ssw_ctx* ctx) : dg(ctx->device), prev(tl_ctx) {
     tl_ctx = ctx;
+    if (prev != ctx) { ctx->tail_event = nullptr; ctx->tail_fresh = false; }     // timer events are shared inside one call only
     // buffers retired by grow() during the previous call: nothing built then is still to be enqueued (hipFree waits for
     // work in flight); nested guards (prev == ctx) leave them to the outermost one
     if (prev != ctx && !ctx->retired.empty()) {
@@ -118,40 +119,59 @@ int grow_select(hipStream_t st, SelectWorkspace& s, size_t frames, size_t k) {
     return SSW_OK;
 }
 
-StageTimer::StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work) : ctx(c), stage(s), st(stream) {
+// Stage timers share their boundary events (r5): a stage that starts right after another one ended on the same stream --
+// nothing enqueued in between: the stages of a chain, a "main launch" timer nested at the start or the end of its pass --
+// takes the event that is already in the stream instead of recording a second one.  An event record is a barrier in the
+// queue (~3 us during which the next kernel cannot overlap the previous one's tail): a single-frame embed had 28 of them in
+// 0.6 ms of kernels.  ctx->tail_event is the last event recorded by a timer, valid while ctx->tail_fresh (cleared by every
+// launch helper that is not bracketed by a timer: see untimed_work(); reset at every entry into the library).
+static hipEvent_t timer_event(ssw_ctx* ctx, hipStream_t st) {
+    if (ctx->tail_event && ctx->tail_fresh && ctx->tail_stream == st) return ctx->tail_event;
+    hipEvent_t e = nullptr;
+    if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
+    else if (hipEventCreateWithFlags(&e, hipEventReleaseToDevice) != hipSuccess) return nullptr;
+    if (hipEventRecord(e, st) != hipSuccess) { ctx->free_events.push_back(e); return nullptr; }
+    ctx->tail_event = e; ctx->tail_stream = st; ctx->tail_fresh = true;
+    return e;
+}
+StageTimer::StageTimer(ssw_ctx* c, int s, hipStream_t stream, double work, int alias_stage) : ctx(c), stage(s), st(stream), alias(alias_stage) {
     if (!ctx->timing) return;
     ctx->stage_work[stage] += work;
+    if (alias >= 0) ctx->stage_work[alias] += work;
     const bool gemm = stage == SSW_STAGE_DCT_ROW || stage == SSW_STAGE_DCT_COL || stage == SSW_STAGE_DCT_ROW_MAIN || stage == SSW_STAGE_DCT_COL_MAIN;
     if (!gemm) ctx->stage_bytes[stage] += work;
-    auto get = [&]() {
-        hipEvent_t e = nullptr;
-        if (!ctx->free_events.empty()) { e = ctx->free_events.back(); ctx->free_events.pop_back(); }
-        else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
-        return e;
-    };
-    a = get(); b = get();
-    if (a) (void)hipEventRecord(a, st);
+    a = timer_event(ctx, st);
+    ctx->tail_fresh = false;                  // the stage's launches follow: its end needs an event of its own
+    armed = a != nullptr;
 }
 void StageTimer::traffic(double bytes) {
     if (ctx->timing) ctx->stage_bytes[stage] += bytes;
 }
 StageTimer::~StageTimer() {
-    if (!ctx->timing || !a || !b) return;
-    (void)hipEventRecord(b, st);
-    ctx->pending.push_back({stage, a, b});
+    if (!ctx->timing || !armed) return;
+    // (a nested timer that just ended left a fresh event: the outer stage ends at the same point)
+    b = timer_event(ctx, st);
+    if (b) ctx->pending.push_back({stage, a, b, alias});
 }
 
 int flush_timers(ssw_ctx* ctx) {
+    std::vector<hipEvent_t> used;
     for (auto& p : ctx->pending) {
         float ms = 0.f;
         SSW_HIP_CHECK(hipEventSynchronize(p.b));
         SSW_HIP_CHECK(hipEventElapsedTime(&ms, p.a, p.b));
         ctx->stage_ms[p.stage] += ms;
         ctx->stage_launches[p.stage] += 1;
-        ctx->free_events.push_back(p.a);
-        ctx->free_events.push_back(p.b);
+        if (p.alias >= 0) { ctx->stage_ms[p.alias] += ms; ctx->stage_launches[p.alias] += 1; }
+        used.push_back(p.a);
+        used.push_back(p.b);
     }
     ctx->pending.clear();
+    // shared boundary events appear in two entries: each goes back to the pool once
+    std::sort(used.begin(), used.end());
+    used.erase(std::unique(used.begin(), used.end()), used.end());
+    for (hipEvent_t e : used) ctx->free_events.push_back(e);
+    ctx->tail_event = nullptr; ctx->tail_fresh = false;
     return SSW_OK;
 }
 
@@ -411,10 +431,9 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                     const FuseCols fc{FUSE_ROWS_COP, cop, (const double*)crot1, (const double*)crot2, (const double*)crot3};
                     const bool merge_r = lpad <= merge_max_lines();       // a single frame: the eight classes in one launch
                     ch.push_back({false, [=](hipStream_t st) -> int {
-                        StageTimer t(ctx, st_pass, st, f_all * pad);
+                        StageTimer t(ctx, st_pass, st, f_all * pad, merge_r ? st_main : -1);
                         t.traffic(px * (esz + 8.0));                     // row operands in, column operands out
                         if (merge_r) {
-                            StageTimer tm(ctx, st_main, st, f_all * pad);
                             return launch_dct_pair_gemm_multi_f64(st, true, false, 8, d, nullptr, nullptr, n, w, h, ep, nullptr, nullptr, true, &fc);
                         }
                         for (int c = 0; c < 7; ++c)
@@ -435,10 +454,9 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                 const FuseCols fc{FUSE_COLS};
                 const bool merge_c = lines <= merge_max_lines();
                 ch.push_back({false, [=](hipStream_t st) -> int {
-                    StageTimer t(ctx, st_pass, st, f_all);
+                    StageTimer t(ctx, st_pass, st, f_all, merge_c ? st_main : -1);
                     t.traffic(gemm_bytes(0.0));
                     if (merge_c) {
-                        StageTimer tm(ctx, st_main, st, f_all);
                         return launch_dct_pair_gemm_multi_f64(st, false, false, 8, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, false, &fc);
                     }
                     for (int c = 0; c < 7; ++c)
@@ -473,11 +491,10 @@ int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass,
                                             {8, 0, P(6), P(7), (const double*)t0, (const double*)t1},          // O rotated, "-"
                                             {7, 0, P(4), P(5), (const double*)t0, (const double*)t1}};         // O rotated, "+"
                 ch.push_back({false, [=](hipStream_t st) -> int {
-                    StageTimer t(ctx, st_pass, st, f_all);
+                    StageTimer t(ctx, st_pass, st, f_all, merge ? st_main : -1);
                     t.traffic(gemm_bytes(0.0));
                     const bool rcm = cm && is_row;
                     if (merge) {
-                        StageTimer tm(ctx, st_main, st, f_all);
                         return launch_dct_pair_gemm_multi_f64(st, is_row, false, 8, d, dst, nullptr, n, w, h, ep, nullptr, nullptr, rcm);
                     }
                     for (int c = 0; c < 7; ++c)
