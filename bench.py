@@ -350,7 +350,8 @@ def run_attack_resize(args, lib, L, ctx, check, dist, dev, rank, world, rgb, rgb
             "config": {"workload": f"batch={B}/GPU {W}x{H} 8-bit frames, {K}-coeff mark, embed -> into_rgb8 -> CatmullRom "
                                    f"resize to 1/8 and back -> extract + similarity; {workload_tag}",
                        "frames_per_gpu": B, "total_frames": total_frames, "width": W, "height": H, "k": K,
-                       "chunk_frames": chunk_eff, "parallelism": f"frame-sharded x{world}, no collectives"},
+                       "chunk_frames": chunk_eff, "transform_plan": ctx.transform_plan(min(chunk_eff, B), W, H),
+                       "parallelism": f"frame-sharded x{world}, no collectives"},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "roofline_step": step_roofline(args.precision, stage, args.steps, elapsed / args.steps * 1e3),
