@@ -466,6 +466,14 @@ def test_bench_line_carries_every_leg():
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1 and j["cpu_baseline"]["value"] > 0
     assert j["parity"]["frames"][0]["sim_delta_vs_cpu_exact"] < 1e-4
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] <= 1.0
+    # r5: what bounds the step -- algorithmic bytes of every stage (GEMM launches included) and executed flop over the wall time
+    rs = j["roofline_step"]
+    assert rs["bound"] in ("hbm", "mfma") and 0 < rs["frac"] <= 1.0 and rs["frac"] <= rs["frac_if_not_overlapped"]
+    by = rs["bytes_per_step_by_stage"]
+    assert by["dct_row"] > 0 and by["dct_col"] > 0 and by["rgb_to_yiq"] > 0 and abs(sum(by.values()) - rs["algorithmic_bytes_per_step"]) < 16
+    px = 4 * 512 * 288                                           # the step's pixels: RGB pre-passes move 28 + 20 + 20 B/px (writer, base, derived)
+    assert abs(by["rgb_to_yiq"] - 68 * px) <= 0.01 * 68 * px
+    assert set(j["config"]["transform_plan"]) >= {"pair_f64", "fused_cols"}
     # the two blocks describe the step: the GEMM kernel family and the pre-pass family (verdict r3 #2)
     assert j["roofline"]["name_match"].startswith("ssw::pair_gemm_") and 0 < j["roofline"]["share_of_step"] <= 1.0
     assert j["roofline_hbm"]["bound"] == "hbm" and j["roofline_hbm"]["name_match"] == "prep16" and 0 < j["roofline_hbm"]["frac"] <= 1.0
