@@ -86,6 +86,24 @@ def test_transform_plan_reports_the_default_path():
         assert c.transform_plan(128, 3840, 2160, L.DCT3)["fused_cols"]
 
 
+def test_diagnostic_build_runs_the_strategy_matrix():
+    """`make ALL_STRATEGIES=1` (lib/libssw_hip_all.so: the default library plus the r1 in-kernel folding and the f32 operand-
+    ready twin).  The tests that need those strategies skip themselves under the default library; here they run in a
+    child process that loads the diagnostic build through SSW_LIB_PATH -- the F32 parametrisations, folded against dense,
+    every folding level in f32, pruned / fused paths of the f32 twin."""
+    import subprocess
+    lib = os.path.join(ROOT, "spread_spectrum_watermarking_amd", "lib", "libssw_hip_all.so")
+    if not os.path.exists(lib):
+        pytest.skip("diagnostic library not built (make -C spread_spectrum_watermarking_amd/csrc ALL_STRATEGIES=1)")
+    env = dict(os.environ, SSW_LIB_PATH=lib)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), os.path.join(ROOT, "tests", "test_pipeline_gpu.py"),
+                        "-m", "gpu", "-q", "-x", "-k", "f32 or folded or strategy or pruned or fused_colour or batch_path"],
+                       env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    tail = r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], tail
+
+
 def test_tuning_table_round_trip():
     """ssw_tuning_set / get / reset (include/ssw.h): defaults, a set value, reset, unknown names."""
     from spread_spectrum_watermarking_amd import _lib as L, tuning
