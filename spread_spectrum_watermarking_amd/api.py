@@ -220,13 +220,14 @@ class tuning:
         return int(v.value)
 
     def __enter__(self):
+        self._previous = {name: tuning.get(name) for name in self._values}      # raises on an unknown name before anything is set
         for name, v in self._values.items():
             check(self._lib.ssw_tuning_set(name.encode(), int(v)), f"ssw_tuning_set({name})")
         return self
 
     def __exit__(self, *exc):
-        for name in self._values:
-            self._lib.ssw_tuning_reset(name.encode())
+        for name, v in self._previous.items():        # nested blocks restore the enclosing block's value, not the default
+            self._lib.ssw_tuning_set(name.encode(), v)
         return False
 
 

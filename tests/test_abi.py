@@ -68,3 +68,20 @@ def test_product_package_never_touches_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "libssw_oracle" not in src and "sswo_" not in src and "import oracle" not in src, f
                 assert "from oracle" not in src, f
+
+
+def test_tuning_table_needs_no_gpu():
+    """ssw_tuning_set / get / reset (include/ssw.h; csrc/tuning.hip): the process-wide table of strategy thresholds is host
+    state -- defaults, nested overrides through the Python context manager, unknown names."""
+    from spread_spectrum_watermarking_amd import _lib as L, tuning
+    lib = L.load()
+    base = tuning.get("efold_cols_min")
+    with tuning(efold_cols_min=64):
+        assert tuning.get("efold_cols_min") == 64
+        with tuning(efold_cols_min=128, fuse_inv_cols=1):
+            assert tuning.get("efold_cols_min") == 128 and tuning.get("fuse_inv_cols") == 1
+        assert tuning.get("efold_cols_min") == 64 and tuning.get("fuse_inv_cols") == 0
+    assert tuning.get("efold_cols_min") == base
+    assert lib.ssw_tuning_set(b"no_such_switch", 1) == L.SSW_ERR_BAD_ARG
+    assert lib.ssw_tuning_reset(None) == L.SSW_OK
+    assert lib.ssw_build_all_strategies() == 0          # the default library is what build() puts at lib/libssw_hip.so

@@ -111,6 +111,9 @@ def test_tuning_table_round_trip():
     assert tuning.get("efold_min") == int(os.environ.get("SSW_EFOLD_MIN", 1280))
     with tuning(efold_min=256):
         assert tuning.get("efold_min") == 256
+        with tuning(efold_min=512, fuse_cols=0):
+            assert tuning.get("efold_min") == 512 and tuning.get("fuse_cols") == 0
+        assert tuning.get("efold_min") == 256 and tuning.get("fuse_cols") == 1
     assert tuning.get("efold_min") == int(os.environ.get("SSW_EFOLD_MIN", 1280))
     assert lib.ssw_tuning_set(b"no_such_switch", 1) == L.SSW_ERR_BAD_ARG
     assert lib.ssw_tuning_reset(None) == L.SSW_OK
