@@ -196,7 +196,7 @@ bool dct_pair_can_fuse_cols(size_t n_frames, size_t w, size_t h) {
     if (dct_pair_class_tile(w) != 128 || !dct_pair_efold(w) || !dct_pair_efold_cols(h, w, true)) return false;
     const size_t hup = dct_pair_fused_units(h);
     if (pair_kpad<double>(h / 8) != hup) return false;
-    if (n_frames * 16 * hup > 0xFFFFFFFFull) return false;
+    if (n_frames * 16 * hup > 0xFFFFFFFFull || n_frames * w > 0xFFFFFFFFull) return false;      // 32-bit line indices in both passes
     return !launch_is_small(n_frames * 16 * hup, w / 16) && !launch_is_small(n_frames * w, h / 16);
 }
 // ... and the inverse transform of such frames (deep inverse rows need whole 128-column tiles anyway)
@@ -208,7 +208,7 @@ bool dct_pair_can_fuse_inv_cols(size_t n_frames, size_t w, size_t h) {
     if (dct_pair_class_tile(w) != 128 || !dct_pair_efold_inv(w) || !dct_pair_efold_cols(h, w, true)) return false;
     const size_t hup = dct_pair_fused_units(h);
     if (pair_kpad<double>(h / 8) != hup) return false;
-    if (n_frames * 16 * hup > 0xFFFFFFFFull) return false;
+    if (n_frames * 16 * hup > 0xFFFFFFFFull || n_frames * w > 0xFFFFFFFFull) return false;
     // (the inverse pass's dependent launches run one class each: every one must fill 128-line tiles by itself)
     auto small1 = [](size_t lines, size_t pairs) { return (unsigned long long)((lines + 127) / 128) * ((pairs + 63) / 64) < 448; };
     return !small1(n_frames * 16 * hup, w / 16) && !small1(n_frames * w, h / 16);
