@@ -367,4 +367,43 @@ int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1,
     return SSW_OK;
 }
 
+// Small passes (a single frame's derived transform: 17 tile rows, one or two tile columns per class -- nine launches of
+// 13-22 us each, every one a fraction of the chip's block slots): the classes of one kind side by side in one launch's tile
+// grid, like the merged launches of the full passes.  classes[c].x2 != nullptr: a class of the split odd half.
+int launch_dct_pair_gemm_rows_subset_merged_f64(hipStream_t st, const PairSubsetClass* classes, unsigned n_classes, float* out,
+                                                unsigned out_stride, size_t lines) {
+    if (lines == 0) return SSW_OK;
+    if (lines > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    const unsigned L = (unsigned)lines, tiles_m = (L + 127) / 128;
+    for (int split = 0; split < 2; ++split) {
+        PairMulti ml;
+        ml.n_classes = 0; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = 0;
+        auto flush = [&]() -> int {
+            if (ml.n_classes == 0) return SSW_OK;
+            const unsigned long long nblk = (unsigned long long)tiles_m * ml.tiles_n_total;
+            if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+            ml.po = PairOut{out, nullptr, out_stride, 0, 0, 0, 0, 1};
+            const Epilogue ep{1.f, 1.f};
+            if (split) pair_gemm_f64_kernel<false, EPI_FWD, false, 3><<<(unsigned)nblk, PT, 0, st>>>(ml, ep);
+            else       pair_gemm_f64_kernel<false, EPI_FWD, true, 2><<<(unsigned)nblk, PT, 0, st>>>(ml, ep);
+            SSW_HIP_CHECK(hipGetLastError());
+            ml.n_classes = 0; ml.tiles_n_total = 0;
+            return SSW_OK;
+        };
+        for (unsigned c = 0; c < n_classes; ++c) {
+            const PairSubsetClass& k = classes[c];
+            if ((k.x2 != nullptr) != (split != 0) || k.cap == 0) continue;
+            if (!split && (k.cap & 1)) return SSW_ERR_BAD_DIMS;
+            if ((unsigned long long)k.Kp * L * sizeof(double) > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+            const unsigned NP = split ? k.cap : k.cap / 2, tiles_n = (NP + 63) / 64;
+            if (split) ml.c[ml.n_classes] = PairClassArgs{k.x1, k.x2, k.y1, k.y2, NP, k.Kp, k.cap, tiles_n, k.off, 0, 1, 2, 0xFFFFFFFFu, 0, 0, 0};
+            else       ml.c[ml.n_classes] = PairClassArgs{k.x1, k.x1, k.y1, k.y1 + (size_t)NP * 8, NP, k.Kp, k.cap, tiles_n, k.off, k.off + NP, 1, 0, 0xFFFFFFFFu, 0, 0, 0};
+            ml.tiles_n_total += tiles_n;
+            if (++ml.n_classes == 8) SSW_TRY(flush());
+        }
+        SSW_TRY(flush());
+    }
+    return SSW_OK;
+}
+
 }  // namespace ssw

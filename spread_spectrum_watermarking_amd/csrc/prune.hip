@@ -41,75 +41,71 @@ __global__ __launch_bounds__(256) void prune_mark_kernel(const uint32_t* __restr
 //   rows[off + j] = basis row of the j-th member (PRUNE_NONE beyond the count)
 //   pos[v]        = compact column of v (PRUNE_NONE when v is not needed or did not fit)
 //   info[0] |= 1 when a class overflows its capacity; info[1 + c] = members of class c
+// The flags become one bit each (LDS, W / 64 words: coalesced loads + ballots); then wave c walks the words for class c with
+// its running count in a register -- no barrier inside the walk.  (r5: the walk was block-wide, three barriers per 1024
+// frequencies and class: 42 us for W = 3840 in front of a single frame's 0.2 ms of pruned row GEMMs.)
 __global__ __launch_bounds__(1024) void prune_build_kernel(const uint32_t* __restrict__ flag, PrunePlan plan,
                                                           uint32_t* __restrict__ rows, uint32_t* __restrict__ pos,
                                                           uint32_t* __restrict__ info) {
-    __shared__ uint32_t wave_sum[16];
-    __shared__ uint32_t base_s;
+    extern __shared__ unsigned long long bits[];                       // (W + 63) / 64 words
     const unsigned t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const unsigned nwords = (plan.W + 63) / 64;
     for (unsigned v = t; v < plan.W; v += 1024) pos[v] = PRUNE_NONE;
     for (unsigned j = t; j < plan.cap_total; j += 1024) rows[j] = PRUNE_NONE;
+    for (unsigned w = wv; w < nwords; w += 16) {
+        const unsigned v = 64 * w + lane;
+        const unsigned long long bal = __ballot(v < plan.W && flag[v] != 0);
+        if (lane == 0) bits[w] = bal;
+    }
     __syncthreads();
-    bool overflow = false;
-    for (unsigned c = 0; c < plan.n_classes; ++c) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (unsigned c = wv; c < plan.n_classes; c += 16) {               // wave-uniform
         const PruneClass pc = plan.c[c];
-        if (t == 0) base_s = 0;
-        __syncthreads();
-        // members of the class in ascending order of v
-        for (unsigned v0 = 0; v0 < plan.W; v0 += 1024) {
-            const unsigned v = v0 + t;
+        unsigned count = 0;
+        for (unsigned w = 0; w < nwords; ++w) {                        // members of the class in ascending order of v
+            const unsigned v = 64 * w + lane;
             const unsigned r = v % pc.mod;
             const bool neg = pc.rem2 != PRUNE_NO_REM && r == pc.rem2;
-            const bool on = v < plan.W && (r == pc.rem || neg) && flag[v] != 0;
+            const bool on = ((bits[w] >> lane) & 1ull) && (r == pc.rem || neg);
             const unsigned long long bal = __ballot(on);
-            const unsigned before = __popcll(bal & ((1ull << lane) - 1ull));
-            if (lane == 0) wave_sum[wv] = __popcll(bal);
-            __syncthreads();
-            unsigned prefix = base_s;
-            for (unsigned q = 0; q < wv; ++q) prefix += wave_sum[q];
             if (on) {
-                const unsigned j = prefix + before;
+                const unsigned j = count + (unsigned)__popcll(bal & below);
                 if (j < pc.cap) {
                     rows[pc.off + j] = ((v + pc.radd) / pc.mod) | (neg ? PRUNE_NEG : 0u);
                     pos[v] = pc.off + j;
                 }
             }
-            __syncthreads();
-            if (t == 0) {
-                unsigned tot = 0;
-                for (unsigned q = 0; q < 16; ++q) tot += wave_sum[q];
-                base_s += tot;
-            }
-            __syncthreads();
+            count += (unsigned)__popcll(bal);
         }
-        if (t == 0) {
-            info[1 + c] = base_s;
-            if (base_s > pc.cap) overflow = true;
+        if (lane == 0) {
+            info[1 + c] = count;
+            if (count > pc.cap) atomicOr(&info[0], 1u);
         }
-        __syncthreads();
     }
-    if (t == 0 && overflow) info[0] = 1u;
 }
 
-// Gathered half basis of one class: dst [Kp / KB][cap][KB] <- rows rows[j] of src [Kp / KB][src_rows][KB], zero
-// rows where rows[j] == PRUNE_NONE.  One thread = one 16-byte piece; k-block pieces are 64 bytes in both precisions.
-__global__ __launch_bounds__(256) void prune_gather_basis_kernel(const uint32_t* __restrict__ rows, unsigned cap,
-                                                                const char* __restrict__ src, unsigned src_rows,
-                                                                unsigned kblocks, char* __restrict__ dst, bool negate) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    const size_t total = (size_t)kblocks * cap * 4;
+// Gathered half bases of the classes of one derived-frame row pass, one launch: job j's dst [Kp / KB][cap][KB] <- rows
+// rows[i] of src [Kp / KB][src_rows][KB], zero rows where rows[i] == PRUNE_NONE.  One thread = one 16-byte piece; k-block
+// pieces are 64 bytes in both precisions.  (r5: one launch per class and basis was sixteen launches of 4.7 us each in front
+// of a single 4K frame's 0.2 ms of row GEMMs.)
+__global__ __launch_bounds__(256) void prune_gather_basis_kernel(const PruneGatherJobs jobs) {
+    unsigned jn = 0;
+    while (jn + 1 < jobs.n && blockIdx.x >= jobs.j[jn + 1].first_block) ++jn;                // block-uniform
+    const PruneGatherJob& job = jobs.j[jn];
+    const size_t i = (blockIdx.x - job.first_block) * (size_t)blockDim.x + threadIdx.x;
+    const size_t total = (size_t)job.kblocks * job.cap * 4;
     if (i >= total) return;
     const unsigned piece = (unsigned)(i & 3);
-    const unsigned j = (unsigned)((i >> 2) % cap);
-    const unsigned kb = (unsigned)((i >> 2) / cap);
-    const uint32_t rf = rows[j];
+    const unsigned r_out = (unsigned)((i >> 2) % job.cap);
+    const unsigned kb = (unsigned)((i >> 2) / job.cap);
+    const uint32_t rf = job.rows[r_out];
     u32x4 v = {0u, 0u, 0u, 0u};
     if (rf != PRUNE_NONE) {
         const uint32_t r = rf & ~PRUNE_NEG;
-        v = *reinterpret_cast<const u32x4*>(src + ((size_t)kb * src_rows + r) * 64 + piece * 16);
-        if (negate && (rf & PRUNE_NEG)) { v[1] ^= 0x80000000u; v[3] ^= 0x80000000u; }      // two doubles: flip the sign bits
+        v = *reinterpret_cast<const u32x4*>(job.src + ((size_t)kb * job.src_rows + r) * 64 + piece * 16);
+        if (job.negate && (rf & PRUNE_NEG)) { v[1] ^= 0x80000000u; v[3] ^= 0x80000000u; }      // two doubles: flip the sign bits
     }
-    *reinterpret_cast<u32x4*>(dst + ((size_t)kb * cap + j) * 64 + piece * 16) = v;
+    *reinterpret_cast<u32x4*>(job.dst + ((size_t)kb * job.cap + r_out) * 64 + piece * 16) = v;
 }
 
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,
@@ -118,17 +114,19 @@ int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, siz
     SSW_HIP_CHECK(hipMemsetAsync(info, 0, SSW_PRUNE_INFO * sizeof(uint32_t), st));
     const size_t count = n_frames * k;
     if (count) prune_mark_kernel<<<(unsigned)((count + 255) / 256), 256, 0, st>>>(idx, count, plan.W, flag);
-    prune_build_kernel<<<1, 1024, 0, st>>>(flag, plan, rows, pos, info);
+    prune_build_kernel<<<1, 1024, ((size_t)plan.W + 63) / 64 * sizeof(unsigned long long), st>>>(flag, plan, rows, pos, info);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }
 
-int launch_prune_gather_basis(hipStream_t st, const uint32_t* rows, unsigned cap, const void* src, size_t src_rows,
-                              size_t kblocks, void* dst, bool negate_flagged_f64) {
-    const size_t total = kblocks * cap * 4;
-    if (total == 0) return SSW_OK;
-    prune_gather_basis_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(rows, cap, (const char*)src, (unsigned)src_rows,
-                                                                                 (unsigned)kblocks, (char*)dst, negate_flagged_f64);
+int launch_prune_gather_bases(hipStream_t st, PruneGatherJobs jobs) {
+    unsigned blocks = 0;
+    for (unsigned j = 0; j < jobs.n; ++j) {
+        jobs.j[j].first_block = blocks;
+        blocks += (unsigned)(((size_t)jobs.j[j].kblocks * jobs.j[j].cap * 4 + 255) / 256);
+    }
+    if (blocks == 0) return SSW_OK;
+    prune_gather_basis_kernel<<<blocks, 256, 0, st>>>(jobs);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

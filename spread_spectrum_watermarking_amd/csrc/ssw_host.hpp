@@ -125,8 +125,8 @@ bool can_fuse_rgb(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float*
 // rgb -> Y (+ I, Q) -> forward transform of Y into `y` (Writer::new / Reader::new_impl), fused where possible
 int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, int u8, size_t n, size_t w,
                            size_t h, float* y, float* i, float* q, float* tmp, Chain& ch);
-// the same transform as two chains: the row pass of a band of image rows, and the column pass of the whole frame
-bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, int u8);
+// the same transform as bands + 1 chains: the row pass of a band of image rows (h / bands of them), and the column pass of the whole frame
+bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, size_t bands, const float* y, const float* tmp, const void* rgb, int u8);
 int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, int u8, size_t w, size_t rows,
                             size_t frame_h, float* tmp, float* i, float* q, Chain& ch);
 int build_forward_cols_after_rows(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, size_t w, size_t h, float* tmp, float* y, Chain& ch);

@@ -148,13 +148,21 @@ int launch_dct_pair_gemm_rows_subset_f64(hipStream_t st, const double* x, const 
                                          unsigned out_stride, unsigned off, size_t lines);
 int launch_dct_pair_gemm_rows_subset_split_f64(hipStream_t st, const double* x1, const double* x2, const double* y1, const double* y2,
                                                unsigned cap, unsigned Kp, float* out, unsigned out_stride, unsigned off, size_t lines);
+// the classes of a small pruned row pass in one or two launches (x2 == nullptr: y1 holds cap gathered rows, pairs j / j + cap/2;
+// else a class of the split odd half: y1 / y2 the gathered cosine / sine rows)
+struct PairSubsetClass {
+    const double *x1, *x2, *y1, *y2;
+    unsigned cap, Kp, off;
+};
+int launch_dct_pair_gemm_rows_subset_merged_f64(hipStream_t st, const PairSubsetClass* classes, unsigned n_classes, float* out,
+                                                unsigned out_stride, size_t lines);
 // split odd half (f64 only; dct_pair_prep.hip "Split odd half"): quarter-length cosine / sine bases (which: 0 cosE, 1 sinE,
 // 2 cosO, 3 sinO), the rotation table of an axis, and the pass that turns an odd operand plane into AS | BD | AD | BS
 bool dct_pair_can_split(size_t len, bool is_row);
 size_t dct_pair_split_kpad(size_t len);
 // tuning.hip: the process-wide table of strategy thresholds / A-B switches (ssw_tuning_set, include/ssw.h)
 enum { TUNE_EFOLD_MIN, TUNE_EFOLD_INV_MIN, TUNE_EFOLD_COLS_MIN, TUNE_CLASS_TILE, TUNE_DEEP_MIN_ROWS, TUNE_DEEP_MIN_COLS, TUNE_PREP_STAGED,
-       TUNE_MERGE_MAX_LINES, TUNE_BN32, TUNE_BAND_SPLIT, TUNE_FUSE_COLS, TUNE_FUSE_INV_COLS, TUNE_COUNT };
+       TUNE_MERGE_MAX_LINES, TUNE_BN32, TUNE_BAND_SPLIT, TUNE_FUSE_COLS, TUNE_FUSE_INV_COLS, TUNE_UPLOAD_BANDS, TUNE_SPECULATE_K, TUNE_COUNT };
 long long tuning(int which);
 unsigned dct_pair_class_tile(size_t len);               // tile width of the class-major plane orders (dct_pair_common.hpp)
 bool dct_pair_efold(size_t len);                        // forward row passes of this length run at level 2 (r4b)
@@ -221,8 +229,20 @@ struct PrunePlan {
 static_assert(SSW_PRUNE_INFO >= 1 + sizeof(PrunePlan::c) / sizeof(PruneClass), "a chunk's info block holds the flag and one count per class");
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,
                        uint32_t* flag /*[W]*/, uint32_t* rows /*[cap_total]*/, uint32_t* pos /*[W]*/, uint32_t* info /*[SSW_PRUNE_INFO]*/);
-int launch_prune_gather_basis(hipStream_t st, const uint32_t* rows, unsigned cap, const void* src, size_t src_rows,
-                              size_t kblocks, void* dst, bool negate_flagged_f64 = false);
+// one gathered basis: rows[] of `src` ([kblocks][src_rows] 64-byte pieces) into `dst` ([kblocks][cap]); `negate`: rows flagged
+// PRUNE_NEG change sign (f64 sine rows)
+struct PruneGatherJob {
+    const uint32_t* rows;
+    const char* src;
+    char* dst;
+    unsigned cap, src_rows, kblocks, first_block;
+    bool negate;
+};
+struct PruneGatherJobs {
+    PruneGatherJob j[18];
+    unsigned n;
+};
+int launch_prune_gather_bases(hipStream_t st, PruneGatherJobs jobs);
 int launch_extract_pruned(hipStream_t st, const float* base, const float* compact, size_t n_frames, size_t w, size_t h,
                           size_t cap, const uint32_t* pos, const uint32_t* indices, size_t k, int method, float alpha,
                           float* out);
@@ -338,13 +358,14 @@ struct ssw_ctx {
     hipStream_t copy_stream = nullptr;
     struct FrameStage {
         Buf buf;
-        hipEvent_t uploaded = nullptr;    // copy_stream: the frame (or its top half) is in the buffer
-        hipEvent_t uploaded2 = nullptr;   // copy_stream: the bottom half (frames uploaded in two bands)
+        static constexpr int MAX_BANDS = 4;
+        hipEvent_t uploaded[MAX_BANDS] = {nullptr, nullptr, nullptr, nullptr};   // copy_stream: band b of the frame (the whole frame: [0]) is in the buffer
         hipEvent_t consumed = nullptr;    // stream: the last kernel that reads (or writes) the buffer is enqueued before
         bool in_use = false;              // `consumed` has been recorded at least once
     };
     FrameStage frame_stage[2];
     unsigned frame_stage_next = 0;
+    size_t expected_k = 0;                // mark length of the context's last Reader::extract / indices (speculative selection of the next base reader)
     // device planes of destroyed handles, kept for the next handle of the same size (hipMalloc + hipFree of
     // three 4K planes cost more than the transform); all reuse is ordered on the context's stream
     std::multimap<size_t, void*> plane_pool;

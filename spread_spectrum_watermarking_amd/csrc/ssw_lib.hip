@@ -31,8 +31,8 @@ struct ssw_writer {
     size_t idx_k = 0;
     bool consumed = false;
     // host staging of embed(): lives as long as the handle, so the copies need no host synchronisation
-    std::vector<float> packed;
-    std::vector<uint32_t> offs, lns;
+    // (one block: the marks, 16-byte padded, then the offset and length tables -- one copy instead of three)
+    std::vector<uint32_t> blob;
     bool staging_in_flight = false;
 };
 struct ssw_reader {
@@ -89,8 +89,8 @@ void pool_put(ssw_ctx* ctx, void* p, size_t bytes) {
 
 // ---- frames in and out of the device ------------------------------------------------------------
 int frame_stage_events(ssw_ctx::FrameStage& fs) {
-    if (!fs.uploaded) SSW_HIP_CHECK(hipEventCreateWithFlags(&fs.uploaded, hipEventDisableTiming));
-    if (!fs.uploaded2) SSW_HIP_CHECK(hipEventCreateWithFlags(&fs.uploaded2, hipEventDisableTiming));
+    for (hipEvent_t& e : fs.uploaded)
+        if (!e) SSW_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (!fs.consumed) SSW_HIP_CHECK(hipEventCreateWithFlags(&fs.consumed, hipEventDisableTiming));
     return SSW_OK;
 }
@@ -102,8 +102,8 @@ int stage_frame_in(ssw_ctx* ctx, const void* host, size_t bytes, ssw_ctx::FrameS
     SSW_TRY(grow(fs.buf, bytes));
     if (fs.in_use) SSW_HIP_CHECK(hipStreamWaitEvent(ctx->copy_stream, fs.consumed, 0));
     SSW_TRY(upload(ctx, fs.buf.p, host, bytes, ctx->copy_stream));
-    SSW_HIP_CHECK(hipEventRecord(fs.uploaded, ctx->copy_stream));
-    SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, fs.uploaded, 0));
+    SSW_HIP_CHECK(hipEventRecord(fs.uploaded[0], ctx->copy_stream));
+    SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, fs.uploaded[0], 0));
     *out = &fs;
     return SSW_OK;
 }
@@ -122,31 +122,46 @@ int forward_from_host(ssw_ctx* ctx, const void* host_rgb, int u8, size_t w, size
     SSW_TRY(grow(ctx->lane[0].plane[3], plane * sizeof(float)));
     float* tmp = (float*)ctx->lane[0].plane[3].p;
     {
-        // Two bands: the row pass of the top half of the frame runs while the bottom half is still crossing PCIe
-        // (image rows are independent lines of a row pass: same values), then the column pass of the whole frame.
+        // Bands of image rows (two to four, `upload_bands`): the row pass of a band runs while the next ones are still
+        // crossing PCIe (image rows are independent lines of a row pass: same values), then the column pass of the whole
+        // frame.  Pinned frames: every copy is enqueued before the first kernel, the kernels wait on the bands' events,
+        // and the host waits once, at the end, for the last copy (the caller's buffer is the DMA source) -- a wait per
+        // band left the link idle for ~30 us between the bands.
         ssw_ctx::FrameStage& fs = ctx->frame_stage[ctx->frame_stage_next & 1];
         SSW_TRY(grow(fs.buf, bytes));
         const bool no_split = tuning(TUNE_BAND_SPLIT) == 0;                     // A/B switch (tuning.hip)
+        long long nb = tuning(TUNE_UPLOAD_BANDS);
+        nb = nb < 2 ? 2 : nb > ssw_ctx::FrameStage::MAX_BANDS ? ssw_ctx::FrameStage::MAX_BANDS : nb;
+        while (nb > 2 && ((bytes / nb) % 16 != 0 || !can_split_forward_rows(ctx, precision == SSW_PRECISION_F64, w, h, (size_t)nb, y, tmp, fs.buf.p, u8))) --nb;
         if (!no_split && bytes >= ((size_t)8 << 20) &&
-            can_split_forward_rows(ctx, precision == SSW_PRECISION_F64, w, h, y, tmp, fs.buf.p, u8)) {
+            can_split_forward_rows(ctx, precision == SSW_PRECISION_F64, w, h, (size_t)nb, y, tmp, fs.buf.p, u8)) {
             ++ctx->frame_stage_next;
             SSW_TRY(frame_stage_events(fs));
             if (fs.in_use) SSW_HIP_CHECK(hipStreamWaitEvent(ctx->copy_stream, fs.consumed, 0));
-            const size_t hb = bytes / 2, hp = plane / 2;
-            for (int band = 0; band < 2; ++band) {
-                hipEvent_t ev = band ? fs.uploaded2 : fs.uploaded;
-                SSW_TRY(upload(ctx, (char*)fs.buf.p + band * hb, (const char*)host_rgb + band * hb, hb, ctx->copy_stream));
-                SSW_HIP_CHECK(hipEventRecord(ev, ctx->copy_stream));
-                SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
+            const size_t hb = bytes / nb, hp = plane / nb, rows = h / nb;
+            bool in_flight = false;
+            int rc = SSW_OK;
+            for (int band = 0; band < (int)nb && rc == SSW_OK; ++band) {
+                bool async = false;
+                rc = upload_nowait(ctx, (char*)fs.buf.p + band * hb, (const char*)host_rgb + band * hb, hb, ctx->copy_stream, &async);
+                in_flight = in_flight || async;
+                if (rc == SSW_OK && hipEventRecord(fs.uploaded[band], ctx->copy_stream) != hipSuccess) rc = SSW_ERR_HIP;
+                if (rc == SSW_OK && hipStreamWaitEvent(ctx->stream, fs.uploaded[band], 0) != hipSuccess) rc = SSW_ERR_HIP;
+                if (rc != SSW_OK) break;
                 Chain ch;
-                SSW_TRY(build_forward_rows_band(ctx, ctx->lane[0], precision, (char*)fs.buf.p + band * hb, u8, w, h / 2, h, tmp + band * hp,
-                                                i ? i + band * hp : nullptr, q ? q + band * hp : nullptr, ch));
-                SSW_TRY(run_serial(ch, ctx->stream));
+                rc = build_forward_rows_band(ctx, ctx->lane[0], precision, (char*)fs.buf.p + band * hb, u8, w, rows, h, tmp + band * hp,
+                                             i ? i + band * hp : nullptr, q ? q + band * hp : nullptr, ch);
+                if (rc == SSW_OK) rc = run_serial(ch, ctx->stream);
             }
-            SSW_TRY(stage_consumed(ctx, fs));
-            Chain ch;
-            SSW_TRY(build_forward_cols_after_rows(ctx, ctx->lane[0], precision, w, h, tmp, y, ch));
-            return run_serial(ch, ctx->stream);
+            if (rc == SSW_OK) rc = stage_consumed(ctx, fs);
+            if (rc == SSW_OK) {
+                Chain ch;
+                rc = build_forward_cols_after_rows(ctx, ctx->lane[0], precision, w, h, tmp, y, ch);
+                if (rc == SSW_OK) rc = run_serial(ch, ctx->stream);
+            }
+            // the caller's buffer is the source of the copies still in flight: wait for them on every path out
+            if (in_flight && hipStreamSynchronize(ctx->copy_stream) != hipSuccess && rc == SSW_OK) rc = SSW_ERR_HIP;
+            return rc;
         }
     }
     ssw_ctx::FrameStage* fs = nullptr;
@@ -284,8 +299,8 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);
     for (auto& fs : ctx->frame_stage) {
         release(fs.buf);
-        if (fs.uploaded) (void)hipEventDestroy(fs.uploaded);
-        if (fs.uploaded2) (void)hipEventDestroy(fs.uploaded2);
+        for (hipEvent_t e : fs.uploaded)
+            if (e) (void)hipEventDestroy(e);
         if (fs.consumed) (void)hipEventDestroy(fs.consumed);
     }
     for (auto& kv : ctx->basis) (void)hipFree(kv.second);
@@ -799,25 +814,27 @@ static int writer_embed_impl(ssw_writer* wr, const float* const* marks, const si
         wr->staging_in_flight = false;
     }
     // zip(indices, mark) truncates every mark at w*h-1 entries (:396, :402)
-    wr->offs.assign(n_marks, 0);
-    wr->lns.assign(n_marks, 0);
     size_t total = 0, max_len = 0;
     for (size_t m = 0; m < n_marks; ++m) {
         const size_t len = std::min(lens[m], plane - 1);
-        wr->offs[m] = (uint32_t)total; wr->lns[m] = (uint32_t)len;
         total += len; max_len = std::max(max_len, len);
     }
     if (max_len == 0) return SSW_OK;
-    wr->packed.resize(total);
-    for (size_t m = 0; m < n_marks; ++m)
-        if (wr->lns[m]) std::memcpy(wr->packed.data() + wr->offs[m], marks[m], wr->lns[m] * sizeof(float));
     const size_t bytes_marks = (total * 4 + 15) / 16 * 16, bytes_tab = (n_marks * 4 + 15) / 16 * 16;
+    wr->blob.assign((bytes_marks + 2 * bytes_tab) / 4, 0u);
+    uint32_t* offs = wr->blob.data() + bytes_marks / 4;
+    uint32_t* lns = offs + bytes_tab / 4;
+    size_t at = 0;
+    for (size_t m = 0; m < n_marks; ++m) {
+        const size_t len = std::min(lens[m], plane - 1);
+        offs[m] = (uint32_t)at; lns[m] = (uint32_t)len;
+        if (len) std::memcpy(wr->blob.data() + at, marks[m], len * sizeof(float));
+        at += len;
+    }
     SSW_TRY(grow(ctx->small, bytes_marks + 2 * bytes_tab));
     char* base = (char*)ctx->small.p;
-    // the host vectors belong to the handle and stay until it is destroyed: no host synchronisation here
-    SSW_HIP_CHECK(hipMemcpyAsync(base, wr->packed.data(), total * 4, hipMemcpyHostToDevice, ctx->stream));
-    SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks, wr->offs.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
-    SSW_HIP_CHECK(hipMemcpyAsync(base + bytes_marks + bytes_tab, wr->lns.data(), n_marks * 4, hipMemcpyHostToDevice, ctx->stream));
+    // the host vector belongs to the handle and stays until it is destroyed: no host synchronisation here
+    SSW_HIP_CHECK(hipMemcpyAsync(base, wr->blob.data(), bytes_marks + 2 * bytes_tab, hipMemcpyHostToDevice, ctx->stream));
     wr->staging_in_flight = true;
     if (keep_original && !wr->y0) {
         SSW_TRY(pool_get(ctx, plane * sizeof(float), (void**)&wr->y0));
@@ -908,6 +925,7 @@ int ssw_writer_destroy(ssw_writer* wr) {
 }
 
 // ---- Reader ---------------------------------------------------------------------------------
+static int reader_ensure_indices(ssw_reader* rd, size_t k);
 static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, int u8, size_t w, size_t h, int is_base,
                               const ssw_config* cfg, ssw_reader** out) {
     if (!ctx || !rgb_hwc || !out) return SSW_ERR_BAD_ARG;
@@ -943,6 +961,11 @@ static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, int u8, size_t 
     if (pool_get(ctx, plane * 4, (void**)&rd->y) != SSW_OK) return fail(SSW_ERR_OUT_OF_MEMORY);
     const int rc = forward_from_host(ctx, rgb_hwc, u8, w, h, c.precision, rd->y, nullptr, nullptr);   // :476-480
     if (rc != SSW_OK) return fail(rc);
+    // The ordering is the reader's (:493) but its length is only known at extract(): queue it now for the length the
+    // context's last extraction used, so that it runs while the derived frame is still crossing PCIe instead of after it
+    // (a list that turns out too short is redone at extract(); a longer one serves as it is).
+    if (is_base && ctx->expected_k && ctx->expected_k <= plane - 1 && ctx->expected_k <= select_max_k() && tuning(TUNE_SPECULATE_K))
+        (void)reader_ensure_indices(rd, ctx->expected_k);
     *out = rd;
     return SSW_OK;
 }
@@ -1015,6 +1038,7 @@ int ssw_reader_indices(ssw_reader* rd, size_t k, uint64_t* out) {
     if (k == 0) return rd->is_base ? SSW_OK : SSW_ERR_NOT_BASE;
     SSW_TRY(reader_ensure_indices(rd, k));
     ssw_ctx* ctx = rd->ctx;
+    ctx->expected_k = k;
     SSW_TRY(grow(ctx->small, k * sizeof(uint64_t)));
     SSW_TRY(launch_widen_indices(ctx->stream, rd->idx, k, (uint64_t*)ctx->small.p));
     return ssw_copy_to_host(ctx, out, ctx->small.p, k * sizeof(uint64_t));
@@ -1031,6 +1055,7 @@ int ssw_reader_extract(ssw_reader* base, ssw_reader* derived, float* out, size_t
     ssw_ctx* ctx = base->ctx;
     CtxGuard g(ctx);
     SSW_TRY(reader_ensure_indices(base, k));
+    ctx->expected_k = k;
     SSW_TRY(grow(ctx->small, k * sizeof(float)));
     if (!derived->y && derived->w == base->w && derived->h == base->h) {
         // the derived frame is still RGB: transform it only where the first k indices of the base reader read it

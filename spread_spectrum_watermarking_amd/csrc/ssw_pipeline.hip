@@ -981,8 +981,9 @@ int build_forward_from_rgb(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const
 // of the top half of a frame runs while the bottom half is still crossing PCIe -- image rows are independent lines
 // of a row pass, so any band of rows gives the values the whole frame gives).  `rows` consecutive image rows starting
 // at `rgb` -> the same rows of the intermediate plane `tmp` (+ I, Q); then the column pass tmp -> y on the whole frame.
-bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, const float* y, const float* tmp, const void* rgb, int u8) {
-    return w >= h && h % 16 == 0 && can_fuse_rgb(ctx, f64, w, h, y, tmp, rgb, u8) && can_fuse_rgb(ctx, f64, w, h / 2, y, tmp, rgb, u8);
+bool can_split_forward_rows(const ssw_ctx* ctx, bool f64, size_t w, size_t h, size_t bands, const float* y, const float* tmp, const void* rgb, int u8) {
+    return bands >= 2 && w >= h && h % 16 == 0 && h % bands == 0 && can_fuse_rgb(ctx, f64, w, h, y, tmp, rgb, u8) &&
+           can_fuse_rgb(ctx, f64, w, h / bands, y, tmp, rgb, u8);
 }
 int build_forward_rows_band(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const void* rgb, int u8, size_t w, size_t rows,
                             size_t frame_h, float* tmp, float* i, float* q, Chain& ch) {
@@ -1323,14 +1324,23 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     double flop = 0.0;
     for (unsigned c = 0; c < plan.n_classes; ++c) flop += (cs[c].x2 ? 4.0 : 2.0) * (double)lines * plan.c[c].cap * (double)cs[c].ktrue;
     ch.push_back({false, [=](hipStream_t st) -> int {
+        PruneGatherJobs jobs;
+        jobs.n = 0;
         for (unsigned c = 0; c < plan.n_classes; ++c) {
-            SSW_TRY(launch_prune_gather_basis(st, rows + plan.c[c].off, plan.c[c].cap, cs[c].basis, cs[c].src_rows,
-                                              cs[c].kp / (64 / esz), gathered + goff[c]));
-            if (cs[c].x2) SSW_TRY(launch_prune_gather_basis(st, rows + plan.c[c].off, plan.c[c].cap, cs[c].basis2, cs[c].src_rows,
-                                                            cs[c].kp / (64 / esz), gathered + goff2[c], true));
+            const unsigned kblocks = (unsigned)(cs[c].kp / (64 / esz));
+            jobs.j[jobs.n++] = {rows + plan.c[c].off, (const char*)cs[c].basis, gathered + goff[c], plan.c[c].cap, (unsigned)cs[c].src_rows, kblocks, 0u, false};
+            if (cs[c].x2) jobs.j[jobs.n++] = {rows + plan.c[c].off, (const char*)cs[c].basis2, gathered + goff2[c], plan.c[c].cap, (unsigned)cs[c].src_rows, kblocks, 0u, true};
         }
+        SSW_TRY(launch_prune_gather_bases(st, jobs));
         StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
         t.traffic(px * (double)esz + (double)lines * (double)cap * 4.0);      // every operand plane once in, the compact plane out
+        if (f64 && lines <= (size_t)tuning(TUNE_MERGE_MAX_LINES)) {          // a single frame: the classes side by side in one launch per kind
+            PairSubsetClass sc[9];
+            for (unsigned c = 0; c < plan.n_classes; ++c)
+                sc[c] = {(const double*)cs[c].x, (const double*)cs[c].x2, (const double*)(gathered + goff[c]),
+                         cs[c].x2 ? (const double*)(gathered + goff2[c]) : nullptr, plan.c[c].cap, (unsigned)cs[c].kp, plan.c[c].off};
+            return launch_dct_pair_gemm_rows_subset_merged_f64(st, sc, plan.n_classes, t_compact, (unsigned)cap, lines);
+        }
         for (unsigned c = 0; c < plan.n_classes; ++c) {
             if (cs[c].x2) SSW_TRY(launch_dct_pair_gemm_rows_subset_split_f64(st, (const double*)cs[c].x, (const double*)cs[c].x2, (const double*)(gathered + goff[c]),
                                                                              (const double*)(gathered + goff2[c]), plan.c[c].cap, (unsigned)cs[c].kp, t_compact,

@@ -33,6 +33,8 @@ Entry g_tune[TUNE_COUNT] = {
     {"band_split", "SSW_BAND_SPLIT", 1},               // single-image handles: row pass of the top half beside the upload of the bottom half
     {"fuse_cols", "SSW_FUSE_COLS", 1},                 // forward: column operands straight from the row GEMMs' epilogue (r5)
     {"fuse_inv_cols", "SSW_FUSE_INV_COLS", 0},         // inverse: the same (r5; bit-identical, measured no faster: off by default)
+    {"upload_bands", "SSW_UPLOAD_BANDS", 3},           // single-image handles: bands of rows a host frame is uploaded and row-transformed in (2 .. 4)
+    {"speculate_k", "SSW_SPECULATE_K", 1},             // Reader::base queues the selection for the context's last extraction length
 };
 
 }  // namespace

@@ -807,6 +807,51 @@ def test_4k_bench_configuration_equals_handles_and_oracle():
         _frame_vs_oracle(rgb[f], marks[f], None, res["idx"][f], res["rgb"][f], ext[f], sims[f])
 
 
+@pytest.mark.parametrize("case", [(3840, 2160, True), (1920, 1080, False)])
+def test_handle_latency_options_do_not_change_results(case):
+    """What the single-image handles do for latency only (r5): the host frame crosses PCIe in two to four bands of rows with
+    the row pass of a band beside the upload of the next (`upload_bands`; every copy enqueued ahead of the kernels), a base
+    reader queues its selection for the mark length the context's last extraction used (`speculate_k`), a single frame's
+    pruned derived transform runs its classes in one launch per kind.  Same marked frame, index lists and extracted marks
+    whatever the options, for extraction lengths shorter and longer than the speculated one; against the batch entry points
+    (no bands, no speculation, unmerged for eight frames) bit for bit.  Reference flow: src/algorithm.rs:295-379, :462-562."""
+    from spread_spectrum_watermarking_amd.api import tuning
+    w, h, as_u8 = case
+    rgb = G.synth(7, 0, 1, w, h)[0]
+    img = f32_to_u8(rgb) if as_u8 else rgb
+    mark = np.random.default_rng(43).standard_normal(2000).astype(np.float32)
+    ks = (1000, 500, 2000, 1000)
+
+    def run():
+        c = G.ctx()
+        marked = wm.Writer(img, ctx=c).mark_rgb8([mark[:1000]]) if as_u8 else wm.Writer(img, ctx=c).mark([mark[:1000]])
+        out = [marked]
+        for k in ks:                                              # the second base reader on speculates k = 1000, then 500, 2000
+            rd = wm.Reader.base(img, ctx=c)
+            out.append(rd.extract(wm.Reader.derived(marked, c), k))
+            out.append(rd.indices(k))
+        return out
+    with tuning(upload_bands=2, speculate_k=0):
+        ref = run()
+    for bands, spec in ((2, 1), (3, 1), (4, 0), (4, 1)):
+        with tuning(upload_bands=bands, speculate_k=spec):
+            got = run()
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b), (bands, spec)
+    # the batch entry points on the same frame
+    if as_u8:
+        marked = G.batch_embed_rgb8(img[None], mark[None, :1000])
+        assert np.array_equal(marked[0], ref[0])
+        ext, _ = G.batch_extract_rgb8(img[None], marked, 1000, mark[None, :1000])
+        assert np.array_equal(ext[0], ref[1])
+    else:
+        res = G.batch_embed(rgb[None], mark[None, :1000], want_idx=True)
+        assert np.array_equal(res["rgb"][0], ref[0])
+        assert np.array_equal(res["idx"][0], ref[2].astype(np.uint32))
+        ext, _ = G.batch_extract(rgb[None], res["rgb"], 1000, mark[None, :1000])
+        assert np.array_equal(ext[0], ref[1])
+
+
 def _mirror_tile(img_u8, w, h):
     """A natural image mirror-tiled (no seams: every tile is the reflection of its neighbour) and cropped to w x h."""
     ih, iw = img_u8.shape[:2]
