@@ -370,6 +370,11 @@ struct ssw_ctx {
     // three 4K planes cost more than the transform); all reuse is ordered on the context's stream
     std::multimap<size_t, void*> plane_pool;
     size_t plane_pool_bytes = 0;
+    // RGB staging buffers of derived readers (filled on `copy_stream`, read on `stream`): kept apart with the event that
+    // says when their last reader was done, so that the next derived frame's upload waits for THAT and not for everything
+    // the context's stream holds (a base reader's transform queued a moment ago)
+    struct RgbSpare { void* p; size_t bytes; hipEvent_t released; };
+    std::vector<RgbSpare> rgb_spares;
     // workspace buffers that grew while a chain of stages was being built: stages built earlier captured the old pointer, so
     // the old allocation stays valid until the next entry into the library frees it (grow(), CtxGuard; r5)
     std::vector<void*> retired;

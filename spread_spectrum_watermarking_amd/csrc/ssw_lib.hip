@@ -87,6 +87,31 @@ void pool_put(ssw_ctx* ctx, void* p, size_t bytes) {
     ctx->plane_pool_bytes += bytes;
 }
 
+// Derived readers' RGB staging (ssw_ctx::rgb_spares).  take: a spare of that size with its event -- the caller makes the copy
+// stream wait on it; none: a pooled / fresh buffer and a new event, and the caller orders the copy behind the whole stream.
+constexpr size_t RGB_SPARES_MAX = 4;
+int rgb_spare_take(ssw_ctx* ctx, size_t bytes, void** p, hipEvent_t* ev, bool* fenced) {
+    for (size_t i = 0; i < ctx->rgb_spares.size(); ++i)
+        if (ctx->rgb_spares[i].bytes == bytes) {
+            *p = ctx->rgb_spares[i].p; *ev = ctx->rgb_spares[i].released; *fenced = true;
+            ctx->rgb_spares.erase(ctx->rgb_spares.begin() + (long)i);
+            return SSW_OK;
+        }
+    *fenced = false;
+    SSW_TRY(pool_get(ctx, bytes, p));
+    if (hipEventCreateWithFlags(ev, hipEventDisableTiming) != hipSuccess) { pool_put(ctx, *p, bytes); *p = nullptr; return SSW_ERR_HIP; }
+    return SSW_OK;
+}
+// the last kernel that reads the buffer is enqueued on the context's stream: mark the point and keep the pair
+void rgb_spare_give(ssw_ctx* ctx, void* p, size_t bytes, hipEvent_t ev) {
+    if (!p) { if (ev) (void)hipEventDestroy(ev); return; }
+    if (ev && ctx->rgb_spares.size() < RGB_SPARES_MAX && hipEventRecord(ev, ctx->stream) == hipSuccess) {
+        ctx->rgb_spares.push_back({p, bytes, ev});
+        return;
+    }
+    if (ev) (void)hipEventDestroy(ev);
+    pool_put(ctx, p, bytes);
+}
 // ---- frames in and out of the device ------------------------------------------------------------
 int frame_stage_events(ssw_ctx::FrameStage& fs) {
     for (hipEvent_t& e : fs.uploaded)
@@ -296,7 +321,7 @@ int ssw_ctx_destroy(ssw_ctx* ctx) {
     release(ctx->hs.marks); release(ctx->hs.ext); release(ctx->hs.sims);
     for (void* p : ctx->retired) (void)hipFree(p);
     ctx->retired.clear();
-    for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);
+    (void)plane_pool_flush(ctx);
     for (auto& fs : ctx->frame_stage) {
         release(fs.buf);
         for (hipEvent_t e : fs.uploaded)
@@ -946,11 +971,13 @@ static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, int u8, size_t 
         // upload only; transformed on first use (see ssw_reader)
         const size_t bytes = plane * 3 * pix_bytes(u8);
         rd->rgb_u8 = u8;
-        if (pool_get(ctx, bytes, &rd->rgb) != SSW_OK) return fail(SSW_ERR_OUT_OF_MEMORY);
-        if (hipEventCreateWithFlags(&rd->rgb_uploaded, hipEventDisableTiming) != hipSuccess) return fail(SSW_ERR_HIP);
-        // the buffer may have been handed back by a handle whose last kernels are still queued on the context's stream
-        if (hipEventRecord(rd->rgb_uploaded, ctx->stream) != hipSuccess ||
-            hipStreamWaitEvent(ctx->copy_stream, rd->rgb_uploaded, 0) != hipSuccess) return fail(SSW_ERR_HIP);
+        bool fenced = false;
+        const int rt = rgb_spare_take(ctx, bytes, &rd->rgb, &rd->rgb_uploaded, &fenced);
+        if (rt != SSW_OK) return fail(rt);
+        // a spare carries the point of the stream at which its previous reader was done with it; any other buffer may have
+        // been handed back by a handle whose last kernels are still queued on the context's stream: behind all of it
+        if (!fenced && hipEventRecord(rd->rgb_uploaded, ctx->stream) != hipSuccess) return fail(SSW_ERR_HIP);
+        if (hipStreamWaitEvent(ctx->copy_stream, rd->rgb_uploaded, 0) != hipSuccess) return fail(SSW_ERR_HIP);
         int rc = upload(ctx, rd->rgb, rgb_hwc, bytes, ctx->copy_stream);
         if (rc != SSW_OK) return fail(rc);
         if (hipEventRecord(rd->rgb_uploaded, ctx->copy_stream) != hipSuccess ||
@@ -989,8 +1016,9 @@ static int reader_ensure_coefficients(ssw_reader* rd) {
     const int rc = run();
     if (rc != SSW_OK) { pool_put(ctx, y, plane * 4); return rc; }
     rd->y = y;
-    pool_put(ctx, rd->rgb, plane * 3 * pix_bytes(rd->rgb_u8));      // reuse is ordered on the stream
+    rgb_spare_give(ctx, rd->rgb, plane * 3 * pix_bytes(rd->rgb_u8), rd->rgb_uploaded);      // reuse is ordered behind this point of the stream
     rd->rgb = nullptr;
+    rd->rgb_uploaded = nullptr;
     return SSW_OK;
 }
 
@@ -1086,8 +1114,7 @@ int ssw_reader_destroy(ssw_reader* rd) {
     CtxGuard g(ctx);
     pool_put(ctx, rd->y, rd->w * rd->h * 4);
     pool_put(ctx, rd->idx, rd->idx_k * sizeof(uint32_t));
-    pool_put(ctx, rd->rgb, rd->w * rd->h * 3 * pix_bytes(rd->rgb_u8));
-    if (rd->rgb_uploaded) (void)hipEventDestroy(rd->rgb_uploaded);
+    rgb_spare_give(ctx, rd->rgb, rd->w * rd->h * 3 * pix_bytes(rd->rgb_u8), rd->rgb_uploaded);
     delete rd;
     return SSW_OK;
 }

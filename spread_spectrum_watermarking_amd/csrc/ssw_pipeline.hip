@@ -35,10 +35,12 @@ CtxGuard::CtxGuard(ssw_ctx* ctx) : dg(ctx->device), prev(tl_ctx) {
 CtxGuard::~CtxGuard() { tl_ctx = prev; }
 
 size_t plane_pool_flush(ssw_ctx* ctx) {
-    const size_t bytes = ctx->plane_pool_bytes;
+    size_t bytes = ctx->plane_pool_bytes;
     for (auto& kv : ctx->plane_pool) (void)hipFree(kv.second);
     ctx->plane_pool.clear();
     ctx->plane_pool_bytes = 0;
+    for (auto& sp : ctx->rgb_spares) { (void)hipFree(sp.p); (void)hipEventDestroy(sp.released); bytes += sp.bytes; }
+    ctx->rgb_spares.clear();
     return bytes;
 }
 
@@ -59,7 +61,7 @@ int dev_malloc(void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes ? bytes : 16);
     if (e == hipSuccess) return SSW_OK;
     (void)hipGetLastError();
-    if (tl_ctx && !tl_ctx->plane_pool.empty()) {                   // spare planes of destroyed handles: give them back first
+    if (tl_ctx && (!tl_ctx->plane_pool.empty() || !tl_ctx->rgb_spares.empty())) {      // spare planes of destroyed handles: give them back first
         (void)plane_pool_flush(tl_ctx);
         e = hipMalloc(p, bytes ? bytes : 16);
         if (e == hipSuccess) return SSW_OK;
