@@ -53,5 +53,10 @@ struct DeepPlanes {        // device pointers of one pass's operand planes
     void *r1p = nullptr, *r1m = nullptr, *r2a = nullptr, *r2b = nullptr;
 };
 
+// dct_pair_prep_light.hip: the level-2 row pre-pass in the form that fits beside the GEMMs
+bool dct_pair_prep_light_ok(size_t w, size_t lines);
+int launch_dct_pair_prep16_rows_light(hipStream_t st, int src_kind, const void* src, const DeepPlanes& dp, const double* rot1,
+                                      const double* rot2, const double* rot3, float* ip, float* qp, size_t rows, size_t w, unsigned K16,
+                                      unsigned unit_h, unsigned unit_hup);
 
 }  // namespace ssw

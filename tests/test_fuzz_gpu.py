@@ -61,6 +61,19 @@ def test_fused_forward_transform_equals_the_unfused_one():
     assert lines[-1] == "fused forward transform: all good"
 
 
+def test_light_row_prepass_is_bit_identical_to_the_register_resident_one():
+    """r5: the level-2 row pre-pass in the form that fits beside the GEMMs (csrc/dct_pair_prep_light.hip: runs of pixels
+    through LDS, one lane per unit, < 64 VGPRs) against pair_prep16_rows_kernel (prep_light = 0) -- whole batch pipelines from
+    f32 / 8-bit / 16-bit frames (I and Q written for the writer), natural and unit line order, partial tiles of units, plain
+    planes: tools/prep_light_check.py."""
+    import prep_light_check
+    lines = []
+    bad = prep_light_check.run(lines.append, batch=[(2160, 3840, 8, 1000), (2160, 3840, 3, 500), (1080, 1920, 5, 500), (272, 512, 40, 100),
+                                                   (144, 1088, 9, 64)], planes=[(272, 576, 30), (1088, 2048, 9)])
+    assert bad == 0, "\n".join(l for l in lines if "FAIL" in l)
+    assert lines[-1] == "light row pre-pass: all good"
+
+
 def test_transform_plan_reports_the_default_path():
     """ssw_ctx_transform_plan (include/ssw.h): what a batch of a given shape runs -- the bench configuration takes the fused
     level-2 path, full HD has level-2 rows over semi-deep columns (no fusion), the reference's 640 x 444 photograph
