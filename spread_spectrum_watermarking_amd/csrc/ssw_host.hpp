@@ -94,6 +94,7 @@ size_t effective_chunk(const ssw_ctx* ctx, size_t w, size_t h, size_t n_frames);
 struct Stage {
     bool hbm;
     std::function<int(hipStream_t)> run;
+    int tag = 0;        // two-lane scheduling hints: 1 = the GEMM launches of a ROW pass, 2 = the RGB pre-pass that opens a forward transform
 };
 typedef std::vector<Stage> Chain;
 

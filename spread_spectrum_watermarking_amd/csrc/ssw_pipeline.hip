@@ -310,8 +310,20 @@ static bool cols_read_class_major(size_t fh, size_t w) {
 }
 
 // One pass of the separable transform (src -> dst along rows or columns) appended to `ch`.
+int build_pass_impl(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass, bool is_row, const float* src, float* dst,
+                    Epilogue ep, Chain& ch, bool* fused_rgb);
 int build_pass(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass, bool is_row, const float* src, float* dst,
                Epilogue ep, Chain& ch, bool* fused_rgb = nullptr) {
+    const size_t first = ch.size();
+    SSW_TRY(build_pass_impl(ctx, ws, x, first_pass, is_row, src, dst, ep, ch, fused_rgb));
+    for (size_t i = first; i < ch.size(); ++i) {                  // hints for the two-lane scheduler (run_pipeline_impl)
+        if (!ch[i].hbm && is_row) ch[i].tag = 1;
+        if (ch[i].hbm && is_row && first_pass && x.type != SSW_DCT3 && x.rgb) ch[i].tag = 2;
+    }
+    return SSW_OK;
+}
+int build_pass_impl(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_pass, bool is_row, const float* src, float* dst,
+                    Epilogue ep, Chain& ch, bool* fused_rgb) {
     const bool inverse = (x.type == SSW_DCT3);
     const bool f64 = (x.precision == SSW_PRECISION_F64);
     const int precision = x.precision;
@@ -1103,11 +1115,22 @@ int run_pipeline_impl(ssw_ctx* ctx, size_t n_chunks, bool two, const std::functi
         ctx->lane[l].done = nullptr;
         SSW_TRY(start(l));
     }
+    // `lane_stagger` (r5 experiment): the second lane starts one stage late, and an RGB pre-pass waits until the other lane's
+    // row pass is through -- it then runs beside that lane's COLUMN launches (MFMA-bound, 12 B/px) instead of its row
+    // launches (16 B/px and an epilogue that is HBM-bound itself)
+    const bool stagger = two && tuning(TUNE_LANE_STAGGER) != 0;
+    bool held_back = stagger;
     while (active[0] || active[1]) {
         for (int l = 0; l < n_lanes; ++l) {
             if (!active[l]) continue;
+            if (l == 1 && held_back) { held_back = false; continue; }
             Stage& s = chain[l][at[l]];
             SSW_TRY(hop(ctx, ctx->lane[l], s.hbm ? H : G));
+            if (stagger && s.tag == 2) {
+                const int o = 1 - l;
+                if (active[o] && at[o] > 0 && chain[o][at[o] - 1].tag == 1 && ctx->lane[o].done)
+                    SSW_HIP_CHECK(hipStreamWaitEvent(ctx->lane[l].cur, ctx->lane[o].done, 0));
+            }
             SSW_TRY(s.run(ctx->lane[l].cur));
             if (two) SSW_TRY(mark_done(ctx, ctx->lane[l]));
             if (++at[l] == chain[l].size()) SSW_TRY(start(l));
@@ -1323,6 +1346,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         else SSW_TRY(launch_dct_pair_prep4_rows_rgb(st, f64, u8, rgb, n, w, h, o2, o3, o1, nullptr, nullptr));
         return sp ? launch_dct_pair_rotate(st, (const double*)o1, (const double*)rot, sp, lines, w) : SSW_OK;
     }});
+    ch.back().tag = 2;
     double flop = 0.0;
     for (unsigned c = 0; c < plan.n_classes; ++c) flop += (cs[c].x2 ? 4.0 : 2.0) * (double)lines * plan.c[c].cap * (double)cs[c].ktrue;
     ch.push_back({false, [=](hipStream_t st) -> int {
