@@ -59,4 +59,16 @@ int launch_dct_pair_prep16_rows_light(hipStream_t st, int src_kind, const void* 
                                       const double* rot2, const double* rot3, float* ip, float* qp, size_t rows, size_t w, unsigned K16,
                                       unsigned unit_h, unsigned unit_hup);
 
+// dct_pair_derived.hip: the derived frame's pruned row pass in one kernel (marks of up to 1024 entries)
+struct DerivedFusedClass {
+    const double *y1, *y2;     // gathered bases (y2: the sine part of a split class)
+    unsigned p1, p2;           // operand planes by number
+    unsigned cap, off;         // gathered rows = compact columns off .. off + cap - 1
+    bool split;
+};
+bool dct_pair_derived_fused_ok(size_t w, unsigned n_classes, const DerivedFusedClass* cls);
+int launch_dct_pair_derived_fused(hipStream_t st, int src_kind, const void* rgb, size_t lines, size_t w, const double* rot1,
+                                  const double* rot2, const double* rot3, unsigned n_classes, const DerivedFusedClass* cls,
+                                  float* out, unsigned cap_total);
+
 }  // namespace ssw

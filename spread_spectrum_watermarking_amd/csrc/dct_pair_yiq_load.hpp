@@ -1,22 +1,44 @@
 // rgb -> Y (I, Q) of four consecutive pixels of an interleaved RGB row (yiq.rs:177-186, the same arithmetic as color.hip /
-// attack.hip): shared by the operand pre-passes that read the frames themselves (dct_pair_prep.hip, dct_pair_prep_light.hip).
+// attack.hip): shared by the operand pre-passes that read the frames themselves (dct_pair_prep.hip, dct_pair_prep_light.hip,
+// dct_pair_derived.hip).  In two steps -- the loads, and the arithmetic on what they returned -- so that a kernel can keep the
+// next tile's pixels in flight while it works on this one.
 #pragma once
 #include "dct_pair_common.hpp"
 
 namespace ssw {
 
-
 __device__ inline float prep_dot3(float m0, float m1, float m2, float a, float b, float c) { return m0 * a + m1 * b + m2 * c; }
 
-// 4 consecutive pixels starting at pixel x of a row (x % 4 == 0): Y (and I, Q)
-// FMT: SSW_PIX_F32 / U8 / U16 (into_rgb32f: as it is, v / 255, v / 65535)
-template <int FMT, bool WITH_IQ>
-__device__ inline void load_yiq4(const void* row_base, unsigned x, f32x4& y, f32x4& iv, f32x4& qv) {
-    float r[4], g[4], b[4];
+// the twelve samples of 4 consecutive pixels as they lie in memory: FMT SSW_PIX_F32: 3 x 16 bytes, U16: 3 x 8, U8: 3 x 4
+template <int FMT> struct RawQuad { u32x4 w[3]; };
+template <> struct RawQuad<SSW_PIX_U16> { u32x2 w[3]; };
+template <> struct RawQuad<SSW_PIX_U8> { uint32_t w[3]; };
+
+// 4 consecutive pixels starting at pixel x of a row (x % 4 == 0)
+template <int FMT>
+__device__ inline void load_raw4(const void* row_base, unsigned x, RawQuad<FMT>& q) {
     if (FMT == SSW_PIX_U16) {
         const u32x2* src = reinterpret_cast<const u32x2*>(static_cast<const uint16_t*>(row_base) + 3 * (size_t)x);
-        const u32x2 w0 = src[0], w1 = src[1], w2 = src[2];
-        const uint32_t wd[6] = {w0[0], w0[1], w1[0], w1[1], w2[0], w2[1]};
+        auto& w = reinterpret_cast<RawQuad<SSW_PIX_U16>&>(q).w;
+        w[0] = src[0]; w[1] = src[1]; w[2] = src[2];
+    } else if (FMT == SSW_PIX_F32) {
+        const u32x4* src = reinterpret_cast<const u32x4*>(static_cast<const float*>(row_base) + 3 * (size_t)x);
+        auto& w = reinterpret_cast<RawQuad<SSW_PIX_F32>&>(q).w;
+        w[0] = src[0]; w[1] = src[1]; w[2] = src[2];
+    } else {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(row_base) + 3 * (size_t)x);
+        auto& w = reinterpret_cast<RawQuad<SSW_PIX_U8>&>(q).w;
+        w[0] = src[0]; w[1] = src[1]; w[2] = src[2];
+    }
+}
+
+// Y (and I, Q) of the four pixels; into_rgb32f: f32 as it is, v / 255, v / 65535
+template <int FMT, bool WITH_IQ>
+__device__ inline void yiq_of_raw4(const RawQuad<FMT>& q, f32x4& y, f32x4& iv, f32x4& qv) {
+    float r[4], g[4], b[4];
+    if (FMT == SSW_PIX_U16) {
+        const auto& w = reinterpret_cast<const RawQuad<SSW_PIX_U16>&>(q).w;
+        const uint32_t wd[6] = {w[0][0], w[0][1], w[1][0], w[1][1], w[2][0], w[2][1]};
         float v[12];
 #pragma unroll
         for (int e = 0; e < 6; ++e) {                               // into_rgb32f: v / 65535
@@ -26,15 +48,15 @@ __device__ inline void load_yiq4(const void* row_base, unsigned x, f32x4& y, f32
 #pragma unroll
         for (int e = 0; e < 4; ++e) { r[e] = v[3 * e]; g[e] = v[3 * e + 1]; b[e] = v[3 * e + 2]; }
     } else if (FMT == SSW_PIX_F32) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(static_cast<const float*>(row_base) + 3 * (size_t)x);
-        const f32x4 v0 = src[0], v1 = src[1], v2 = src[2];
-        r[0] = v0[0]; g[0] = v0[1]; b[0] = v0[2];
-        r[1] = v0[3]; g[1] = v1[0]; b[1] = v1[1];
-        r[2] = v1[2]; g[2] = v1[3]; b[2] = v2[0];
-        r[3] = v2[1]; g[3] = v2[2]; b[3] = v2[3];
+        const auto& w = reinterpret_cast<const RawQuad<SSW_PIX_F32>&>(q).w;
+        float v[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) v[e] = __uint_as_float(w[e >> 2][e & 3]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { r[e] = v[3 * e]; g[e] = v[3 * e + 1]; b[e] = v[3 * e + 2]; }
     } else {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(row_base) + 3 * (size_t)x);
-        const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+        const auto& w = reinterpret_cast<const RawQuad<SSW_PIX_U8>&>(q).w;
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
         const uint8_t by[12] = {(uint8_t)w0, (uint8_t)(w0 >> 8), (uint8_t)(w0 >> 16), (uint8_t)(w0 >> 24),
                                 (uint8_t)w1, (uint8_t)(w1 >> 8), (uint8_t)(w1 >> 16), (uint8_t)(w1 >> 24),
                                 (uint8_t)w2, (uint8_t)(w2 >> 8), (uint8_t)(w2 >> 16), (uint8_t)(w2 >> 24)};
@@ -53,5 +75,12 @@ __device__ inline void load_yiq4(const void* row_base, unsigned x, f32x4& y, f32
     }
 }
 
+// both steps at once
+template <int FMT, bool WITH_IQ>
+__device__ inline void load_yiq4(const void* row_base, unsigned x, f32x4& y, f32x4& iv, f32x4& qv) {
+    RawQuad<FMT> q;
+    load_raw4<FMT>(row_base, x, q);
+    yiq_of_raw4<FMT, WITH_IQ>(q, y, iv, qv);
+}
 
 }  // namespace ssw

@@ -93,19 +93,29 @@ __global__ __launch_bounds__(256) void prune_gather_basis_kernel(const PruneGath
     while (jn + 1 < jobs.n && blockIdx.x >= jobs.j[jn + 1].first_block) ++jn;                // block-uniform
     const PruneGatherJob& job = jobs.j[jn];
     const size_t i = (blockIdx.x - job.first_block) * (size_t)blockDim.x + threadIdx.x;
-    const size_t total = (size_t)job.kblocks * job.cap * 4;
+    const unsigned cap_out = job.frag ? (job.cap + 15u) & ~15u : job.cap;      // fragment order: whole tiles of 16 rows, zero rows behind the class
+    const size_t total = (size_t)job.kblocks * cap_out * 4;
     if (i >= total) return;
     const unsigned piece = (unsigned)(i & 3);
-    const unsigned r_out = (unsigned)((i >> 2) % job.cap);
-    const unsigned kb = (unsigned)((i >> 2) / job.cap);
-    const uint32_t rf = job.rows[r_out];
+    const unsigned r_out = (unsigned)((i >> 2) % cap_out);
+    const unsigned kb = (unsigned)((i >> 2) / cap_out);
+    const uint32_t rf = r_out < job.cap ? job.rows[r_out] : PRUNE_NONE;
     u32x4 v = {0u, 0u, 0u, 0u};
     if (rf != PRUNE_NONE) {
         const uint32_t r = rf & ~PRUNE_NEG;
         v = *reinterpret_cast<const u32x4*>(job.src + ((size_t)kb * job.src_rows + r) * 64 + piece * 16);
         if (job.negate && (rf & PRUNE_NEG)) { v[1] ^= 0x80000000u; v[3] ^= 0x80000000u; }      // two doubles: flip the sign bits
     }
-    *reinterpret_cast<u32x4*>(job.dst + ((size_t)kb * job.cap + r_out) * 64 + piece * 16) = v;
+    if (!job.frag) {
+        *reinterpret_cast<u32x4*>(job.dst + ((size_t)kb * job.cap + r_out) * 64 + piece * 16) = v;
+        return;
+    }
+    // r5, the fused derived pass (dct_pair_derived.hip): MFMA B-fragment order -- per tile of 16 rows [k / 4][k % 4][row % 16] doubles,
+    // so that a wave reads a fragment (16 rows x 4 k) as 512 contiguous bytes.  f64 only (8 k per k-block).
+    const unsigned tile = r_out >> 4, li = r_out & 15u, k = 8 * kb + 2 * piece;      // this piece: k and k + 1
+    u32x2* d = reinterpret_cast<u32x2*>(job.dst) + ((size_t)tile * (2 * job.kblocks) + (k >> 2)) * 64 + li;
+    d[(k & 3u) * 16] = (u32x2){v[0], v[1]};
+    d[((k + 1) & 3u) * 16] = (u32x2){v[2], v[3]};
 }
 
 int launch_prune_build(hipStream_t st, const uint32_t* idx, size_t n_frames, size_t k, const PrunePlan& plan,
@@ -123,7 +133,8 @@ int launch_prune_gather_bases(hipStream_t st, PruneGatherJobs jobs) {
     unsigned blocks = 0;
     for (unsigned j = 0; j < jobs.n; ++j) {
         jobs.j[j].first_block = blocks;
-        blocks += (unsigned)(((size_t)jobs.j[j].kblocks * jobs.j[j].cap * 4 + 255) / 256);
+        const unsigned cap_out = jobs.j[j].frag ? (jobs.j[j].cap + 15u) & ~15u : jobs.j[j].cap;
+        blocks += (unsigned)(((size_t)jobs.j[j].kblocks * cap_out * 4 + 255) / 256);
     }
     if (blocks == 0) return SSW_OK;
     prune_gather_basis_kernel<<<blocks, 256, 0, st>>>(jobs);

@@ -15,6 +15,9 @@
 #include <cstring>
 
 #include "ssw_host.hpp"
+#include "dct_pair_split.hpp"
+
+#include <array>
 #include <cstdlib>
 
 namespace ssw {
@@ -1253,6 +1256,8 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     // class -> image operand plane(s), cached basis plane(s), padded / true sum length
     struct ClassSrc { const void* x; const void* basis; size_t src_rows, kp, ktrue; const void* x2 = nullptr; const void* basis2 = nullptr; };
     ClassSrc cs[9];
+    int pn1[9] = {0}, pn2[9] = {0};          // level 2: the classes' operand planes by number (the fused kernel's A-fragments)
+    bool level2 = false;
     unsigned ci = 0;
     const size_t lines = n * h;
     const void *rot = nullptr, *rot2 = nullptr, *rot3 = nullptr;
@@ -1279,6 +1284,9 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         cs[ci++] = {P(10), sb2[0], re, kp16, w / 16, P(11), sb2[1]};
         cs[ci++] = {P(8), h0, w / 16, kp16, w / 16};
         cs[ci++] = {P(9), h1, w / 16, kp16, w / 16};
+        static const int planes_l2[9][2] = {{0, 3}, {1, 2}, {4, 5}, {6, 7}, {12, 13}, {14, 15}, {10, 11}, {8, -1}, {9, -1}};
+        for (int c = 0; c < 9; ++c) { pn1[c] = planes_l2[c][0]; pn2[c] = planes_l2[c][1]; }
+        level2 = true;
     } else if (ps.split) {
         const void* sb[4];
         for (int b = 0; b < 4; ++b) SSW_TRY(get_basis(ctx, w, false, true, 5 + b, &sb[b]));
@@ -1325,8 +1333,9 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     if (ci != plan.n_classes) return SSW_ERR_BAD_ARG;
     size_t goff[9], goff2[9], gtotal = 0;
     for (unsigned c = 0; c < plan.n_classes; ++c) {
-        goff[c] = gtotal; gtotal += cs[c].kp * plan.c[c].cap * esz;
-        goff2[c] = gtotal; if (cs[c].x2) gtotal += cs[c].kp * plan.c[c].cap * esz;
+        const size_t cap16 = (plan.c[c].cap + 15) / 16 * 16;               // (whole tiles of 16 rows: the fused pass's fragment order)
+        goff[c] = gtotal; gtotal += cs[c].kp * cap16 * esz;
+        goff2[c] = gtotal; if (cs[c].x2) gtotal += cs[c].kp * cap16 * esz;
     }
     SSW_TRY(grow(ws.gathered, gtotal));
     char* gathered = (char*)ws.gathered.p;
@@ -1336,6 +1345,45 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     const bool deep = ps.deep;
     const double px = (double)n * (double)w * (double)h;
     const double prep_bytes = px * (3.0 * (double)pix_bytes(u8) + (double)esz);
+    double flop = 0.0;
+    for (unsigned c = 0; c < plan.n_classes; ++c) flop += (cs[c].x2 ? 4.0 : 2.0) * (double)lines * plan.c[c].cap * (double)cs[c].ktrue;
+    auto gather_jobs = [=](bool frag) {
+        PruneGatherJobs jobs;
+        jobs.n = 0;
+        for (unsigned c = 0; c < plan.n_classes; ++c) {
+            const unsigned kblocks = (unsigned)(cs[c].kp / (64 / esz));
+            jobs.j[jobs.n++] = {rows + plan.c[c].off, (const char*)cs[c].basis, gathered + goff[c], plan.c[c].cap, (unsigned)cs[c].src_rows, kblocks, 0u, false, frag};
+            if (cs[c].x2) jobs.j[jobs.n++] = {rows + plan.c[c].off, (const char*)cs[c].basis2, gathered + goff2[c], plan.c[c].cap, (unsigned)cs[c].src_rows, kblocks, 0u, true, frag};
+        }
+        return jobs;
+    };
+    // r5: marks of up to 1024 entries at level 2 -- the whole row pass in one kernel (dct_pair_derived.hip): no operand planes
+    if (level2 && f64) {
+        DerivedFusedClass fc[9];
+        for (unsigned c = 0; c < plan.n_classes; ++c)
+            fc[c] = {(const double*)(gathered + goff[c]), cs[c].x2 ? (const double*)(gathered + goff2[c]) : nullptr, (unsigned)pn1[c],
+                     (unsigned)(pn2[c] < 0 ? 0 : pn2[c]), plan.c[c].cap, plan.c[c].off, cs[c].x2 != nullptr};
+        if (dct_pair_derived_fused_ok(w, plan.n_classes, fc)) {
+            const unsigned ncl = plan.n_classes;
+            std::array<DerivedFusedClass, 9> fca;
+            for (unsigned c = 0; c < 9; ++c) fca[c] = fc[c < ncl ? c : 0];
+            ch.push_back({true, [=](hipStream_t st) -> int {
+                SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
+                return launch_prune_gather_bases(st, gather_jobs(true));
+            }});
+            const double in_bytes = px * 3.0 * (double)pix_bytes(u8);
+            ch.push_back({false, [=](hipStream_t st) -> int {
+                StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
+                t.traffic(in_bytes + (double)lines * (double)cap * 4.0);          // the frames in, the compact plane out
+                return launch_dct_pair_derived_fused(st, pix_src_kind(u8), rgb, lines, w, (const double*)rot, (const double*)rot2, (const double*)rot3,
+                                                     ncl, fca.data(), t_compact, (unsigned)cap);
+            }});
+            ch.back().tag = 1;
+            Xform xc{SSW_DCT2, precision, n, cap, h, (float*)ws.compact[1].p, t_compact};
+            xc.natural_order = true;
+            return build_pass(ctx, ws, xc, false, false, t_compact, (float*)ws.compact[1].p, Epilogue{1.f, 1.f}, ch);
+        }
+    }
     // the set of columns, then Reader::derived's colour conversion + operand pre-pass (same kernels as the full path)
     ch.push_back({true, [=](hipStream_t st) -> int {
         SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
@@ -1347,17 +1395,8 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         return sp ? launch_dct_pair_rotate(st, (const double*)o1, (const double*)rot, sp, lines, w) : SSW_OK;
     }});
     ch.back().tag = 2;
-    double flop = 0.0;
-    for (unsigned c = 0; c < plan.n_classes; ++c) flop += (cs[c].x2 ? 4.0 : 2.0) * (double)lines * plan.c[c].cap * (double)cs[c].ktrue;
     ch.push_back({false, [=](hipStream_t st) -> int {
-        PruneGatherJobs jobs;
-        jobs.n = 0;
-        for (unsigned c = 0; c < plan.n_classes; ++c) {
-            const unsigned kblocks = (unsigned)(cs[c].kp / (64 / esz));
-            jobs.j[jobs.n++] = {rows + plan.c[c].off, (const char*)cs[c].basis, gathered + goff[c], plan.c[c].cap, (unsigned)cs[c].src_rows, kblocks, 0u, false};
-            if (cs[c].x2) jobs.j[jobs.n++] = {rows + plan.c[c].off, (const char*)cs[c].basis2, gathered + goff2[c], plan.c[c].cap, (unsigned)cs[c].src_rows, kblocks, 0u, true};
-        }
-        SSW_TRY(launch_prune_gather_bases(st, jobs));
+        SSW_TRY(launch_prune_gather_bases(st, gather_jobs(false)));
         StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
         t.traffic(px * (double)esz + (double)lines * (double)cap * 4.0);      // every operand plane once in, the compact plane out
         if (f64 && lines <= (size_t)tuning(TUNE_MERGE_MAX_LINES)) {          // a single frame: the classes side by side in one launch per kind

@@ -37,6 +37,7 @@ Entry g_tune[TUNE_COUNT] = {
     {"speculate_k", "SSW_SPECULATE_K", 1},             // Reader::base queues the selection for the context's last extraction length
     {"prep_light", "SSW_PREP_LIGHT", 1},               // level-2 row pre-pass in the < 64-VGPR form that runs beside the GEMMs (0: pair_prep16_rows_kernel)
     {"lane_stagger", "SSW_LANE_STAGGER", 1},           // two lanes: RGB pre-passes beside the other lane's column launches, not its row launches (r5: +0.7 %)
+    {"derived_fused", "SSW_DERIVED_FUSED", 1},         // the derived frame's pruned row pass in one kernel (marks of up to 1024 entries; 0: pre-pass + launches)
 };
 
 }  // namespace

@@ -69,9 +69,22 @@ def test_light_row_prepass_is_bit_identical_to_the_register_resident_one():
     import prep_light_check
     lines = []
     bad = prep_light_check.run(lines.append, batch=[(2160, 3840, 8, 1000), (2160, 3840, 3, 500), (1080, 1920, 5, 500), (272, 512, 40, 100),
-                                                   (144, 1088, 9, 64)], planes=[(272, 576, 30), (1088, 2048, 9)])
+                                                   (144, 1088, 9, 64)], planes=[(272, 576, 30), (1088, 2048, 9)], derived=[])
     assert bad == 0, "\n".join(l for l in lines if "FAIL" in l)
     assert lines[-1] == "light row pre-pass: all good"
+
+
+def test_fused_derived_pass_is_bit_identical_to_prepass_and_launches():
+    """r5 (verdict r4 #6): the derived frame's pruned row pass in one kernel (csrc/dct_pair_derived.hip: pixels -> Y -> level-2
+    fold -> MFMA against the gathered bases, no operand planes) against the pre-pass + nine gathered launches
+    (derived_fused = 0): extracted marks and similarities of ssw_batch_extract{,_rgb8,_rgb16} bit for bit, marks of 64 .. 1024
+    entries (class tiles of 4 .. 32 gathered columns), one to forty frames, 512 .. 7680 columns: tools/prep_light_check.py.
+    Reader::extract reads the derived plane only at the base's first k indices, /root/reference/src/algorithm.rs:556-561."""
+    import prep_light_check
+    lines = []
+    bad = prep_light_check.run(lines.append, batch=[], planes=[])
+    assert bad == 0, "\n".join(l for l in lines if "FAIL" in l)
+    assert sum("one kernel ==" in l for l in lines) == 3 * len(prep_light_check.DERIVED)
 
 
 def test_transform_plan_reports_the_default_path():

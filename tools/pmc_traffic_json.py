@@ -88,6 +88,8 @@ names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESI
         "r5, reader: RGB f32 in, the sixteen f64 operand planes of the level-2 row pass out (the < 64-VGPR form, csrc/dct_pair_prep_light.hip)"),
     "pair_prep16_rows_light_kernel<1, true, 8>": ("pair_prep16_rows_light_kernel<rgb, with I/Q>", lines_r * W * (12 + 8 + esz),
         "r5, writer: RGB f32 in, operand planes + I, Q planes out"),
+    "derived_fused_kernel<1>": ("derived_fused_kernel<rgb>", lines_r * W * 12 + lines_r * 256 * 4,
+        "r5: the derived frame's pruned row pass in one kernel (csrc/dct_pair_derived.hip): RGB f32 in, the compact plane (256 columns for k = 1000) out"),
     "pair_prep16_cols_kernel<double>": ("pair_prep16_cols_kernel<double>", lines_r * W * (4 + esz),
         "r3 kernel (SSW_PREP_STAGED=0): f32 plane in, transposed deep f64 operand planes out (mean over launches incl. the narrow pruned ones)"),
     "pair_prep16_inv_rows_kernel<double>": ("pair_prep16_inv_rows_kernel<double>", lines_r * W * (4 + esz), "r3 kernel: coefficient plane in, deep inverse operand planes out"),

@@ -20,10 +20,14 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tools")):
 BATCH = [(2160, 3840, 8, 1000), (2160, 3840, 4, 1000), (1080, 1920, 5, 500), (4320, 7680, 1, 2000), (272, 512, 40, 100), (144, 1088, 9, 64),
          (720, 1280, 48, 300)]
 PLANES = [(2160, 3840, 2), (272, 576, 30), (1088, 2048, 9)]
+# r5, the derived frame's pruned row pass in one kernel (csrc/dct_pair_derived.hip, tuning derived_fused) against pre-pass + launches:
+# (h, w, frames, k) -- k <= 1024 takes the kernel; 64 .. 1024 covers class tiles of 4 .. 32 gathered columns
+DERIVED = [(2160, 3840, 8, 1000), (2160, 3840, 3, 1024), (1080, 1920, 5, 500), (1080, 1920, 40, 64), (272, 512, 40, 100), (144, 1088, 9, 300),
+           (4320, 7680, 1, 1000), (1088, 2048, 17, 785)]
 LOW = dict(efold_min=256, efold_inv_min=256, efold_cols_min=64)
 
 
-def run(out=print, batch=BATCH, planes=PLANES):
+def run(out=print, batch=BATCH, planes=PLANES, derived=DERIVED):
     import gpu_util as G
     from conftest import f32_to_u8
     from spread_spectrum_watermarking_amd import _lib as L, tuning
@@ -64,6 +68,31 @@ def run(out=print, batch=BATCH, planes=PLANES):
         same = np.array_equal(*res)
         bad += not same
         out(f"planes {h} x {w} n={n}: light == pair_prep16_rows_kernel: {same}{'' if same else '   <-- FAIL'}")
+    for (h, w, n, k) in derived:
+        rgb = G.synth(9, 0, n, w, h)
+        marks = np.random.default_rng(k + 1).standard_normal((n, k)).astype(np.float32)
+        cfg = G.default_config(L.PRECISION_F64)
+        with tuning(**LOW), G.fresh_ctx():
+            marked = G.batch_embed(rgb, marks, cfg)["rgb"]
+        u8, m8 = f32_to_u8(rgb), f32_to_u8(marked)
+        to16 = lambda a: np.floor(np.clip(a, 0, 1) * np.float32(65535) + np.float32(0.5)).astype(np.uint16)
+        u16, m16 = to16(rgb), to16(marked)
+        for kind in ("f32", "u8", "u16"):
+            res = []
+            for fused in (1, 0):
+                with tuning(derived_fused=fused, **LOW), G.fresh_ctx() as c:
+                    if kind == "f32":
+                        res.append(G.batch_extract(rgb, marked, k, marks, cfg))
+                    elif kind == "u8":
+                        res.append(G.batch_extract_rgb8(u8, m8, k, marks, cfg))
+                    else:
+                        res.append(G.batch_extract_rgb16(u16, m16, k, marks, cfg))
+                    ps = c.prune_stats()
+                    assert ps["redone_chunks"] == 0, ps
+            same = all(np.array_equal(p, q) for p, q in zip(*res))
+            bad += not same
+            out(f"derived {h} x {w} n={n} k={k} {kind}: one kernel == pre-pass + launches (extracted marks, similarities): {same}{'' if same else '   <-- FAIL'}")
+        del rgb, marked, u8, m8, u16, m16
     out("light row pre-pass: " + ("FAILED" if bad else "all good"))
     return bad
 
