@@ -1363,7 +1363,8 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
         for (unsigned c = 0; c < plan.n_classes; ++c)
             fc[c] = {(const double*)(gathered + goff[c]), cs[c].x2 ? (const double*)(gathered + goff2[c]) : nullptr, (unsigned)pn1[c],
                      (unsigned)(pn2[c] < 0 ? 0 : pn2[c]), plan.c[c].cap, plan.c[c].off, cs[c].x2 != nullptr};
-        if (dct_pair_derived_fused_ok(w, plan.n_classes, fc)) {
+        // (a single frame is 135 blocks of 16 lines for 256 CUs: the merged launches below are 35 us faster there)
+        if (lines > (size_t)tuning(TUNE_MERGE_MAX_LINES) && dct_pair_derived_fused_ok(w, plan.n_classes, fc)) {
             const unsigned ncl = plan.n_classes;
             std::array<DerivedFusedClass, 9> fca;
             for (unsigned c = 0; c < 9; ++c) fca[c] = fc[c < ncl ? c : 0];

@@ -80,7 +80,7 @@ def run(out=print, batch=BATCH, planes=PLANES, derived=DERIVED):
         for kind in ("f32", "u8", "u16"):
             res = []
             for fused in (1, 0):
-                with tuning(derived_fused=fused, **LOW), G.fresh_ctx() as c:
+                with tuning(derived_fused=fused, merge_max_lines=256, **LOW), G.fresh_ctx() as c:      # (passes of more lines than that take the kernel)
                     if kind == "f32":
                         res.append(G.batch_extract(rgb, marked, k, marks, cfg))
                     elif kind == "u8":
