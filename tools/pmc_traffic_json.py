@@ -155,7 +155,10 @@ out["families"] = {"_unit": f"one step = embed + extract of one {chunk}-frame pa
 # r5: a fused forward transform has no column pre-pass (its launches are absent from the profile): count what ran
 n_fwd_cols = out["families"]["prepass"]["members_launches_per_step"].get("prep16_cols_l2_kernel<1>", 0) + \
              out["families"]["prepass"]["members_launches_per_step"].get("prep16_cols_staged_kernel<1, true>", 0)
-pre_alg = px_step * (28 + 20 + 20 + (n_fwd_cols + 2) * 12)
+# r5: the derived frame's row pass in one kernel (csrc/dct_pair_derived.hip) has no pre-pass and no operand planes: its frames
+# (12 B/px) are counted with the kernel itself (kernels["derived_fused_kernel<rgb>"]), in neither family
+derived_fused = any("derived_fused_kernel" in k for k in fetch)
+pre_alg = px_step * (28 + 20 + (0 if derived_fused else 20) + (n_fwd_cols + 2) * 12)
 out["families"]["prepass"]["algorithmic_bytes_per_step"] = int(pre_alg)
 out["families"]["prepass"]["traffic_over_algorithmic"] = round(out["families"]["prepass"]["hbm_bytes_per_step"] / pre_alg, 3)
 # the GEMM family's algorithmic bytes per step, as ssw_ctx_get_traffic counts them (csrc/ssw_pipeline.hip build_pass): per
@@ -165,7 +168,7 @@ out["families"]["prepass"]["traffic_over_algorithmic"] = round(out["families"]["
 fused = any(k.startswith("pair_gemm_f64_kernel<false, 7") for k in out["families"]["gemm"]["members_launches_per_step"])
 fwd_rows = 16 if fused else 12
 gemm_alg = px_step * (2 * (fwd_rows + 12)            # writer and base reader: forward rows + columns
-                      + 8                             # derived frame: operands of the gathered row launches (the compact planes are a few percent)
+                      + (0 if derived_fused else 8)   # derived frame: operands of the gathered row launches (the compact planes are a few percent)
                       + (8 + 14 + 4) + (8 + 14 + 8 + 12))      # inverse rows; inverse columns with the RGB epilogue
 out["families"]["gemm"]["algorithmic_bytes_per_step"] = int(gemm_alg)
 out["families"]["gemm"]["traffic_over_algorithmic"] = round(out["families"]["gemm"]["hbm_bytes_per_step"] / gemm_alg, 3)
