@@ -44,7 +44,7 @@ struct DfJobs {
 };
 
 template <int SRC /*1 rgb f32, 2 rgb u8, 3 rgb u16*/>
-__global__ __launch_bounds__(256, 2) void derived_fused_kernel(const void* __restrict__ SRCP, const double* __restrict__ rot1,
+__global__ __launch_bounds__(256, 2) void prep16_derived_fused_kernel(const void* __restrict__ SRCP, const double* __restrict__ rot1,
                                                               const double* __restrict__ rot2, const double* __restrict__ rot3,
                                                               DfJobs jobs, float* __restrict__ out, unsigned rows, unsigned W,
                                                               unsigned Kp, unsigned cap_total) {
@@ -280,15 +280,15 @@ int launch_dct_pair_derived_fused(hipStream_t st, int src_kind, const void* rgb,
         int dev = 0;
         SSW_HIP_CHECK(hipGetDevice(&dev));
         if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-            for (const void* f : {reinterpret_cast<const void*>(derived_fused_kernel<1>), reinterpret_cast<const void*>(derived_fused_kernel<2>),
-                                  reinterpret_cast<const void*>(derived_fused_kernel<3>)})
+            for (const void* f : {reinterpret_cast<const void*>(prep16_derived_fused_kernel<1>), reinterpret_cast<const void*>(prep16_derived_fused_kernel<2>),
+                                  reinterpret_cast<const void*>(prep16_derived_fused_kernel<3>)})
                 SSW_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
         }
     }
-    if (src_kind == 1) derived_fused_kernel<1><<<nblk, 256, smem, st>>>(rgb, rot1, rot2, rot3, jobs, out, (unsigned)lines, (unsigned)w, Kp, cap_total);
-    else if (src_kind == 2) derived_fused_kernel<2><<<nblk, 256, smem, st>>>(rgb, rot1, rot2, rot3, jobs, out, (unsigned)lines, (unsigned)w, Kp, cap_total);
-    else derived_fused_kernel<3><<<nblk, 256, smem, st>>>(rgb, rot1, rot2, rot3, jobs, out, (unsigned)lines, (unsigned)w, Kp, cap_total);
+    if (src_kind == 1) prep16_derived_fused_kernel<1><<<nblk, 256, smem, st>>>(rgb, rot1, rot2, rot3, jobs, out, (unsigned)lines, (unsigned)w, Kp, cap_total);
+    else if (src_kind == 2) prep16_derived_fused_kernel<2><<<nblk, 256, smem, st>>>(rgb, rot1, rot2, rot3, jobs, out, (unsigned)lines, (unsigned)w, Kp, cap_total);
+    else prep16_derived_fused_kernel<3><<<nblk, 256, smem, st>>>(rgb, rot1, rot2, rot3, jobs, out, (unsigned)lines, (unsigned)w, Kp, cap_total);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

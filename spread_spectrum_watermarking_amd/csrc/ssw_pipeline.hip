@@ -1373,9 +1373,10 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
                 return launch_prune_gather_bases(st, gather_jobs(true));
             }});
             const double in_bytes = px * 3.0 * (double)pix_bytes(u8);
+            // (timed with the RGB pre-passes: an HBM-bound kernel -- frames in, compact plane out -- whose 0.1e12 flop ride along;
+            // bench.py's GEMM family stays "every pair_gemm_f64_kernel launch")
             ch.push_back({false, [=](hipStream_t st) -> int {
-                StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
-                t.traffic(in_bytes + (double)lines * (double)cap * 4.0);          // the frames in, the compact plane out
+                StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, in_bytes + (double)lines * (double)cap * 4.0);
                 return launch_dct_pair_derived_fused(st, pix_src_kind(u8), rgb, lines, w, (const double*)rot, (const double*)rot2, (const double*)rot3,
                                                      ncl, fca.data(), t_compact, (unsigned)cap);
             }});

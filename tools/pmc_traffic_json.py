@@ -88,7 +88,7 @@ names = {   # instance in the rocprofv3 output -> (label used by bench.py / DESI
         "r5, reader: RGB f32 in, the sixteen f64 operand planes of the level-2 row pass out (the < 64-VGPR form, csrc/dct_pair_prep_light.hip)"),
     "pair_prep16_rows_light_kernel<1, true, 8>": ("pair_prep16_rows_light_kernel<rgb, with I/Q>", lines_r * W * (12 + 8 + esz),
         "r5, writer: RGB f32 in, operand planes + I, Q planes out"),
-    "derived_fused_kernel<1>": ("derived_fused_kernel<rgb>", lines_r * W * 12 + lines_r * 256 * 4,
+    "prep16_derived_fused_kernel<1>": ("prep16_derived_fused_kernel<rgb>", lines_r * W * 12 + lines_r * 256 * 4,
         "r5: the derived frame's pruned row pass in one kernel (csrc/dct_pair_derived.hip): RGB f32 in, the compact plane (256 columns for k = 1000) out"),
     "pair_prep16_cols_kernel<double>": ("pair_prep16_cols_kernel<double>", lines_r * W * (4 + esz),
         "r3 kernel (SSW_PREP_STAGED=0): f32 plane in, transposed deep f64 operand planes out (mean over launches incl. the narrow pruned ones)"),
@@ -156,9 +156,9 @@ out["families"] = {"_unit": f"one step = embed + extract of one {chunk}-frame pa
 n_fwd_cols = out["families"]["prepass"]["members_launches_per_step"].get("prep16_cols_l2_kernel<1>", 0) + \
              out["families"]["prepass"]["members_launches_per_step"].get("prep16_cols_staged_kernel<1, true>", 0)
 # r5: the derived frame's row pass in one kernel (csrc/dct_pair_derived.hip) has no pre-pass and no operand planes: its frames
-# (12 B/px) are counted with the kernel itself (kernels["derived_fused_kernel<rgb>"]), in neither family
-derived_fused = any("derived_fused_kernel" in k for k in fetch)
-pre_alg = px_step * (28 + 20 + (0 if derived_fused else 20) + (n_fwd_cols + 2) * 12)
+# (12 B/px in, the compact plane out) count for the pre-pass family, whose name match the kernel carries
+derived_fused = any("prep16_derived_fused_kernel" in k for k in fetch)
+pre_alg = px_step * (28 + 20 + (12 if derived_fused else 20) + (n_fwd_cols + 2) * 12) + (chunk * H * 256 * 4 if derived_fused else 0)
 out["families"]["prepass"]["algorithmic_bytes_per_step"] = int(pre_alg)
 out["families"]["prepass"]["traffic_over_algorithmic"] = round(out["families"]["prepass"]["hbm_bytes_per_step"] / pre_alg, 3)
 # the GEMM family's algorithmic bytes per step, as ssw_ctx_get_traffic counts them (csrc/ssw_pipeline.hip build_pass): per
