@@ -580,3 +580,14 @@ def test_bench_rccl_path_world_size_one():
                {"SSW_FORCE_DIST": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                 "MASTER_PORT": "29617"})
     assert j["ranks"]["dist_backend"] == "nccl" and j["ranks"]["ranks_seen"] == [0]
+
+
+def test_graft_entry_smoke_runs():
+    """__graft_entry__.smoke() -- what the driver runs on the GPU box before the bench -- inside the suite, so that a change of
+    bars or of the default library cannot break it unnoticed (r5: it had, for the f32 leg)."""
+    import importlib
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    g = importlib.import_module("__graft_entry__")
+    g.smoke()
