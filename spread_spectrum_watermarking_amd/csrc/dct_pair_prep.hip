@@ -1401,6 +1401,8 @@ int launch_dct_pair_prep16_inv_rows(hipStream_t st, const float* in, size_t n_fr
     const unsigned unit_hup = unit_order ? (unsigned)dct_pair_fused_units(h) : 0u;
     const size_t rows = unit_order ? n_frames * 16 * unit_hup : n_frames * h;       // operand lines
     if (rows > 0xFFFFFFFFull) return SSW_ERR_BAD_DIMS;
+    if (dct_pair_efold_inv(w) && dct_pair_inv_prep_light_ok(w, rows))          // r5 A/B: whole rows through LDS, one lane per unit (dct_pair_prep_light.hip)
+        return launch_prep16_inv_rows_light(st, in, rows, w, base, rot1, rot2, rot3, (unsigned)dct_pair_split_kpad(w / 2), unit_order ? (unsigned)h : 0u, unit_hup);
     if (dct_pair_efold_inv(w))
         return launch_prep16_inv_rows_l2(st, in, rows, w, base, rot1, rot2, rot3, (unsigned)dct_pair_split_kpad(w / 2), unit_order ? (unsigned)h : 0u, unit_hup);
     if (dct_pair_prep_staged_rows_ok())

@@ -17,6 +17,8 @@
 #include "dct_pair_colops.hpp"
 #include "dct_pair_yiq_load.hpp"
 
+#include <atomic>
+
 namespace ssw {
 namespace {
 
@@ -133,6 +135,97 @@ __global__ __launch_bounds__(16 * LINES, 8) void pair_prep16_rows_light_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The INVERSE row pre-pass at level 2 (prep16_inv_rows_l2_kernel's sixteen planes, dct_pair_prep_staged.hip) in the same style:
+// a block parks LINES whole coefficient rows in LDS (contiguous 16-byte loads, all of a lane's in flight together), then one
+// lane per (line, unit k) gathers the unit's sixteen coefficients -- c[2k+1], c[W/2-1-2k], ... c[16k], c[16k+8], c[8k+4] ...:
+// strides of 2 .. 16 floats, spread over the banks by 4 floats of padding per 32 -- and runs inv_col_l2_unit_lo / _hi
+// (dct_pair_colops.hpp: the operations and the order of the staged kernel).  A wave = 8 consecutive units of 2 lines of 4
+// k-blocks: every store instruction writes four 128-byte lines whole.
+// ---------------------------------------------------------------------------------------------
+constexpr int ILINES = 2;
+__device__ inline unsigned ipos(unsigned j) { return j + 4u * (j >> 5); }
+
+__global__ __launch_bounds__(128) void prep16_inv_rows_light_kernel(const float* __restrict__ X, double* __restrict__ base,
+                                                                    const double* __restrict__ rot1, const double* __restrict__ rot2,
+                                                                    const double* __restrict__ rot3, unsigned rows, unsigned W,
+                                                                    unsigned K16, unsigned unit_h, unsigned unit_hup) {
+    extern __shared__ __attribute__((aligned(16))) float ls[];          // ILINES x pitch floats
+    const unsigned pitch = W + W / 8;
+    const unsigned tid = threadIdx.x;
+    const unsigned line0 = blockIdx.x * ILINES;
+    const unsigned N16 = W / 16, Wq4 = W / 4;
+    // ---- phase 1: the lines' coefficient rows (unit order of the fused inverse transform: see prep16_inv_rows_l2_kernel)
+    for (unsigned q0 = 0; q0 < ILINES * Wq4; q0 += 128 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned q = q0 + tid + 128 * i;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (q >= ILINES * Wq4) continue;
+            const unsigned ll = q / Wq4, j4 = q - ll * Wq4, line = line0 + ll;
+            if (line >= rows) continue;
+            size_t src_row = line;
+            bool ok = true;
+            if (unit_h) {
+                const unsigned lpf = 16 * unit_hup, z = line / lpf, rem = line - z * lpf;
+                ok = (rem >> 4) < unit_h / 16;
+                src_row = (size_t)z * unit_h + (ok ? inv_col_unit_row(rem >> 4, rem & 15u, unit_h) : 0u);
+            }
+            if (ok) v[i] = *reinterpret_cast<const f32x4*>(X + src_row * W + 4 * j4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned q = q0 + tid + 128 * i;
+            if (q >= ILINES * Wq4) continue;
+            const unsigned ll = q / Wq4, j4 = q - ll * Wq4;
+            *reinterpret_cast<f32x4*>(ls + ll * pitch + ipos(4 * j4)) = v[i];
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: (line, unit) items; item = 16 kb + 8 ll + kk: unit k = 8 kb + kk of line ll
+    const unsigned Wh = W / 2, N8 = W / 8, Nq = W / 4;
+    for (unsigned it = tid; it < ILINES * K16; it += 128) {
+        const unsigned kk = it & 7u, ll = (it >> 3) & (unsigned)(ILINES - 1), kb = it >> 4, k = 8 * kb + kk;
+        const unsigned line = line0 + ll;
+        if (line >= rows || k >= K16) continue;
+        const unsigned at = (unsigned)(((size_t)kb * rows + line) * 8 + kk) * 8u;        // byte offset inside a plane (< 4 GB: the launcher checks)
+        const size_t pstride = (size_t)rows * K16 * sizeof(double);
+        auto put = [&](int a, double v) { *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (size_t)a * pstride + at) = v; };
+        if (k >= N16) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) put(a, 0.0);
+            continue;
+        }
+        const float* c = ls + ll * pitch;
+        const unsigned km = N8 - 1 - k;
+        auto C = [&](unsigned j) { return c[ipos(j)]; };
+        {
+            const float x[8] = {C(2 * k + 1), C(Wh - 1 - 2 * k), C(Wh + 2 * k + 1), C(W - 1 - 2 * k),
+                                C(2 * km + 1), C(Wh - 1 - 2 * km), C(Wh + 2 * km + 1), C(W - 1 - 2 * km)};
+            ColL2Tab t;
+            t.ra = rot_load(rot1, k, Nq); t.rb = rot_load(rot1, km, Nq);
+            t.c3 = rot3[k]; t.s3 = rot3[N16 + k];
+            double o[8];
+            inv_col_l2_unit_lo(x, t, o);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) put(a, o[a]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float x[8] = {C(16 * k), C(16 * k + 8), C(8 * k + 4), C(8 * km + 4),
+                                C(4 * k + 2), C(Wh - 2 - 4 * k), C(Wh + 4 * k + 2), C(W - 2 - 4 * k)};
+            ColL2Tab t;
+            t.rc = rot_load(rot2, k, N8);
+            t.c3 = rot3[k]; t.s3 = rot3[N16 + k];
+            double o[8];
+            inv_col_l2_unit_hi(x, t, o);
+#pragma unroll
+            for (int a = 0; a < 8; ++a) put(8 + a, o[a]);
+        }
+    }
+}
+
 }  // namespace
 
 bool dct_pair_prep_light_ok(size_t w, size_t lines) {
@@ -156,6 +249,31 @@ int launch_dct_pair_prep16_rows_light(hipStream_t st, int src_kind, const void* 
     else                    { if (iq) SSW_LIGHT(3, true); else SSW_LIGHT(3, false); }
 #undef SSW_LIGHT
 #undef SSW_LIGHT1
+    SSW_HIP_CHECK(hipGetLastError());
+    return SSW_OK;
+}
+
+bool dct_pair_inv_prep_light_ok(size_t w, size_t lines) {
+    return tuning(TUNE_INV_PREP_LIGHT) != 0 && w % 128 == 0 && dct_pair_efold_inv(w) &&
+           lines * dct_pair_split_kpad(w / 2) * sizeof(double) <= 0xFFFFFFFFull;
+}
+
+int launch_prep16_inv_rows_light(hipStream_t st, const float* in, size_t rows, size_t w, double* base, const double* rot1,
+                                 const double* rot2, const double* rot3, unsigned K16, unsigned unit_h, unsigned unit_hup) {
+    const size_t smem = (size_t)ILINES * (w + w / 8) * sizeof(float);
+    if (smem > 160 * 1024 / 2) return SSW_ERR_BAD_DIMS;
+    {
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        SSW_HIP_CHECK(hipGetDevice(&dev));
+        if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+            SSW_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(prep16_inv_rows_light_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+            if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+        }
+    }
+    const unsigned long long nblk = (rows + ILINES - 1) / ILINES;
+    if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
+    prep16_inv_rows_light_kernel<<<(unsigned)nblk, 128, smem, st>>>(in, base, rot1, rot2, rot3, (unsigned)rows, (unsigned)w, K16, unit_h, unit_hup);
     SSW_HIP_CHECK(hipGetLastError());
     return SSW_OK;
 }

@@ -59,6 +59,9 @@ int launch_dct_pair_prep16_rows_light(hipStream_t st, int src_kind, const void* 
                                       const double* rot2, const double* rot3, float* ip, float* qp, size_t rows, size_t w, unsigned K16,
                                       unsigned unit_h, unsigned unit_hup);
 
+bool dct_pair_inv_prep_light_ok(size_t w, size_t lines);
+int launch_prep16_inv_rows_light(hipStream_t st, const float* in, size_t rows, size_t w, double* base, const double* rot1,
+                                 const double* rot2, const double* rot3, unsigned K16, unsigned unit_h, unsigned unit_hup);
 // dct_pair_derived.hip: the derived frame's pruned row pass in one kernel (marks of up to 1024 entries)
 struct DerivedFusedClass {
     const double *y1, *y2;     // gathered bases (y2: the sine part of a split class)

@@ -38,6 +38,7 @@ Entry g_tune[TUNE_COUNT] = {
     {"prep_light", "SSW_PREP_LIGHT", 1},               // level-2 row pre-pass in the < 64-VGPR form that runs beside the GEMMs (0: pair_prep16_rows_kernel)
     {"lane_stagger", "SSW_LANE_STAGGER", 1},           // two lanes: RGB pre-passes beside the other lane's column launches, not its row launches (r5: +0.7 %)
     {"derived_fused", "SSW_DERIVED_FUSED", 1},         // the derived frame's pruned row pass in one kernel (marks of up to 1024 entries; 0: pre-pass + launches)
+    {"inv_prep_light", "SSW_INV_PREP_LIGHT", 0},       // inverse row pre-pass at level 2: whole rows through LDS, one lane per unit (r5 A/B)
 };
 
 }  // namespace

@@ -65,7 +65,8 @@ def test_light_row_prepass_is_bit_identical_to_the_register_resident_one():
     """r5: the level-2 row pre-pass in the form that fits beside the GEMMs (csrc/dct_pair_prep_light.hip: runs of pixels
     through LDS, one lane per unit, < 64 VGPRs) against pair_prep16_rows_kernel (prep_light = 0) -- whole batch pipelines from
     f32 / 8-bit / 16-bit frames (I and Q written for the writer), natural and unit line order, partial tiles of units, plain
-    planes: tools/prep_light_check.py."""
+    planes; and the inverse row pre-pass in the same style (inv_prep_light, off by default) against prep16_inv_rows_l2_kernel:
+    tools/prep_light_check.py."""
     import prep_light_check
     lines = []
     bad = prep_light_check.run(lines.append, batch=[(2160, 3840, 8, 1000), (2160, 3840, 3, 500), (1080, 1920, 5, 500), (272, 512, 40, 100),
@@ -82,7 +83,7 @@ def test_fused_derived_pass_is_bit_identical_to_prepass_and_launches():
     Reader::extract reads the derived plane only at the base's first k indices, /root/reference/src/algorithm.rs:556-561."""
     import prep_light_check
     lines = []
-    bad = prep_light_check.run(lines.append, batch=[], planes=[])
+    bad = prep_light_check.run(lines.append, batch=[], planes=[], inverse=[])
     assert bad == 0, "\n".join(l for l in lines if "FAIL" in l)
     assert sum("one kernel ==" in l for l in lines) == 3 * len(prep_light_check.DERIVED)
 

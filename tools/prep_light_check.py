@@ -24,10 +24,11 @@ PLANES = [(2160, 3840, 2), (272, 576, 30), (1088, 2048, 9)]
 # (h, w, frames, k) -- k <= 1024 takes the kernel; 64 .. 1024 covers class tiles of 4 .. 32 gathered columns
 DERIVED = [(2160, 3840, 8, 1000), (2160, 3840, 3, 1024), (1080, 1920, 5, 500), (1080, 1920, 40, 64), (272, 512, 40, 100), (144, 1088, 9, 300),
            (4320, 7680, 1, 1000), (1088, 2048, 17, 785)]
+INVERSE = [(2160, 3840, 3), (1080, 1920, 3), (272, 512, 30), (4320, 7680, 1), (144, 1280, 7), (2160, 3840, 1)]      # inv_prep_light: rows of a multiple of 128 columns
 LOW = dict(efold_min=256, efold_inv_min=256, efold_cols_min=64)
 
 
-def run(out=print, batch=BATCH, planes=PLANES, derived=DERIVED):
+def run(out=print, batch=BATCH, planes=PLANES, derived=DERIVED, inverse=INVERSE):
     import gpu_util as G
     from conftest import f32_to_u8
     from spread_spectrum_watermarking_amd import _lib as L, tuning
@@ -93,6 +94,15 @@ def run(out=print, batch=BATCH, planes=PLANES, derived=DERIVED):
             bad += not same
             out(f"derived {h} x {w} n={n} k={k} {kind}: one kernel == pre-pass + launches (extracted marks, similarities): {same}{'' if same else '   <-- FAIL'}")
         del rgb, marked, u8, m8, u16, m16
+    for (h, w, n) in inverse:
+        x = np.random.default_rng(h * 3 + w).standard_normal((n, h, w)).astype(np.float32)
+        res = []
+        for light in (1, 0):
+            with tuning(inv_prep_light=light, **LOW), G.fresh_ctx():
+                res.append(G.dct2d(x, L.DCT3, L.PRECISION_F64))
+        same = np.array_equal(*res)
+        bad += not same
+        out(f"inverse planes {h} x {w} n={n}: light inverse row pre-pass == prep16_inv_rows_l2_kernel: {same}{'' if same else '   <-- FAIL'}")
     out("light row pre-pass: " + ("FAILED" if bad else "all good"))
     return bad
 
