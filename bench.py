@@ -265,9 +265,9 @@ def family_rooflines(prec_name, stage, steps, W, H, chunk_eff, frames_per_step):
     pre_bytes = stage["rgb_to_yiq"]["work"] + stage["dct_prep"]["work"]
     gbs = rate(pre_bytes, pre_ms) / 1e9
     members = hbm_report(stage, ["rgb_to_yiq", "dct_prep"])
-    roofline_hbm = {"bound": "hbm", "kernel": "deep operand pre-passes (family: pair_prep16_rows_light_kernel<rgb>, prep16_cols_l2_kernel, "
-                                               "prep16_inv_rows_l2_kernel, prep16_inv_cols_l2_kernel; below the level-2 sizes the "
-                                               "prep16_*_staged_kernel forms)", "name_match": "prep16",
+    roofline_hbm = {"bound": "hbm", "kernel": "deep operand pre-passes (family: pair_prep16_rows_light_kernel<rgb>, prep16_derived_fused_kernel (the derived "
+                                               "frame's pre-pass + pruned row pass in one), prep16_cols_l2_kernel, prep16_inv_rows_l2_kernel, "
+                                               "prep16_inv_cols_l2_kernel; below the level-2 sizes the prep16_*_staged_kernel forms)", "name_match": "prep16",
                     "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
                     "share_of_step": round(pre_ms / all_ms, 4) if all_ms else None,
                     "algorithmic_bytes_per_step": pre_bytes / steps, "kernel_ms_per_step": round(pre_ms / steps, 3),
