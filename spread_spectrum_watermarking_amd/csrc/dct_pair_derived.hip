@@ -5,7 +5,7 @@
 // Reader::extract (/root/reference/src/algorithm.rs:556-561) reads the derived plane at the k indices of the base plane's
 // ordering and nowhere else: prune.hip gathers, per frequency class, the basis rows of the columns a chunk needs, and the row
 // pass multiplies every line's operands with them.  Here a block owns 16 image rows (lines) for the whole sum:
-//   phase 1  (dct_pair_prep_light.hip) the tile's pixel runs -> Y -> LDS, 32 units of the fold at a time;
+//   phase 1  (dct_pair_prep_light.hip) the tile's pixel runs -> Y -> LDS, 16 units of the fold (= four k-steps) at a time;
 //   phase 2  lane (line li, unit 4 w + lq) of wave w folds its unit (col_l2_unit's operations and order): its sixteen results ARE
 //            the lane's elements of the sixteen planes' MFMA A-fragments for k-step w -- written to LDS for the other waves;
 //   phase 3  every wave owns a few (class, 16-column tile) jobs: per k-step A-fragment(s) from LDS, B-fragment(s) of the
@@ -32,7 +32,7 @@ typedef double f64x4d __attribute__((ext_vector_type(4)));
 constexpr int DF_LINES = 16, DF_PITCH = 16 * 16 + 8, DF_MAXJ = 5;
 
 struct DfJob {
-    const double* y1;          // gathered basis of the class, k-blocked [Kp / 8][cap][8]
+    const double* y1;          // gathered basis of the class in MFMA fragment order (prune_gather_basis_kernel, frag): per 16 rows [k / 4][k % 4][row % 16]
     const double* y2;          // the sine part's (split classes), or nullptr
     unsigned p1, p2;           // operand planes (numbering of pair_prep16_rows_kernel's level-2 planes)
     unsigned cap, row0;        // gathered rows of the class, first row of this job's tile
