@@ -37,6 +37,20 @@ def test_random_shapes_through_the_batch_pipelines(case):
     assert fuzz_batch.passes(r), r
 
 
+@pytest.mark.parametrize("case", fuzz_batch.shapes(8, 77), ids=lambda c: f"{c[0]}x{c[1]}x{c[2]}k{c[3]}")
+def test_random_shapes_through_the_level2_batch_pipelines(case):
+    """The same on the kernels the 4K / 8K batches run -- level-2 passes, the fused forward transform where the shape allows,
+    unmerged launches, the derived frame's row pass in one kernel (r5, csrc/dct_pair_derived.hip) -- reached at fuzz sizes
+    through lowered thresholds (ssw_tuning_set; a fresh context): pruned + two lanes against full transforms + one lane bit
+    for bit, frame 0 against the oracle."""
+    import gpu_util as G
+    from spread_spectrum_watermarking_amd import tuning
+    with tuning(merge_max_lines=64, efold_min=256, efold_inv_min=256, efold_cols_min=64), G.fresh_ctx():
+        r = fuzz_batch.check(*case)
+    assert r["same"], "pruned + two lanes differs from full transforms + one lane"
+    assert fuzz_batch.passes(r), r
+
+
 def test_level2_row_passes_on_small_shapes():
     """Rows of 1280 columns or more (and columns of 720 rows or more) take the level-2 passes (csrc/ssw_pipeline.hip build_pass; 4K and 8K frames in
     test_gpu_parity.py / test_pipeline_gpu.py run them at full size, where only size-independent properties and committed
