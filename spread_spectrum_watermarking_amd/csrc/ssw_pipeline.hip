@@ -1380,7 +1380,6 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
                 return launch_dct_pair_derived_fused(st, pix_src_kind(u8), rgb, lines, w, (const double*)rot, (const double*)rot2, (const double*)rot3,
                                                      ncl, fca.data(), t_compact, (unsigned)cap);
             }});
-            ch.back().tag = 1;
             Xform xc{SSW_DCT2, precision, n, cap, h, (float*)ws.compact[1].p, t_compact};
             xc.natural_order = true;
             return build_pass(ctx, ws, xc, false, false, t_compact, (float*)ws.compact[1].p, Epilogue{1.f, 1.f}, ch);
