@@ -16,6 +16,7 @@ configs[3], the one the metric is quoted on).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import socket
@@ -55,12 +56,36 @@ def free_port() -> int:
     return p
 
 
+def count_gpus_sysfs(nodes: str = "/sys/class/kfd/kfd/topology/nodes", dri: str = "/dev/dri") -> int:
+    """GPUs of this node as the kernel driver lists them -- no HIP / HSA call, so the launcher process never opens a device
+    (a parent that has initialised the GPU must not fork ranks on this pool).  KFD topology nodes with simd_count > 0 are GPUs
+    (CPUs have 0); HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES narrow the count like they narrow the ranks' view."""
+    n = 0
+    for props in glob.glob(os.path.join(nodes, "*", "properties")):
+        try:
+            with open(props) as f:
+                for line in f:
+                    key, _, val = line.partition(" ")
+                    if key == "simd_count" and int(val) > 0:
+                        n += 1
+                        break
+        except (OSError, ValueError):
+            pass
+    if n == 0:
+        n = len(glob.glob(os.path.join(dri, "renderD*")))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n: int) -> int:
     """Parent of a plain `python bench.py --gpus N` run: one child process per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment, the same command line.  The parent makes no GPU call
-    (torch.cuda.device_count() reads sysfs, it does not initialise HIP) and never re-execs."""
+    (the GPUs are counted from sysfs, count_gpus_sysfs) and never re-execs."""
     shared = bool(os.environ.get("SSW_BENCH_SHARE_DEVICE"))           # tests: every rank on device 0
-    n_dev = torch.cuda.device_count()
+    n_dev = count_gpus_sysfs()
     if n_dev == 0:
         print("bench.py needs a GPU: the product path has no CPU fallback", file=sys.stderr)
         return 2

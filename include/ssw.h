@@ -145,9 +145,10 @@ int ssw_ctx_set_stream(ssw_ctx* ctx, void* hip_stream);
    library behind a producer, or a consumer behind the library, without a host synchronisation. */
 int ssw_ctx_wait_event(ssw_ctx* ctx, void* hip_event);
 int ssw_ctx_record_event(ssw_ctx* ctx, void* hip_event);
-/* Frames processed per internal pass of the batch entry points (bounds the workspace: 36 bytes per
-   pixel of a pass in the default GEMM strategy, per lane -- see ssw_ctx_set_overlap).  0 = automatic, the
-   default: about 2^30 pixels per pass (128 4K frames, 514 full-HD frames, 32 8K frames; 38.7 GB of
+/* Frames processed per internal pass of the batch entry points (bounds the workspace: up to 44 bytes per
+   pixel of a pass in the default GEMM strategy, per lane -- four f32 planes, row and column operand planes side
+   by side since the fused forward transform, the inverse's A1 / T2 / E; see ssw_ctx_set_overlap).  0 = automatic, the
+   default: about 2^30 pixels per pass (128 4K frames, 514 full-HD frames, 32 8K frames; up to 47 GB of
    workspace per lane): sized for the 288 GB of an MI355X, where longer GEMM launches amortise their tails
    (2^28 pixels cost 2.8 % at 4K, 1.8 % at full HD).  The automatic size never asks for more than half of what
    the device can give at the time of the call (free memory + what the context already holds): a smaller device
@@ -228,6 +229,12 @@ int ssw_ctx_set_odd_split(ssw_ctx* ctx, int enable);
      band_split (1)        single-image handles: row pass of the top half beside the upload of the bottom half
      fuse_cols (1)         forward transform: the row GEMMs' epilogue writes the column operands (no f32 plane between the passes)
      fuse_inv_cols (0)     inverse transform: the same (bit-identical, 8 B/px less traffic, measured no faster: off)
+     upload_bands (3)      single-image handles: bands of rows a host frame is uploaded and row-transformed in (2 .. 4)
+     speculate_k (1)       Reader::base queues its selection for the mark length of the context's last extraction
+     prep_light (1)        level-2 RGB row pre-pass in the < 64-VGPR form that fits beside GEMM blocks (0: the register-resident kernel)
+     lane_stagger (1)      two lanes: an RGB pre-pass waits for the other lane's row launches and runs beside its column launches
+     derived_fused (1)     the derived frame's pruned row pass in one kernel (0: pre-pass + gathered launches)
+     inv_prep_light (0)    inverse row pre-pass at level 2 with whole rows through LDS (bit-identical, measured no faster: off)
    An entry never set reads its SSW_<NAME> environment variable at first use (the r4 behaviour), else the default.
    ssw_tuning_set takes effect for the calls that follow; workspaces and cached plans of existing contexts were sized
    under the old values, so change a value before creating the context that should see it (tests use a fresh context).

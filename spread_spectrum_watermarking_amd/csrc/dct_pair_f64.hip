@@ -44,6 +44,11 @@ namespace ssw {
 __device__ unsigned long long* g_tile_trace = nullptr;
 __device__ unsigned int g_tile_trace_cap = 0;
 __device__ unsigned int g_tile_trace_n = 0;
+__device__ unsigned int* g_tile_kstep = nullptr;        // [cap][32] per-k-step stamps (tools/tile_trace.py --ksteps)
+extern "C" int ssw_debug_set_tile_kstep(void* dev_ptr) {
+    unsigned int* p = static_cast<unsigned int*>(dev_ptr);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_kstep), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
 extern "C" int ssw_debug_set_tile_trace(void* dev_ptr, unsigned cap) {
     unsigned long long* p = static_cast<unsigned long long*>(dev_ptr);
     unsigned zero = 0;
@@ -58,10 +63,10 @@ extern "C" int ssw_debug_get_tile_trace_count(unsigned* n) {
 }  // namespace ssw
 #endif
 #include "dct_pair_f64_kernel.hpp"
-#ifdef SSW_TILE_TRACE
+#if defined(SSW_TILE_TRACE) && !defined(SSW_TILE_TRACE_FWD_ONLY)
 #define SSW_INV_PART -1
 #include "dct_pair_f64_inv.inc"      // the diagnostic build keeps one unit (one set of trace globals)
-#endif
+#endif                               // (-DSSW_TILE_TRACE_FWD_ONLY: only the forward instances trace; the inverse ones come from the normal objects: 3 min instead of 9)
 
 namespace ssw {
 
@@ -194,6 +199,10 @@ static bool launch_is_small(size_t lines, size_t pairs) {
 bool dct_pair_can_fuse_cols(size_t n_frames, size_t w, size_t h) {
     if (tuning(TUNE_FUSE_COLS) == 0 || n_frames == 0 || w < h || w % 128 != 0 || h % 16 != 0) return false;
     if (dct_pair_class_tile(w) != 128 || !dct_pair_efold(w) || !dct_pair_efold_cols(h, w, true)) return false;
+    // ... and the column pass must reach its deep branch by itself (build_pass_impl: two && split && deep): with the public
+    // thresholds lowered (ssw_tuning_set: deep_min_cols, efold_cols_min) below 128 rows it would not, and would read an f32
+    // plane the fused row pass never wrote
+    if (!dct_pair_can_split(h, false) || !dct_pair_can_fold2_cols(h)) return false;
     const size_t hup = dct_pair_fused_units(h);
     if (pair_kpad<double>(h / 8) != hup) return false;
     if (n_frames * 16 * hup > 0xFFFFFFFFull || n_frames * w > 0xFFFFFFFFull) return false;      // 32-bit line indices in both passes
@@ -206,6 +215,7 @@ bool dct_pair_can_fuse_cols(size_t n_frames, size_t w, size_t h) {
 bool dct_pair_can_fuse_inv_cols(size_t n_frames, size_t w, size_t h) {
     if (tuning(TUNE_FUSE_INV_COLS) == 0 || n_frames == 0 || w < h || w % 128 != 0 || h % 16 != 0) return false;
     if (dct_pair_class_tile(w) != 128 || !dct_pair_efold_inv(w) || !dct_pair_efold_cols(h, w, true)) return false;
+    if (!dct_pair_can_split(h, false) || !dct_pair_can_fold2_cols(h)) return false;      // as above
     const size_t hup = dct_pair_fused_units(h);
     if (pair_kpad<double>(h / 8) != hup) return false;
     if (n_frames * 16 * hup > 0xFFFFFFFFull || n_frames * w > 0xFFFFFFFFull) return false;
@@ -263,6 +273,7 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     ml.n_classes = (unsigned)n_classes; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
+    ml.stagger = nblk > 1024 ? (unsigned)tuning(TUNE_GEMM_STAGGER) : 0u;
     PairOut po{out, tmp, (unsigned)w, (unsigned)h, (unsigned)(inverse ? leff0 : len), 0, 1, 2};
     po.tmp_out = tmp_out;
     if (class_major && inverse && desc[0].kind >= 3 && desc[0].kind <= 8) { po.cm = dct_pair_efold_inv(len) ? 2u : 1u; po.cmt = dct_pair_class_tile(len); }

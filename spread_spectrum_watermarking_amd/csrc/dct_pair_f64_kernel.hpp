@@ -49,8 +49,13 @@ constexpr int PBK = 8;
 #ifdef SSW_TILE_TRACE
 // diagnostic build only (tools/tile_trace.py): the trace globals are defined by dct_pair_f64.hip before this header
 #define SSW_TT(i) do { if (threadIdx.x == 0) tt[i] = wall_clock64(); } while (0)
+// ... and per k-step (the barrier in the middle of step t has been passed): 32-bit wall-clock stamps of up to 32 steps per tile
+// (into LDS: a global store -- and the load of the trace pointer -- inside the loop made the compiler drain the loop's prefetch
+// with vmcnt(0) at every step and doubled the main loop; trace_end copies them out)
+#define SSW_KT(t) do { if (threadIdx.x == 0 && (t) < 32u) kst_lds[t] = (unsigned)wall_clock64(); } while (0)
 #else
 #define SSW_TT(i) do { } while (0)
+#define SSW_KT(t) do { } while (0)
 #endif
 typedef PairOutT<double> PairOut;
 
@@ -76,6 +81,7 @@ struct PairClassArgs {
 struct PairMulti {
     PairClassArgs c[8];
     unsigned n_classes, L, tiles_m, tiles_n_total;
+    unsigned stagger = 0;              // r6 A/B (tuning: gemm_stagger): blocks 256 .. 511 sleep this many x 8128 cycles before their tile
     PairOut po;                        // the fields the classes share; c1 .. bn32 are overwritten per class
 };
 
@@ -86,14 +92,26 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     // operand tiles [buffer][product][rows * 8]; a column pass reuses the region to transpose its results (epilogue)
     constexpr int SXD = 2 * NX * BM * PBK, SYD = 2 * 2 * BN * PBK;
     constexpr int TRD = COLS ? 4 * 32 * (BM / 2 + 16) / 2 : 0;              // 4 waves x 32 result rows x pitch floats
+#ifdef SSW_TILE_TRACE
+    __shared__ __attribute__((aligned(16))) double lds[(SXD + SYD > TRD ? SXD + SYD : TRD) + 16];
+    unsigned* kst_lds = reinterpret_cast<unsigned*>(lds + (SXD + SYD > TRD ? SXD + SYD : TRD));
+#else
     __shared__ __attribute__((aligned(16))) double lds[SXD + SYD > TRD ? SXD + SYD : TRD];
+#endif
     double (*sX)[NX][BM * PBK] = reinterpret_cast<double (*)[NX][BM * PBK]>(lds);
     double (*sY)[2][BN * PBK] = reinterpret_cast<double (*)[2][BN * PBK]>(lds + SXD);
 
 #ifdef SSW_TILE_TRACE
     unsigned long long tt[5] = {0, 0, 0, 0, 0};
     const unsigned long long cyc0 = clock64();
+    unsigned kslot = 0xFFFFFFFFu;
+    if (threadIdx.x == 0 && g_tile_trace) kslot = atomicAdd(&g_tile_trace_n, 1u);
 #endif
+    // the two blocks of a CU that start a launch together keep meeting in their epilogues (their phase difference is
+    // preserved from tile to tile); a launch-time offset for the second residents lets one block's epilogue and prologue run
+    // under the other's main loop
+    if (ml.stagger && blockIdx.x >= 256u && blockIdx.x < 512u)
+        for (unsigned i = 0; i < ml.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     SSW_TT(0);
     unsigned tm, tn;
     tile_of_block(blockIdx.x, gridDim.x, ml.tiles_m, ml.tiles_n_total, tm, tn);
@@ -134,8 +152,13 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     const unsigned yoff = ((yr - p0) * 8 + 2 * sc) * 8u;
     // block-uniform buffer resources (scalar registers) at the tile's first line of k-block 0; a k-step
     // advances a scalar byte offset by one k-block (< 4 GB: checked by the launcher)
-    const __amdgpu_buffer_rsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc((void*)(X1g + (size_t)m0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
-    const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void*)(X2g + (size_t)m0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
+#ifdef SSW_ABL_X0          // timing-only ablation: every block stages the lines of tile 0 (L2-resident): what the operands' memory latency costs
+    const size_t m0x = 0;
+#else
+    const size_t m0x = m0;
+#endif
+    const __amdgpu_buffer_rsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc((void*)(X1g + m0x * 8), 0, 0xFFFFFFFFu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void*)(X2g + m0x * 8), 0, 0xFFFFFFFFu, 0x00020000);
     const __amdgpu_buffer_rsrc_t y1r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y1g + (size_t)p0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
     const __amdgpu_buffer_rsrc_t y2r = __builtin_amdgcn_make_buffer_rsrc((void*)(Y2g + (size_t)p0 * 8), 0, 0xFFFFFFFFu, 0x00020000);
     const unsigned xstep = L * 64u, ystep = yrows * 64u;
@@ -276,6 +299,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
         gload(t + 2);
         interleave(B1{});
         __syncthreads();
+        SSW_KT(t);
         fread(nxtc, B0{}, fa);
         fmma(fb);
         interleave(B0{});
@@ -321,6 +345,10 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
         fmma(fb);
     }
     SSW_TT(2);
+#ifdef SSW_ABL_NOEPI       // timing-only ablation: no epilogue (one store keeps the accumulators alive)
+    if (acc1[0][0][0] + acc2[NI - 1][NJ - 1][3] == 1.2345e300) po.out[0] = 1.f;
+    return;
+#endif
 
 #ifdef SSW_TILE_TRACE
     auto trace_end = [&]() {
@@ -330,7 +358,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     __builtin_amdgcn_s_waitcnt(0);
     if (threadIdx.x == 0 && g_tile_trace) {
         tt[3] = wall_clock64();
-        const unsigned slot = atomicAdd(&g_tile_trace_n, 1u);
+        const unsigned slot = kslot;
         if (slot < g_tile_trace_cap) {
             unsigned hwid = 0, xcc = 0;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
@@ -342,6 +370,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
             o[6] = ((unsigned long long)Kp << 32) | NP;
             o[5] |= ((clock64() - cyc0) & 0xFFFFFFFull) << 36;     // shader cycles of the block (28 bits) above the tag
             o[7] = tt[4];
+            if (g_tile_kstep)
+                for (unsigned i = 0; i < 32u; ++i) g_tile_kstep[32ull * slot + i] = kst_lds[i];
         }
     }
     };

@@ -77,6 +77,10 @@ struct StageTimer {
     StageTimer& operator=(const StageTimer&) = delete;
 };
 int flush_timers(ssw_ctx* ctx);
+// Anything that is enqueued outside a StageTimer -- an event wait or record, an unbracketed launch or copy -- ends the sharing
+// of the last timer's end event (ssw_pipeline.hip: timer_event): the next stage records its own start behind it and is not
+// billed for it (a lane's hop to the other stream is a hipStreamWaitEvent: shared, it counted the dependency stall as stage time).
+inline void untimed_work(ssw_ctx* ctx) { if (ctx) ctx->tail_fresh = false; }
 
 // kind 0 = dense N x N, 1 / 2 = even / odd half basis, 3 / 4 = the same, k-blocked (operand-ready GEMMs)
 int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const void** out);

@@ -106,6 +106,7 @@ int rgb_spare_take(ssw_ctx* ctx, size_t bytes, void** p, hipEvent_t* ev, bool* f
 void rgb_spare_give(ssw_ctx* ctx, void* p, size_t bytes, hipEvent_t ev) {
     if (!p) { if (ev) (void)hipEventDestroy(ev); return; }
     if (ev && ctx->rgb_spares.size() < RGB_SPARES_MAX && hipEventRecord(ev, ctx->stream) == hipSuccess) {
+        untimed_work(ctx);
         ctx->rgb_spares.push_back({p, bytes, ev});
         return;
     }
@@ -129,11 +130,13 @@ int stage_frame_in(ssw_ctx* ctx, const void* host, size_t bytes, ssw_ctx::FrameS
     SSW_TRY(upload(ctx, fs.buf.p, host, bytes, ctx->copy_stream));
     SSW_HIP_CHECK(hipEventRecord(fs.uploaded[0], ctx->copy_stream));
     SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, fs.uploaded[0], 0));
+    untimed_work(ctx);
     *out = &fs;
     return SSW_OK;
 }
 int stage_consumed(ssw_ctx* ctx, ssw_ctx::FrameStage& fs) {
     SSW_HIP_CHECK(hipEventRecord(fs.consumed, ctx->stream));
+    untimed_work(ctx);
     fs.in_use = true;
     return SSW_OK;
 }
@@ -172,6 +175,7 @@ int forward_from_host(ssw_ctx* ctx, const void* host_rgb, int u8, size_t w, size
                 in_flight = in_flight || async;
                 if (rc == SSW_OK && hipEventRecord(fs.uploaded[band], ctx->copy_stream) != hipSuccess) rc = SSW_ERR_HIP;
                 if (rc == SSW_OK && hipStreamWaitEvent(ctx->stream, fs.uploaded[band], 0) != hipSuccess) rc = SSW_ERR_HIP;
+                untimed_work(ctx);                  // the band's first stage starts its timer behind the wait for its upload
                 if (rc != SSW_OK) break;
                 Chain ch;
                 rc = build_forward_rows_band(ctx, ctx->lane[0], precision, (char*)fs.buf.p + band * hb, u8, w, rows, h, tmp + band * hp,
@@ -982,6 +986,7 @@ static int reader_create_impl(ssw_ctx* ctx, const void* rgb_hwc, int u8, size_t 
         if (rc != SSW_OK) return fail(rc);
         if (hipEventRecord(rd->rgb_uploaded, ctx->copy_stream) != hipSuccess ||
             hipStreamWaitEvent(ctx->stream, rd->rgb_uploaded, 0) != hipSuccess) return fail(SSW_ERR_HIP);
+        untimed_work(ctx);
         *out = rd;
         return SSW_OK;
     }

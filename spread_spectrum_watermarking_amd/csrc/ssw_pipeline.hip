@@ -119,6 +119,7 @@ int grow_select(hipStream_t st, SelectWorkspace& s, size_t frames, size_t k) {
     SSW_ALLOC(&s.cand, nf * cap * sizeof(uint64_t));
     SSW_HIP_CHECK(hipMemsetAsync(s.hist, 0, nf * 2048 * sizeof(uint32_t), st));   // see select.hip:
     SSW_HIP_CHECK(hipMemsetAsync(s.ctrl, 0, nf * 4 * sizeof(uint32_t), st));      // zero between uses
+    untimed_work(tl_ctx);
     s.frames = nf;
     s.cap = cap;
     return SSW_OK;
@@ -128,8 +129,10 @@ int grow_select(hipStream_t st, SelectWorkspace& s, size_t frames, size_t k) {
 // nothing enqueued in between: the stages of a chain, a "main launch" timer nested at the start or the end of its pass --
 // takes the event that is already in the stream instead of recording a second one.  An event record is a barrier in the
 // queue (~3 us during which the next kernel cannot overlap the previous one's tail): a single-frame embed had 28 of them in
-// 0.6 ms of kernels.  ctx->tail_event is the last event recorded by a timer, valid while ctx->tail_fresh (cleared by every
-// launch helper that is not bracketed by a timer: see untimed_work(); reset at every entry into the library).
+// 0.6 ms of kernels.  ctx->tail_event is the last event recorded by a timer, valid while ctx->tail_fresh: cleared by the next
+// timer's own launches, by untimed_work() (ssw_host.hpp) -- called wherever something is enqueued outside a timer: the lanes'
+// hops / done records / stagger waits, the pruned transform's table launches, basis generation, workspace memsets, copies,
+// the upload / download hand-offs of the handle and streaming entry points -- and at every entry into the library.
 static hipEvent_t timer_event(ssw_ctx* ctx, hipStream_t st) {
     if (ctx->tail_event && ctx->tail_fresh && ctx->tail_stream == st) return ctx->tail_event;
     hipEvent_t e = nullptr;
@@ -202,6 +205,7 @@ int get_basis(ssw_ctx* ctx, size_t n, bool inverse, bool f64, int kind, const vo
                               : launch_make_half_basis_f32(ctx->stream, n, inverse, kind - 1, (float*)p))
              : f64     ? launch_make_basis_f64(ctx->stream, n, inverse, (double*)p)
                        : launch_make_basis_f32(ctx->stream, n, inverse, (float*)p);
+    untimed_work(ctx);
     if (rc != SSW_OK) { (void)hipFree(p); return rc; }
     ctx->basis[key] = p;
     *out = p;
@@ -309,7 +313,9 @@ static size_t merge_max_lines() {
 // Can the column pre-pass of an `fh`-row plane read the class-major order a deep row pass leaves (dct_pair_common.hpp)?  The
 // deep kernels all can; of the semi-deep ones (fh % 16 == 8: 1080 rows) only the LDS-staged forms.
 static bool cols_read_class_major(size_t fh, size_t w) {
-    return dct_pair_can_fold2_cols(fh) && (dct_pair_can_deep_cols(fh) || (dct_pair_can_semi_deep_cols(fh) && dct_pair_prep_staged_cols_ok(w, true)));
+    // (dct_pair_can_split: the column pass reaches its deep / semi-deep branch only through the split -- fh >= 128 whatever the thresholds say)
+    return dct_pair_can_fold2_cols(fh) && dct_pair_can_split(fh, false) &&
+           (dct_pair_can_deep_cols(fh) || (dct_pair_can_semi_deep_cols(fh) && dct_pair_prep_staged_cols_ok(w, true)));
 }
 
 // One pass of the separable transform (src -> dst along rows or columns) appended to `ch`.
@@ -1070,6 +1076,7 @@ int next_sync_event(ssw_ctx* ctx, hipEvent_t* out) {
 int mark_done(ssw_ctx* ctx, ssw_ctx::Lane& ln) {
     SSW_TRY(next_sync_event(ctx, &ln.done));
     SSW_HIP_CHECK(hipEventRecord(ln.done, ln.cur));
+    untimed_work(ctx);
     return SSW_OK;
 }
 
@@ -1077,6 +1084,7 @@ int mark_done(ssw_ctx* ctx, ssw_ctx::Lane& ln) {
 int hop(ssw_ctx* ctx, ssw_ctx::Lane& ln, hipStream_t to) {
     if (ln.cur == to) return SSW_OK;
     if (ln.done) SSW_HIP_CHECK(hipStreamWaitEvent(to, ln.done, 0));
+    untimed_work(ctx);                             // the next stage's timer starts behind the wait, not in front of it
     ln.cur = to;
     return SSW_OK;
 }
@@ -1098,6 +1106,7 @@ int run_pipeline_impl(ssw_ctx* ctx, size_t n_chunks, bool two, const std::functi
         SSW_TRY(next_sync_event(ctx, &ev));
         SSW_HIP_CHECK(hipEventRecord(ev, G));
         SSW_HIP_CHECK(hipStreamWaitEvent(H, ev, 0));
+        untimed_work(ctx);
     }
     Chain chain[ssw_ctx::MAX_LANES];
     size_t at[ssw_ctx::MAX_LANES] = {0, 0};
@@ -1133,6 +1142,7 @@ int run_pipeline_impl(ssw_ctx* ctx, size_t n_chunks, bool two, const std::functi
                 const int o = 1 - l;
                 if (active[o] && at[o] > 0 && chain[o][at[o] - 1].tag == 1 && ctx->lane[o].done)
                     SSW_HIP_CHECK(hipStreamWaitEvent(ctx->lane[l].cur, ctx->lane[o].done, 0));
+                untimed_work(ctx);
             }
             SSW_TRY(s.run(ctx->lane[l].cur));
             if (two) SSW_TRY(mark_done(ctx, ctx->lane[l]));
@@ -1147,7 +1157,18 @@ int run_pipeline(ssw_ctx* ctx, size_t n_chunks, const std::function<int(size_t, 
     if (n_chunks == 0) return SSW_OK;
     // two lanes pay from three chunks on (with two, each lane would run a single chunk: measured equal to one lane)
     const bool two = pipeline_uses_two_lanes(ctx, n_chunks);
-    const int rc = run_pipeline_impl(ctx, n_chunks, two, build);
+    int rc = run_pipeline_impl(ctx, n_chunks, two, build);
+    if (rc == SSW_ERR_OUT_OF_MEMORY && !ctx->retired.empty()) {
+        // Workspaces that grew during this call left their old allocations retired (grow(): stages already built may hold
+        // them), so the call's peak was old + new.  Everything enqueued so far is complete after the waits below and nothing
+        // built is still to run: give the retired buffers back and run the chunks again (same kernels, same outputs).
+        if (two) (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        for (void* p : ctx->retired) (void)hipFree(p);
+        ctx->retired.clear();
+        untimed_work(ctx);
+        rc = run_pipeline_impl(ctx, n_chunks, two, build);
+    }
     if (rc != SSW_OK && two) {
         // a failing stage (out of memory inside grow(), most likely) must not leave the second stream running
         // behind the caller's back: the lanes' buffers are reused by the next call on the context's stream
@@ -1369,6 +1390,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
             std::array<DerivedFusedClass, 9> fca;
             for (unsigned c = 0; c < 9; ++c) fca[c] = fc[c < ncl ? c : 0];
             ch.push_back({true, [=](hipStream_t st) -> int {
+                untimed_work(ctx);
                 SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
                 return launch_prune_gather_bases(st, gather_jobs(true));
             }});
@@ -1388,6 +1410,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     // the set of columns, then Reader::derived's colour conversion + operand pre-pass (same kernels as the full path)
     ch.push_back({true, [=](hipStream_t st) -> int {
         SSW_TRY(launch_prune_build(st, idx, n, k, plan, flag, rows, pos, info));
+        untimed_work(ctx);
         StageTimer t(ctx, SSW_STAGE_RGB_TO_YIQ, st, prep_bytes);
         if (deep) return launch_dct_pair_prep16_rows(st, pix_src_kind(u8), rgb, n, w, h, sp, (const double*)rot, (const double*)rot2,
                                                      (const double*)rot3, nullptr, nullptr);
@@ -1398,6 +1421,7 @@ int build_pruned_derived(ssw_ctx* ctx, ssw_ctx::Lane& ws, int precision, const v
     ch.back().tag = 2;
     ch.push_back({false, [=](hipStream_t st) -> int {
         SSW_TRY(launch_prune_gather_bases(st, gather_jobs(false)));
+        untimed_work(ctx);
         StageTimer t(ctx, SSW_STAGE_DCT_ROW, st, flop);
         t.traffic(px * (double)esz + (double)lines * (double)cap * 4.0);      // every operand plane once in, the compact plane out
         if (f64 && lines <= (size_t)tuning(TUNE_MERGE_MAX_LINES)) {          // a single frame: the classes side by side in one launch per kind
@@ -1456,7 +1480,7 @@ int batch_embed_impl(ssw_ctx* ctx, const ssw_config* cfg, const void* dev_rgb, i
         SelectWorkspace* sel = &ws.sel;
         SSW_TRY(build_forward_from_rgb(ctx, ws, c.precision, rgb, u8_in, n, w, h, y, pi, pq, tmp, ch));   // Writer::new :308-313
         ch.push_back({true, [=](hipStream_t st) -> int {
-            if (coef_out) SSW_HIP_CHECK(hipMemcpyAsync(coef_out, y, n * plane * sizeof(float), hipMemcpyDeviceToDevice, st));
+            if (coef_out) { SSW_HIP_CHECK(hipMemcpyAsync(coef_out, y, n * plane * sizeof(float), hipMemcpyDeviceToDevice, st)); untimed_work(ctx); }
             if (k_eff == 0) return SSW_OK;
             SSW_TRY(topk(ctx, st, *sel, y, n, w, h, c.ordering, k_eff, idx));                              // :314 (first k only)
             StageTimer t(ctx, SSW_STAGE_EMBED, st);                                                       // :356

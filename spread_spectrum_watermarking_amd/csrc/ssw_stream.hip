@@ -118,8 +118,10 @@ int stream_embed_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* const*
             const size_t f0 = groups[g].f0, n = groups[g].n;
             SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, hs.up_done[s], 0));
             if (g >= (size_t)NB) SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, hs.down_done[s], 0));   // download of group g - NB reads out[s]
+            untimed_work(ctx);                 // the group's first stage timer starts behind these waits
             SSW_TRY(batch_embed_impl(ctx, cfg, hs.in[s].p, SSW_PIX_U8, n, w, h, (const float*)hs.marks.p + f0 * k, k, hs.out[s].p, true, nullptr, nullptr));
             SSW_HIP_CHECK(hipEventRecord(hs.k_done[s], ctx->stream));
+            untimed_work(ctx);
             if (g + NB - 1 < n_groups) SSW_TRY(h2d(g + NB - 1));      // staged (pageable) frames: the host copies while group g computes
             // the download of group g - 1 is issued AFTER the kernels of group g: a pageable output buffer makes
             // download_nowait a blocking staged copy, and the device must have its next group queued before the host sleeps
@@ -173,9 +175,11 @@ int stream_extract_rgb8(ssw_ctx* ctx, const ssw_config* cfg, const uint8_t* cons
             // looks at its overflow flags once at its end (one host wait per group) -- PCIe keeps running through it
             if (g + NB - 1 < n_groups) SSW_TRY(h2d(g + NB - 1));
             SSW_HIP_CHECK(hipStreamWaitEvent(ctx->stream, hs.up_done[s], 0));
+            untimed_work(ctx);
             SSW_TRY(batch_extract_impl(ctx, cfg, hs.in[s].p, hs.in2[s].p, SSW_PIX_U8, n, w, h, k, (float*)hs.ext.p + f0 * k,
                                        host_marks ? (const float*)hs.marks.p + f0 * k : nullptr, host_sims ? (float*)hs.sims.p + f0 : nullptr));
             SSW_HIP_CHECK(hipEventRecord(hs.k_done[s], ctx->stream));
+            untimed_work(ctx);
         }
         SSW_HIP_CHECK(hipStreamWaitEvent(ctx->down_stream, hs.k_done[(n_groups - 1) % NB], 0));
         if (k) SSW_TRY(download_nowait(ctx, host_extracted, hs.ext.p, n_frames * k * sizeof(float), ctx->down_stream, &as));

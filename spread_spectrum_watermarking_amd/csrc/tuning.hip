@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "ssw_internal.hpp"
 
@@ -39,19 +40,27 @@ Entry g_tune[TUNE_COUNT] = {
     {"lane_stagger", "SSW_LANE_STAGGER", 1},           // two lanes: RGB pre-passes beside the other lane's column launches, not its row launches (r5: +0.7 %)
     {"derived_fused", "SSW_DERIVED_FUSED", 1},         // the derived frame's pruned row pass in one kernel (marks of up to 1024 entries; 0: pre-pass + launches)
     {"inv_prep_light", "SSW_INV_PREP_LIGHT", 0},       // inverse row pre-pass at level 2: whole rows through LDS, one lane per unit (r5 A/B)
+    {"gemm_stagger", "SSW_GEMM_STAGGER", 0},           // r6 A/B: the GEMM blocks 256 .. 511 of a launch (the CUs' second residents) start this many ~3.4-us sleeps late
 };
+
+// value and state change together under this lock (first read from the environment, set, reset); the fast path of a reader
+// is one acquire load of a state that is no longer 0.  (a reader that had seen state 0 stored the environment's
+// value unconditionally and could overwrite a concurrent ssw_tuning_set.)
+std::mutex g_tune_lock;
 
 }  // namespace
 
 long long tuning(int which) {
     Entry& e = g_tune[which];
     if (e.state.load(std::memory_order_acquire) == 0) {
-        const char* s = std::getenv(e.env);
-        long long v = s ? std::atoll(s) : e.dflt;
-        if (which == TUNE_BAND_SPLIT && std::getenv("SSW_NO_SPLIT")) v = 0;      // the r3 name of the switch
-        e.value.store(v, std::memory_order_relaxed);
-        int expect = 0;
-        e.state.compare_exchange_strong(expect, 1, std::memory_order_release);
+        std::lock_guard<std::mutex> lk(g_tune_lock);
+        if (e.state.load(std::memory_order_relaxed) == 0) {
+            const char* s = std::getenv(e.env);
+            long long v = s ? std::atoll(s) : e.dflt;
+            if (which == TUNE_BAND_SPLIT && std::getenv("SSW_NO_SPLIT")) v = 0;      // the r3 name of the switch
+            e.value.store(v, std::memory_order_relaxed);
+            e.state.store(1, std::memory_order_release);
+        }
     }
     return e.value.load(std::memory_order_relaxed);
 }
@@ -64,6 +73,7 @@ int ssw_tuning_set(const char* name, long long value) {
     if (!name) return SSW_ERR_BAD_ARG;
     for (int i = 0; i < ssw::TUNE_COUNT; ++i)
         if (std::strcmp(ssw::g_tune[i].name, name) == 0) {
+            std::lock_guard<std::mutex> lk(ssw::g_tune_lock);
             ssw::g_tune[i].value.store(value, std::memory_order_relaxed);
             ssw::g_tune[i].state.store(2, std::memory_order_release);
             return SSW_OK;
@@ -81,6 +91,7 @@ int ssw_tuning_get(const char* name, long long* value) {
 int ssw_tuning_reset(const char* name) {
     for (int i = 0; i < ssw::TUNE_COUNT; ++i)
         if (!name || std::strcmp(ssw::g_tune[i].name, name) == 0) {
+            std::lock_guard<std::mutex> lk(ssw::g_tune_lock);
             ssw::g_tune[i].state.store(0, std::memory_order_release);
             if (name) return SSW_OK;
         }

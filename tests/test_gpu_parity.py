@@ -7,7 +7,7 @@ Bars (BASELINE.json north star):
     correctly rounded transform, the rest within 1 ulp-scale (2e-7 of the plane's AC max).
   * DCT, f32 MFMA precision: <= 1e-6 of the plane's largest coefficient (the DC term; measured
     <= 3.3e-7.  The reference's own tests use 1e-4 abs on inputs whose DC is 12..47, i.e. ~2e-6).
-  * extracted marks: <= 1e-5 relative (canonical); f32 precision: median <= 1e-5, max <= 2e-3
+  * extracted marks: per element |d_i| <= 1e-5 * max(1, |ref_i|) (canonical; _ext_within_1e5); f32 precision: median <= 1e-5, max <= 2e-3
     (an f32 FFT such as rustdct's sits at median 1e-6 / max 1.6e-4 from the exact transform, see
     DESIGN.md "Numerics"); similarity delta < 1e-4 in both.
 """
@@ -29,6 +29,14 @@ F32, F64 = L.PRECISION_F32, L.PRECISION_F64
 # precisions of the default test run: f64 (the parity path); f32 joins when the diagnostic build with its operand-ready twin is loaded
 # (in the default library SSW_PRECISION_F32 runs the dense kernels: covered by the known-answer and single_simple tests below)
 PRECISIONS = [F32, F64] if ALL_STRATEGIES else [F64]
+
+
+def _ext_within_1e5(ext, ref):
+    """north_star's bar on extracted marks, per element: |ext_i - ref_i| <= 1e-5 * max(1, |ref_i|) (relative f32 where the
+    element is above 1 in magnitude, absolute 1e-5 below -- marks are N(0, 1) samples, so most elements are below 1)."""
+    ext, ref = np.asarray(ext, np.float64), np.asarray(ref, np.float64)
+    return bool(np.all(np.abs(ext - ref) <= 1e-5 * np.maximum(1.0, np.abs(ref))))
+
 
 
 def ac_max(plane):
@@ -509,7 +517,7 @@ def test_canonical_pipeline_matches_oracle(marks, cat_images):
     assert np.array_equal(reader.indices(1000), O.indices(ref_coef, k=1000))
     ext = reader.extract(wm.Reader.derived(res, precision=F64), 1000)
     ref_ext, ref_sim = O.extract_frame(cat, ref_res, mark)
-    assert np.abs(ext - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert _ext_within_1e5(ext, ref_ext)
     assert abs(wm.Tester(ext).similarity(mark).similarity - ref_sim) < 1e-4
 
 
@@ -696,7 +704,7 @@ def test_full_hd_pipeline_parity_with_oracle():
     assert np.abs(res["rgb"][0] - ref_marked).max() <= 2e-7 and np.mean(res["rgb"][0] == ref_marked) > 0.999
     ext, sims = G.batch_extract(rgb, res["rgb"], k, mark)
     ref_ext, ref_sim = O.extract_frame(rgb[0], ref_marked, mark[0])
-    assert np.abs(ext[0] - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert _ext_within_1e5(ext[0], ref_ext)
     assert abs(float(sims[0]) - ref_sim) < 1e-4
 
 
@@ -741,13 +749,13 @@ def _whole_pipeline_vs_oracle(w, h, k, seed, frame):
     assert np.abs(res["rgb"][0] - ref_marked).max() <= 2e-7 and np.mean(res["rgb"][0] == ref_marked) > 0.999
     ext, sims = G.batch_extract(rgb, res["rgb"], k, mark)
     ref_ext, ref_sim = O.extract_frame(rgb[0], ref_marked, mark[0])
-    assert np.abs(ext[0] - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert _ext_within_1e5(ext[0], ref_ext)
     assert abs(float(sims[0]) - ref_sim) < 1e-4
     # the oracle's own marked frame as the derived input: identical inputs on both sides, so extraction is
     # bit-exact wherever the 2 k coefficients it reads are (a canonical-precision coefficient differs from the
     # oracle's by one ulp with probability ~1e-6: allow a handful, each worth <= ulp / alpha in the mark)
     ext_o, sims_o = G.batch_extract(rgb, ref_marked[None], k, mark)
-    assert np.mean(ext_o[0] == ref_ext) >= 0.999 and np.abs(ext_o[0] - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert np.mean(ext_o[0] == ref_ext) >= 0.999 and _ext_within_1e5(ext_o[0], ref_ext)
     assert abs(float(sims_o[0]) - ref_sim) < 1e-5 * abs(ref_sim)
     return rgb, mark, res
 
@@ -769,7 +777,7 @@ def _frame_vs_oracle(rgb, mark, coef, idx, marked, ext, sim):
     ref_marked = O.embed_frame(rgb, mark)
     assert np.abs(marked - ref_marked).max() <= 2e-7 and np.mean(marked == ref_marked) > 0.999
     ref_ext, ref_sim = O.extract_frame(rgb, ref_marked, mark)
-    assert np.abs(ext - ref_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(ref_ext)).max()
+    assert _ext_within_1e5(ext, ref_ext)
     assert abs(float(sim) - ref_sim) < 1e-4
 
 
@@ -881,7 +889,7 @@ def test_natural_image_at_level2_shapes_matches_the_oracle(shape, cat_images, ma
     # identical 8-bit inputs on both sides: the oracle's own marked frame as the derived image
     ext, sims = G.batch_extract_rgb8(img[None], o_wm8[None], k, mark)
     o_ext, o_sim = O.extract_frame(frame, u8_to_f32(o_wm8), mark[0])
-    assert np.mean(ext[0] == o_ext) >= 0.999 and np.abs(ext[0] - o_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(o_ext)).max()
+    assert np.mean(ext[0] == o_ext) >= 0.999 and _ext_within_1e5(ext[0], o_ext)
     assert abs(float(sims[0]) - o_sim) < 1e-5 * abs(o_sim) + 1e-5
     # the f32 entry points on the same frame: coefficients and the index list
     res = G.batch_embed(frame[None], mark, want_coef=True, want_idx=True)
@@ -917,7 +925,7 @@ def test_8k_pipeline_and_resize_attack_parity_with_oracle():
     ext, sims = G.batch_extract_rgb8(frame8[None], o_back[None], k, mark)
     o_ext, o_sim = O.extract_frame(O.u8_to_f32(frame8), O.u8_to_f32(o_back), mark[0])
     # same 8-bit inputs on both sides: bit-exact extraction (up to the rare 1-ulp coefficient, see above)
-    assert np.mean(ext[0] == o_ext) >= 0.999 and np.abs(ext[0] - o_ext).max() <= 1e-5 * np.maximum(1.0, np.abs(o_ext)).max()
+    assert np.mean(ext[0] == o_ext) >= 0.999 and _ext_within_1e5(ext[0], o_ext)
     assert abs(float(sims[0]) - o_sim) < 1e-5 * abs(o_sim) + 1e-5
     # and the all-device flow from the device's own marked frame
     back_d = G.resize_rgb8(G.resize_rgb8(wm8[0], w // 8, h // 8), w, h)

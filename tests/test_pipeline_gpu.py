@@ -54,27 +54,27 @@ free0, _ = probe.mem_info()
 for _ in range(3):
     cycle()
 free1, _ = probe.mem_info()
-print("leaked_bytes", free0 - free1)
+for _ in range(3):
+    cycle()
+free2, _ = probe.mem_info()
+# a leak repeats with every cycle; a one-time allocation of the runtime (its pools grow on first use) shows in one window only
+print("leaked_bytes", min(free0 - free1, free1 - free2), "windows", free0 - free1, free1 - free2)
 """
 
 
 def test_context_create_destroy_releases_device_memory(tmp_path):
     """ssw_ctx_destroy frees every workspace buffer (operand planes, lanes, selection, bases, compact planes): three
     create / batch embed + extract / destroy cycles leave the device's free memory where it was.  In a fresh
-    process, so that other tests' contexts and the allocator's history do not blur the reading."""
+    process, so that other tests' contexts and the allocator's history do not blur the reading.  Two windows of three
+    cycles each, the smaller difference counts: what leaks per cycle shows in both, what the runtime allocates once for
+    itself (seen once on a fresh box in r5: the first window read >= 8 MiB, a repeat read 0) shows in one."""
     script = tmp_path / "leak_check.py"
     script.write_text(_LEAK_SCRIPT)
-    def attempt():
-        r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "leaked_bytes" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
-        return int(r.stdout.split("leaked_bytes")[1].split()[0])
-    try:
-        leaked = attempt()
-    except AssertionError:
-        leaked = 1 << 40
-    if leaked >= 8 << 20:      # the first GPU process on a fresh box has been seen to fail here once (driver-side first-use allocations): a leak repeats
-        leaked = attempt()
-    assert leaked < 8 << 20, f"device memory leaked across context cycles: {leaked / 2**20:.1f} MiB"
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    # no retry: a child that dies (rc != 0) is a failure of context teardown, whatever came before it
+    assert r.returncode == 0 and "leaked_bytes" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    leaked = int(r.stdout.split("leaked_bytes")[1].split()[0])
+    assert leaked < 8 << 20, f"device memory leaked across context cycles: {r.stdout[-300:]}"
 
 
 def test_alloc_failure_is_out_of_memory_and_recoverable():

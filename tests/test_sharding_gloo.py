@@ -69,6 +69,33 @@ def test_shard_frames_partition():
     assert bench.shard_frames(512, 8, 7) == (448, 512)        # 64 frames per GPU (configs[4])
 
 
+def test_launcher_counts_gpus_from_sysfs_without_a_hip_call(tmp_path, monkeypatch):
+    """VERDICT r5 #7b: the parent of `python bench.py --gpus N` must not open the device before it starts the ranks; it
+    counts KFD topology nodes with simd_count > 0 (CPU nodes have 0), narrowed by the visibility variables."""
+    sys.path.insert(0, ROOT)
+    import bench
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count {16 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    dri = tmp_path / "dri"
+    dri.mkdir()
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    assert bench.count_gpus_sysfs(str(nodes), str(dri)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.count_gpus_sysfs(str(nodes), str(dri)) == 2
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # no KFD topology (container without the driver's sysfs): render nodes as the fallback, none -> 0 -> the launcher refuses
+    empty = tmp_path / "none"
+    empty.mkdir()
+    assert bench.count_gpus_sysfs(str(empty), str(dri)) == 0
+    (dri / "renderD128").write_text("")
+    assert bench.count_gpus_sysfs(str(empty), str(dri)) == 1
+    import inspect
+    assert "device_count" not in inspect.getsource(bench.launch_ranks)
+
+
 def test_two_rank_gloo_run_equals_single_process(tmp_path):
     total, w, h, k, world = 5, 96, 64, 50, 2
     out = str(tmp_path / "sims.npy")
