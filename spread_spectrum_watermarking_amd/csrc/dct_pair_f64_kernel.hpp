@@ -46,6 +46,9 @@
 #endif
 // (the host pass never generates code for a kernel body, but it does check it: the LDS-DMA builtins and the s_waitcnt statements
 // made it drop the kernels' launch stubs without a word -- the host sees the register-staged body)
+#ifndef SSW_GEMM_NS
+#define SSW_GEMM_NS 2          // stages of the ring.  2: 48 KB of LDS per block, like the register-staged kernel, one k-step ahead; 3: 72 KB, two ahead -- measured equal (r6: rows 56.2-56.9 vs 56.4-56.5 ms, columns 43.5-43.7 vs 43.5-43.9 per 256 4K frames), so the smaller one
+#endif
 #if SSW_GEMM_DMA && defined(__HIP_DEVICE_COMPILE__)
 #define SSW_GEMM_DMA_DEV 1
 #else
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     // operand tiles [buffer][product][rows * 8]; a column pass reuses the region to transpose its results (epilogue)
 #if SSW_GEMM_DMA_DEV
     // r6: the tiles arrive by LDS-DMA (buffer_load ... lds) in a ring of NS stages [X1 | X2 | Y1 | Y2], two k-steps ahead of the MFMAs
-    constexpr int NS = 3;
+    constexpr int NS = SSW_GEMM_NS;
     constexpr int STG = NX * BM * PBK + 2 * BN * PBK;                      // doubles per stage
     constexpr int SXD = NS * STG, SYD = 0;
 #else
@@ -341,9 +344,10 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     // k-steps before its first read.  A raw s_barrier: __syncthreads() would wait for vmcnt(0) and drain the ring.
     const unsigned nk = Kp / PBK;          // >= 2
     Frag fa, fb;
+    static_assert(NS == 2 || NS == 3, "ring of two or three stages");
     issue(0, 0);
     issue(1, STG);
-    if (nk > 2) {
+    if (NS == 3 && nk > 2) {
         issue(2, 2 * STG);
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LPT) : "memory");
     } else {
@@ -353,8 +357,8 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     SSW_TT(1);
     fread(0u, B0{}, fa);
     unsigned cur = 0, nxt = STG, t = 0;
-    // one k-step: second half-step of stage `cur`, the barrier, first half-step of stage `nxt`.  ISSUE: k-step t + 3 exists and is
-    // requested into stage `cur`; VM: DMA instructions of this wave that may stay in flight at the barrier (the stage behind nxt)
+    // one k-step: second half-step of stage `cur`, the barrier, first half-step of stage `nxt`.  ISSUE: k-step t + NS exists and is
+    // requested into stage `cur`; VM: DMA instructions of this wave that may stay in flight at the barrier (the stages behind nxt)
     auto step = [&](auto issuec, auto vmc) {
         constexpr bool ISSUE = decltype(issuec)::value != 0;
         constexpr int VM = decltype(vmc)::value;
@@ -364,15 +368,15 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(VM) : "memory");
         SSW_KT(t);
         fread(nxt, B0{}, fa);
-        if (ISSUE) issue(t + 3, cur);          // (behind the reads in program order: LDS accesses keep theirs, so the DMA instructions can then go one per MFMA)
+        if (ISSUE) issue(t + NS, cur);         // (behind the reads in program order: LDS accesses keep theirs, so the DMA instructions can then go one per MFMA)
         fmma(fb);
         interleave(std::integral_constant<int, ISSUE ? LPT : 0>{});
         cur = nxt;
         nxt = nxt + STG == NS * STG ? 0u : nxt + STG;
         ++t;
     };
-    while (t + 3 < nk) step(B1{}, std::integral_constant<int, LPT>{});
-    if (t + 2 < nk) step(B0{}, std::integral_constant<int, LPT>{});          // k-step nk - 3: stage nk - 1 stays in flight
+    while (t + NS < nk) step(B1{}, std::integral_constant<int, (NS - 2) * LPT>{});
+    if (NS == 3 && t + 2 < nk) step(B0{}, std::integral_constant<int, LPT>{});          // k-step nk - 3: stage nk - 1 stays in flight
     if (t + 1 < nk) step(B0{}, B0{});                                         // k-step nk - 2: the last stage must have landed
     fread(cur, B1{}, fb);
     fmma(fa);
