@@ -16,10 +16,10 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // resident on one XCD cover a compact rectangle of tiles and share A/B panels in its L2
 // (GROUP_M 4 measured 2.5 % faster than 8 on the 9-tile-wide column pass at 4K, equal elsewhere).
 __device__ inline void tile_of_block(unsigned bid, unsigned nblk, unsigned tiles_m, unsigned tiles_n,
-                                     unsigned& tm, unsigned& tn) {
+                                     unsigned& tm, unsigned& tn, unsigned group_m = 4) {
     const unsigned q = nblk / 8, r = nblk % 8, xcd = bid % 8;
     const unsigned id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
-    constexpr unsigned GROUP_M = 4;
+    const unsigned GROUP_M = group_m;
     const unsigned per_group = GROUP_M * tiles_n;
     const unsigned g = id / per_group;
     const unsigned first_m = g * GROUP_M;

@@ -95,6 +95,7 @@ struct PairClassArgs {
 struct PairMulti {
     PairClassArgs c[8];
     unsigned n_classes, L, tiles_m, tiles_n_total;
+    unsigned group_m = 4;              // tile rows per group of the block -> tile map (tile_of_block; tuning: gemm_group_m)
     unsigned stagger = 0;              // r6 A/B (tuning: gemm_stagger): blocks 256 .. 511 sleep this many x 8128 cycles before their tile
     PairOut po;                        // the fields the classes share; c1 .. bn32 are overwritten per class
 };
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
         for (unsigned i = 0; i < ml.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     SSW_TT(0);
     unsigned tm, tn;
-    tile_of_block(blockIdx.x, gridDim.x, ml.tiles_m, ml.tiles_n_total, tm, tn);
+    tile_of_block(blockIdx.x, gridDim.x, ml.tiles_m, ml.tiles_n_total, tm, tn, ml.group_m);
     unsigned cls = 0;
     while (cls + 1 < ml.n_classes && tn >= ml.c[cls].tiles_n) { tn -= ml.c[cls].tiles_n; ++cls; }      // block-uniform
     const PairClassArgs& ca = ml.c[cls];

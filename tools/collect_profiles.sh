@@ -5,7 +5,7 @@
 #   trace domains other than the kernel trace (MI355X_MICROARCH.md, rocprofv3 section).
 # usage (in the container, so that the commit is recorded): git rev-parse --short HEAD > .commit_stamp; gpurun -- bash tools/collect_profiles.sh r5
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
