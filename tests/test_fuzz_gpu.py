@@ -4,6 +4,7 @@ exact-operand folding / in-kernel folding / dense; rows or columns first; class-
 r3 pre-passes by shape) and of the batch pipelines (pruned + two lanes against full + one lane) -- not only the
 hand-picked shapes of test_gpu_parity.py.  Reference: src/dct2d.rs:83-219 (the transform the oracle restates),
 src/algorithm.rs:295-316, :355-379, :529-593 (the batch flows).  Everything goes through the C ABI; the oracle checks."""
+import json
 import os
 import sys
 
@@ -100,6 +101,31 @@ def test_fused_derived_pass_is_bit_identical_to_prepass_and_launches():
     bad = prep_light_check.run(lines.append, batch=[], planes=[], inverse=[])
     assert bad == 0, "\n".join(l for l in lines if "FAIL" in l)
     assert sum("one kernel ==" in l for l in lines) == 3 * len(prep_light_check.DERIVED)
+
+
+def test_gemm_ring_reproduces_the_register_staged_kernels_planes_bit_for_bit():
+    """r6: the GEMM's operand tiles arrive by LDS-DMA in a ring (csrc/dct_pair_f64_kernel.hpp, SSW_GEMM_DMA) instead of through
+    registers + ds_write -- same products, same k order per accumulator, so every plane is the r5 kernel's bit for bit.
+    tests/golden/gemm_digests.json holds the digests of the register-staged build (-DSSW_GEMM_DMA=0) on ssw_synth_frames
+    inputs: plane transforms (forward, orthonormal, inverse: src/dct2d.rs:83-219) of eight shapes covering every strategy --
+    4K / 8K batches and single frames, 1080p, 720p, the 444-row dense path -- and three batch embed + extract pipelines
+    (marked frames, extracted marks, similarities); tools/lib_ab_check.py computes them for the loaded library in a child process."""
+    import lib_ab_check
+    with open(os.path.join(ROOT, "tests", "golden", "gemm_digests.json")) as f:
+        want = json.load(f)["digests"]
+    got = lib_ab_check.digests()
+    assert set(got) == set(want)
+    diff = [k for k in want if got[k] != want[k]]
+    assert not diff, f"planes differ from the register-staged kernel's: {diff}"
+
+
+def test_gemm_tile_order_and_stagger_knobs_choose_between_equal_results():
+    """ssw_tuning_set names of r6 (gemm_group_m, gemm_group_m_rows: tile rows per group of the block -> tile map; gemm_stagger:
+    a launch-time offset for the CUs' second resident blocks) are A/B switches of the schedule: the digests stay the same."""
+    import lib_ab_check
+    base = lib_ab_check.digests()
+    for env in ({"SSW_GEMM_GROUP_M_ROWS": "1", "SSW_GEMM_GROUP_M": "16"}, {"SSW_GEMM_STAGGER": "2", "SSW_GEMM_GROUP_M_ROWS": "16"}):
+        assert lib_ab_check.digests(env=env) == base, env
 
 
 def test_transform_plan_reports_the_default_path():

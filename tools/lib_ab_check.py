@@ -2,7 +2,8 @@
 """Bit-for-bit A/B of two builds of the library (e.g. lib/libssw_hip.so against a variant of tools/build_variant.sh): every build
 runs in a child process (SSW_LIB_PATH), transforms the same synthetic frames -- ssw_dct2d forward, orthonormal and inverse on
 shapes of every strategy, one batch embed + extract -- and prints a digest per case; the parent compares the digests.
-usage: python tools/lib_ab_check.py LIB_A LIB_B"""
+usage: python tools/lib_ab_check.py LIB_A LIB_B
+       python tools/lib_ab_check.py --golden LIB OUT.json     (writes the digests of one build: tests/golden/gemm_digests.json)"""
 import hashlib
 import os
 import subprocess
@@ -49,16 +50,33 @@ def child():
     ctx.close()
 
 
+def digests(lib=None, env=None):
+    """{case: digest} of one build (None: the default library), computed in a child process."""
+    e = dict(os.environ, **(env or {}))
+    if lib:
+        e["SSW_LIB_PATH"] = os.path.abspath(lib)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=e, capture_output=True, text=True, timeout=1200)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout[-2000:] + r.stderr[-3000:])
+    return {" ".join(l.split()[1:-1]): l.split()[-1] for l in r.stdout.splitlines() if l.startswith("DIGEST")}
+
+
 def main():
+    if sys.argv[1] == "--golden":
+        import json
+        d = digests(sys.argv[2])
+        with open(sys.argv[3], "w") as f:
+            json.dump({"_how": "python tools/lib_ab_check.py --golden <library built with -DSSW_GEMM_DMA=0: the register-staged r5 GEMM kernel> "
+                               "tests/golden/gemm_digests.json -- sha256[:16] of the f32 outputs on ssw_synth_frames(seed 7) inputs",
+                       "digests": d}, f, indent=1)
+        print(f"{len(d)} digests -> {sys.argv[3]}")
+        return 0
     libs = sys.argv[1:3]
-    res = []
-    for lib in libs:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=dict(os.environ, SSW_LIB_PATH=os.path.abspath(lib)),
-                           capture_output=True, text=True, timeout=1200)
-        if r.returncode != 0:
-            print(r.stdout[-2000:], r.stderr[-3000:])
-            return 2
-        res.append({" ".join(l.split()[1:-1]): l.split()[-1] for l in r.stdout.splitlines() if l.startswith("DIGEST")})
+    try:
+        res = [digests(lib) for lib in libs]
+    except RuntimeError as e:
+        print(e)
+        return 2
     bad = 0
     for key in res[0]:
         same = res[0][key] == res[1].get(key)
