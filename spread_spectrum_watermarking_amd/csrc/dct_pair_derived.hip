@@ -15,15 +15,23 @@
 //            /root/reference/src/dct2d.rs:152-168 -- into the compact plane [line][cap_total].
 // Applies to marks of up to 1024 entries (classes of at most 32 / 16 gathered columns); longer ones take the launches.
 //
-// Measured (128 4K frames): 4.0 ms against 3.6 (pre-pass) + 1.7 (launches) + the planes' round trip; loads alone 2.0 ms, fold + MFMAs alone
-// 1.9 -- together more than their sum until the next tile's pixels were requested behind the last B-fragment load of the tile
-// in work (vector-memory loads complete in order: a request in front of the B-fragments made every MFMA wait for the
-// prefetch).  -DDF_NO_LOADS / -DDF_NO_FOLD / -DDF_NO_MFMA build the timing variants those numbers came from (wrong results).
+// Measured (128 4K frames): r5 4.0-4.2 ms against 3.6 (pre-pass) + 1.7 (launches) + the planes' round trip; loads alone 2.0 ms, fold +
+// MFMAs alone 1.9.  r6: 3.4 ms -- every vector-memory load of the tile loop unconditional and in a fixed order (buffer loads whose
+// range check drops what does not exist), so that the compiler counts its waits: with the fragment loads inside wave-uniform
+// branches it had waited for vmcnt(0) in front of every k-step, the next tile's pixels included.  Loads do return in order, too:
+// the next tile's pixels requested in front of the fold (-DDF_EARLY_REQUEST=1: behind the fragments of k-steps 0 and 1 only)
+// measure 3.7 ms, the fragments of k-steps 2 and 3 then stand behind them.  Fragments two k-steps ahead instead of one: no change.
+// -DDF_NO_LOADS / -DDF_NO_FOLD / -DDF_NO_MFMA build the timing variants the r5 numbers came from (wrong results).
 #include "dct_pair_split.hpp"
 #include "dct_pair_colops.hpp"
 #include "dct_pair_yiq_load.hpp"
 
 #include <atomic>
+#include <type_traits>
+
+#ifndef DF_EARLY_REQUEST
+#define DF_EARLY_REQUEST 0
+#endif
 
 namespace ssw {
 namespace {
@@ -57,6 +65,29 @@ __global__ __launch_bounds__(256, 2) void prep16_derived_fused_kernel(const void
     const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));      // wave-uniform: the job table is read by scalar loads
     const unsigned line0 = blockIdx.x * DF_LINES;
     const unsigned nj = jobs.n[wv];
+    // r6: every vector-memory load of the loop is unconditional and comes in a fixed order (the compiler's counted s_waitcnt
+    // vmcnt(N) needs that: with the fragment and pixel loads inside wave-uniform branches it waited for vmcnt(0) in front of
+    // every k-step, i.e. for the next tile's pixels as well -- what r5 read as "loads complete in order").  A job that does not
+    // exist, a class without a sine part, k-steps behind the padded sum and rows / units outside the frame are buffer ranges
+    // of zero records or offsets behind the range: such loads return 0 without a memory access.
+    __amdgpu_buffer_rsrc_t jr1[DF_MAXJ], jr2[DF_MAXJ];
+    unsigned jp1[DF_MAXJ], jp2[DF_MAXJ];
+    bool jon[DF_MAXJ], jon2[DF_MAXJ];
+#pragma unroll
+    for (int j = 0; j < DF_MAXJ; ++j) {
+        const DfJob& jb = jobs.j[wv][j];
+        jon[j] = (unsigned)j < nj;
+        jon2[j] = jon[j] && jb.y2 != nullptr;
+        const size_t at0 = jon[j] ? (size_t)(jb.row0 >> 4) * (Kp / 4) * 64 : 0;      // the job's fragment stream: [k / 4][64 lanes]
+        jr1[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(jon[j] ? jb.y1 + at0 : rot1), 0, jon[j] ? (Kp / 4) * 512u : 0u, 0x00020000);
+        jr2[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(jon2[j] ? jb.y2 + at0 : rot1), 0, jon2[j] ? (Kp / 4) * 512u : 0u, 0x00020000);
+        jp1[j] = jon[j] ? jb.p1 * 64u : 0u;
+        jp2[j] = jon2[j] ? jb.p2 * 64u : 0u;
+    }
+    constexpr unsigned PXB = SRC == 1 ? 12u : SRC == 3 ? 6u : 3u;                   // bytes per pixel of the frames
+    const unsigned rows_here = rows - line0 < (unsigned)DF_LINES ? rows - line0 : (unsigned)DF_LINES;
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc((void*)(static_cast<const char*>(SRCP) + (size_t)line0 * W * PXB), 0,
+                                                                      rows_here * W * PXB, 0x00020000);
     f64x4d acc[DF_MAXJ][2];
 #pragma unroll
     for (int j = 0; j < DF_MAXJ; ++j) { acc[j][0] = (f64x4d){0, 0, 0, 0}; acc[j][1] = (f64x4d){0, 0, 0, 0}; }
@@ -81,9 +112,11 @@ __global__ __launch_bounds__(256, 2) void prep16_derived_fused_kernel(const void
     RawQuad<SRC - 1> raw[4];
     unsigned dst[4];
     double tv = 0.0;
+    bool tv_ok = false;
     auto request = [&](unsigned e0) {
         const double* tsrc = tab_src(tid, e0);
-        tv = tsrc ? *tsrc : 0.0;
+        tv = *(tsrc ? tsrc : rot3);                               // (always a load; entries outside the table are dropped by park)
+        tv_ok = tsrc != nullptr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const unsigned t = tid + 256 * i;
@@ -94,13 +127,25 @@ __global__ __launch_bounds__(256, 2) void prep16_derived_fused_kernel(const void
             if (u < 8) px = asc ? hv * N8 + e0 + 4 * q : (hv + 1) * N8 - 16 - e0 + 4 * q;
             else       px = asc ? W - (hv + 1) * N8 + e0 + 4 * q : W - 16 - hv * N8 - e0 + 4 * q;
             const unsigned efirst = asc ? e0 + 4 * q : e0 + 12 - 4 * q;
-            const size_t row = line0 + ll;
-            dst[i] = (row < rows && efirst < N16) ? ll * DF_PITCH + u * 16 + 4 * q : 0xFFFFFFFFu;
-            if (dst[i] == 0xFFFFFFFFu) continue;
-            const void* base = SRC == 3 ? static_cast<const void*>(static_cast<const uint16_t*>(SRCP) + row * W * 3)
-                             : SRC == 2 ? static_cast<const void*>(static_cast<const uint8_t*>(SRCP) + row * W * 3)
-                                        : static_cast<const void*>(static_cast<const float*>(SRCP) + row * W * 3);
-            load_raw4<SRC - 1>(base, px, raw[i]);
+            const bool ok = ll < rows_here && efirst < N16;
+            dst[i] = ok ? ll * DF_PITCH + u * 16 + 4 * q : 0xFFFFFFFFu;
+            const unsigned off = ok ? (ll * W + px) * PXB : 0x80000000u;           // behind the range: nothing is read
+            if (SRC == 1) {
+                auto& w = reinterpret_cast<RawQuad<SSW_PIX_F32>&>(raw[i]).w;
+                w[0] = __builtin_amdgcn_raw_buffer_load_b128(fr, off, 0, 0);
+                w[1] = __builtin_amdgcn_raw_buffer_load_b128(fr, off + 16u, 0, 0);
+                w[2] = __builtin_amdgcn_raw_buffer_load_b128(fr, off + 32u, 0, 0);
+            } else if (SRC == 3) {
+                auto& w = reinterpret_cast<RawQuad<SSW_PIX_U16>&>(raw[i]).w;
+                w[0] = __builtin_amdgcn_raw_buffer_load_b64(fr, off, 0, 0);
+                w[1] = __builtin_amdgcn_raw_buffer_load_b64(fr, off + 8u, 0, 0);
+                w[2] = __builtin_amdgcn_raw_buffer_load_b64(fr, off + 16u, 0, 0);
+            } else {
+                auto& w = reinterpret_cast<RawQuad<SSW_PIX_U8>&>(raw[i]).w;
+                w[0] = __builtin_amdgcn_raw_buffer_load_b32(fr, off, 0, 0);
+                w[1] = __builtin_amdgcn_raw_buffer_load_b32(fr, off + 4u, 0, 0);
+                w[2] = __builtin_amdgcn_raw_buffer_load_b32(fr, off + 8u, 0, 0);
+            }
         }
     };
     auto park = [&]() {
@@ -111,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void prep16_derived_fused_kernel(const void
             yiq_of_raw4<SRC - 1, false>(raw[i], y, iv, qv);
             *reinterpret_cast<f32x4*>(ys + dst[i]) = y;
         }
-        if (tid < 14 * 16) tabs[tid] = tv;
+        if (tid < 14 * 16) tabs[tid] = tv_ok ? tv : 0.0;
     };
 #ifndef DF_NO_LOADS
     request(0);
@@ -126,22 +171,28 @@ __global__ __launch_bounds__(256, 2) void prep16_derived_fused_kernel(const void
         // B-fragments (gathered basis rows, from L2; fragment order of prune_gather_basis_kernel: per tile of 16 gathered rows
         // [k / 4][k % 4][row % 16], a fragment = 512 contiguous bytes, rows behind the class are zero rows) of all jobs for one
         // k-step; those of the first k-step are requested before the fold, those of k-step s + 1 before the MFMAs of k-step s
-        double bn1[DF_MAXJ], bn2[DF_MAXJ];
-        auto load_b = [&](int ks) {
-            const unsigned k4 = k0 / 4 + ks;
-            const bool ok = 4 * k4 < Kp;                          // block-uniform
+        // r6: the fragments of a k-step are requested TWO k-steps ahead (those of k-steps 0 and 1 before the fold): one k-step of
+        // ten MFMAs (0.27 us) did not cover a trip to L2 under load, and the next tile's pixels can be requested one k-step earlier
+        double bf1[4][DF_MAXJ], bf2[4][DF_MAXJ];
+        auto load_b = [&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            const unsigned koff = (k0 / 4 + ks) * 512u;           // fragment k / 4 of the stream (behind Kp / 4: zero)
 #pragma unroll
             for (int j = 0; j < DF_MAXJ; ++j) {
-                bn1[j] = 0.0; bn2[j] = 0.0;
-                if ((unsigned)j >= nj || !ok) continue;           // wave-uniform
-                const DfJob& jb = jobs.j[wv][j];
-                const size_t at = (size_t)(jb.row0 >> 4) * (Kp / 4) * 64 + (size_t)k4 * 64 + lane;
-                bn1[j] = jb.y1[at];
-                if (jb.y2) bn2[j] = jb.y2[at];
+                const u32x2 w1 = __builtin_amdgcn_raw_buffer_load_b64(jr1[j], lane * 8u, koff, 0);
+                const u32x2 w2 = __builtin_amdgcn_raw_buffer_load_b64(jr2[j], lane * 8u, koff, 0);
+                bf1[ks][j] = __hiloint2double((int)w1[1], (int)w1[0]);
+                bf2[ks][j] = __hiloint2double((int)w2[1], (int)w2[0]);
             }
         };
+        using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
+        using K2 = std::integral_constant<int, 2>; using K3 = std::integral_constant<int, 3>;
 #ifndef DF_NO_MFMA
-        load_b(0);
+        load_b(K0{});
+        load_b(K1{});
+#endif
+#if !defined(DF_NO_LOADS) && DF_EARLY_REQUEST
+        if (e0 + 16 < N16) request(e0 + 16);           // A/B: the next tile's pixels behind the first two k-steps' fragments, in front of the fold
 #endif
         // ---- phase 2: wave wv folds k-step wv: lane = (line li, unit e0 + 4 wv + lq); its sixteen results are the lane's elements
         // of the sixteen planes' A-fragments for that k-step (col_l2_unit's operations and order, in two halves like the light pre-pass)
@@ -190,28 +241,26 @@ __global__ __launch_bounds__(256, 2) void prep16_derived_fused_kernel(const void
 #ifndef DF_NO_MFMA
         // ---- phase 3: the tile's four k-steps; per k-step one MFMA (two: split classes) into each job's accumulators -- consecutive
         // MFMAs never touch the same accumulator (a chain of dependent f64 MFMAs issues at half rate)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            double c1[DF_MAXJ], c2[DF_MAXJ];
-#pragma unroll
-            for (int j = 0; j < DF_MAXJ; ++j) { c1[j] = bn1[j]; c2[j] = bn2[j]; }
-            if (ks < 3) load_b(ks + 1);
-#ifndef DF_NO_LOADS
-            if (ks == 2 && e0 + 16 < N16) request(e0 + 16);       // behind the tile's last B-fragment load (k-step 3's, just issued)
+        auto kstep = [&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            if (ks == 0) load_b(K2{});
+            if (ks == 1) load_b(K3{});
+#if !defined(DF_NO_LOADS) && !DF_EARLY_REQUEST
+            if (ks == 1 && e0 + 16 < N16) request(e0 + 16);       // behind the tile's last B-fragment load (k-step 3's, just issued)
 #endif
-            if (k0 + 4 * ks >= N16) continue;                     // block-uniform
+            if (k0 + 4 * ks >= N16) return;                       // block-uniform
 #pragma unroll
             for (int j = 0; j < DF_MAXJ; ++j) {
-                if ((unsigned)j >= nj) continue;                  // wave-uniform
-                const DfJob& jb = jobs.j[wv][j];
-                const double a1 = afrag[((size_t)ks * 16 + jb.p1) * 64 + lane];
-                acc[j][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, c1[j], acc[j][0], 0, 0, 0);
-                if (jb.y2) {
-                    const double a2 = afrag[((size_t)ks * 16 + jb.p2) * 64 + lane];
-                    acc[j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, c2[j], acc[j][1], 0, 0, 0);
+                if (!jon[j]) continue;                            // wave-uniform
+                const double a1 = afrag[(size_t)ks * 16 * 64 + jp1[j] + lane];
+                acc[j][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bf1[ks][j], acc[j][0], 0, 0, 0);
+                if (jon2[j]) {
+                    const double a2 = afrag[(size_t)ks * 16 * 64 + jp2[j] + lane];
+                    acc[j][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, bf2[ks][j], acc[j][1], 0, 0, 0);
                 }
             }
-        }
+        };
+        kstep(K0{}); kstep(K1{}); kstep(K2{}); kstep(K3{});
 #endif
         __syncthreads();
     }
