@@ -270,7 +270,18 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
         const bool bn32 = force >= 0 ? force != 0 : 0.92 * balance((unsigned long long)tiles_m * tn32) > balance((unsigned long long)tiles_m * tiles_n);
         if (bn32) { ml.c[0].tiles_n = tiles_n = tn32; ml.c[0].bn32 = 1; }
     }
-    const unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
+    unsigned long long nblk = (unsigned long long)tiles_m * tiles_n;
+    // batch passes (more lines than merge_max_lines) that come with several classes run them class after class in one launch
+    const bool cls_major = n_classes > 1 && (size_t)L > (size_t)tuning(TUNE_MERGE_MAX_LINES);
+    if (cls_major) {
+        nblk = 0;
+        for (int c = 0; c < n_classes; ++c) {
+            ml.cbase[c] = (unsigned)nblk;
+            nblk += ((unsigned long long)tiles_m * ml.c[c].tiles_n + 7ull) & ~7ull;
+        }
+        for (int c = n_classes; c < 9; ++c) ml.cbase[c] = (unsigned)nblk;
+        ml.cls_major = 1;
+    }
     if (nblk > 0x7FFFFFFFull) return SSW_ERR_BAD_DIMS;
     ml.n_classes = (unsigned)n_classes; ml.L = L; ml.tiles_m = tiles_m; ml.tiles_n_total = tiles_n;
     ml.stagger = nblk > 1024 ? (unsigned)tuning(TUNE_GEMM_STAGGER) : 0u;

@@ -95,6 +95,11 @@ struct PairClassArgs {
 struct PairMulti {
     PairClassArgs c[8];
     unsigned n_classes, L, tiles_m, tiles_n_total;
+    // r6: a batch pass's classes in ONE launch, class after class (cls_major): class c owns the blocks [cbase[c], cbase[c + 1]) --
+    // whole multiples of 8, so that a block's XCD is the one its class-local number says; the surplus blocks return at once --
+    // and walks its tiles like a launch of its own.  The next class's blocks start where the previous one's last blocks retire:
+    // no drained chip between the eight launches of a pass.  (Single frames keep their classes' tile columns side by side.)
+    unsigned cls_major = 0, cbase[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned group_m = 4;              // tile rows per group of the block -> tile map (tile_of_block; tuning: gemm_group_m)
     unsigned stagger = 0;              // r6 A/B (tuning: gemm_stagger): blocks 256 .. 511 sleep this many x 8128 cycles before their tile
     PairOut po;                        // the fields the classes share; c1 .. bn32 are overwritten per class
@@ -137,10 +142,16 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     if (ml.stagger && blockIdx.x >= 256u && blockIdx.x < 512u)
         for (unsigned i = 0; i < ml.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     SSW_TT(0);
-    unsigned tm, tn;
-    tile_of_block(blockIdx.x, gridDim.x, ml.tiles_m, ml.tiles_n_total, tm, tn, ml.group_m);
-    unsigned cls = 0;
-    while (cls + 1 < ml.n_classes && tn >= ml.c[cls].tiles_n) { tn -= ml.c[cls].tiles_n; ++cls; }      // block-uniform
+    unsigned tm, tn, cls = 0;
+    if (ml.cls_major) {
+        while (cls + 1 < ml.n_classes && blockIdx.x >= ml.cbase[cls + 1]) ++cls;                        // block-uniform
+        const unsigned lid = blockIdx.x - ml.cbase[cls], nb = ml.tiles_m * ml.c[cls].tiles_n;
+        if (lid >= nb) return;
+        tile_of_block(lid, nb, ml.tiles_m, ml.c[cls].tiles_n, tm, tn, ml.group_m);
+    } else {
+        tile_of_block(blockIdx.x, gridDim.x, ml.tiles_m, ml.tiles_n_total, tm, tn, ml.group_m);
+        while (cls + 1 < ml.n_classes && tn >= ml.c[cls].tiles_n) { tn -= ml.c[cls].tiles_n; ++cls; }  // block-uniform
+    }
     const PairClassArgs& ca = ml.c[cls];
     const double* __restrict__ X1g = ca.x1;
     const double* __restrict__ X2g = ca.x2;

@@ -309,6 +309,10 @@ size_t split_scratch_elems(size_t n, size_t w, size_t h) {
 static size_t merge_max_lines() {
     return (size_t)tuning(TUNE_MERGE_MAX_LINES);
 }
+// ... and batch passes too when `merge_batch` is on: their classes then run class after class inside the one launch (cls_major)
+static bool merge_classes(size_t lines) {
+    return lines <= merge_max_lines() || tuning(TUNE_MERGE_BATCH) != 0;
+}
 
 // Can the column pre-pass of an `fh`-row plane read the class-major order a deep row pass leaves (dct_pair_common.hpp)?  The
 // deep kernels all can; of the semi-deep ones (fh % 16 == 8: 1080 rows) only the LDS-staged forms.
@@ -452,7 +456,7 @@ int build_pass_impl(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_
                                                 {8, 0, P(6), P(7), (const double*)t0, (const double*)t1},
                                                 {7, 0, P(4), P(5), (const double*)t0, (const double*)t1}};
                     const FuseCols fc{FUSE_ROWS_COP, cop, (const double*)crot1, (const double*)crot2, (const double*)crot3};
-                    const bool merge_r = lpad <= merge_max_lines();       // a single frame: the eight classes in one launch
+                    const bool merge_r = merge_classes(lpad);       // a single frame: the eight classes in one launch
                     ch.push_back({false, [=](hipStream_t st) -> int {
                         StageTimer t(ctx, st_pass, st, f_all * pad, merge_r ? st_main : -1);
                         t.traffic(px * (esz + 8.0));                     // row operands in, column operands out
@@ -475,7 +479,7 @@ int build_pass_impl(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_
                                             {8, 0, CP(6), CP(7), (const double*)t0, (const double*)t1},
                                             {7, 0, CP(4), CP(5), (const double*)t0, (const double*)t1}};
                 const FuseCols fc{FUSE_COLS};
-                const bool merge_c = lines <= merge_max_lines();
+                const bool merge_c = merge_classes(lines);
                 ch.push_back({false, [=](hipStream_t st) -> int {
                     StageTimer t(ctx, st_pass, st, f_all, merge_c ? st_main : -1);
                     t.traffic(gemm_bytes(0.0));
@@ -783,7 +787,7 @@ int build_pass_impl(ssw_ctx* ctx, ssw_ctx::Lane& ws, const Xform& x, bool first_
                     t.traffic(gemm_bytes(14.0));
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &da, dst, (double*)A1, n, w, h, ep));
                     SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 1, &db, dst, (double*)A1, n, w, h, ep, nullptr, (double*)T2, rcm));
-                    if (lines <= merge_max_lines()) {          // single frames: the classes of each dependent stage in one launch
+                    if (merge_classes(lines)) {          // single frames (merge_batch: batches too): the classes of each dependent stage in one launch
                         SSW_TRY(launch_dct_pair_gemm_multi_f64(st, is_row, true, 2, d1, dst, (double*)T2, n, w, h, ep, nullptr, (double*)TE, rcm));
                         return launch_dct_pair_gemm_multi_f64(st, is_row, true, 4, d0, dst, (double*)TE, n, w, h, ep, with_sink ? &sink : nullptr, nullptr, rcm);
                     }
