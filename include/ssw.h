@@ -236,6 +236,7 @@ int ssw_ctx_set_odd_split(ssw_ctx* ctx, int enable);
      derived_fused (1)     the derived frame's pruned row pass in one kernel (0: pre-pass + gathered launches)
      inv_prep_light (0)    inverse row pre-pass at level 2 with whole rows through LDS (bit-identical, measured no faster: off)
      gemm_group_m (4), gemm_group_m_rows (4)   tile rows per group of the GEMM launches' block -> tile map (column / row passes)
+     tile48 (1)            48-pair GEMM tiles for classes whose 64-pair tiling ends in a tile of <= 16 pairs (135 = 48 + 48 + 39)
      merge_batch (0)       a batch pass's independent GEMM launches as one launch, class after class (r6 A/B: +1.7 % one lane, +0 two)
      gemm_stagger (0)      r6 A/B: the second resident block of every CU starts this many 3.4-us sleeps late (measured: no effect)
    An entry never set reads its SSW_<NAME> environment variable at first use (the r4 behaviour), else the default.

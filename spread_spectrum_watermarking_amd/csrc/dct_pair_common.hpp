@@ -64,6 +64,9 @@ struct PairOutT {
     unsigned wide = 0;
     // block tiles of 32 instead of 64 pairs (every tile runs the 4 x 1 wave layout): small launches whose 64-pair
     // grid would load the CUs unevenly -- a single 4K frame's column pass is 60 x 9 = 540 blocks for 256 CUs
+    // r6: tile width code -- 0: 64 pairs, 1: 32 (as above), 2: 48 pairs, three pair tiles on the 4 x 1 wave grid: a class of 135 pairs
+    // (4K columns) as 48 + 48 + 39 instead of 64 + 64 + 7 -- the 7-pair tile ran a whole sum's worth of operand tiles for a
+    // quarter of a tile's MFMAs (without it the column pass took 15 % less time for 5 % less work)
     unsigned bn32 = 0;
     // split odd half (dct_pair_f64.hip, "rotated quarter-length pair"): the two products are a cosine and a sine
     // transform of the rotated operands and the outputs are their sum and difference: 1 = (acc1 + acc2 -> first

@@ -108,8 +108,17 @@ int pair_class_args(const PairClassDesc& d, bool is_row, bool inverse, size_t le
     ca.NP = (unsigned)(kind == 0 ? leff / 2 : split ? leff / 8 : leff / 4);      // class E: n/8 + 1 pairs in n/8 slots (fold0)
     ca.Kp = (unsigned)(split ? pair_kpad<double>(leff / 4) : kind == 1 ? pair_kpad<double>(leff / 2) : pair_kpad<double>(leff));
     ca.yrows = kind == 2 ? 2 * ca.NP : eshape ? ca.NP + 1 : ca.NP;      // lines of the basis plane(s): class E's keep row n/8
+#ifdef SSW_ABL_NP128        // timing-only ablation: the 135-pair column classes without their 7-pair tail tile
+    if (!is_row && ca.NP == 135) ca.NP = 128;
+#endif
     ca.tiles_n = (ca.NP + 63) / 64;
     ca.c1 = 0; ca.c2 = 1; ca.cs = 2; ca.pm = 0; ca.np1 = 0xFFFFFFFFu; ca.p2lo = 0; ca.bn32 = 0; ca.fold0 = 0;
+    // 48-pair tiles where 64-pair ones would end in a tile of at most 16 pairs and 48 need no more tiles (135 = 48 + 48 + 39
+    // instead of 64 + 64 + 7: 4K and 1080p columns); `tile48` = 0: A/B switch
+    if (tuning(TUNE_TILE48) != 0 && ca.NP > 64 && (ca.NP % 64) != 0 && (ca.NP % 64) <= 16 && (ca.NP + 47) / 48 == ca.tiles_n) {
+        ca.bn32 = 2;
+        ca.tiles_n = (ca.NP + 47) / 48;
+    }
     ca.gsh = 31; ca.e2off = 0;
     if (kind == 1) { ca.c1 = 0; ca.c2 = 2 * fs; ca.cs = 4 * fs; }
     if (kind == 2) { ca.c1 = fs; ca.c2 = fs + 2 * fs * ca.NP; ca.cs = 2 * fs; }
@@ -259,6 +268,9 @@ int launch_dct_pair_gemm_multi_f64(hipStream_t st, bool is_row, bool inverse, in
     const bool small = (unsigned long long)((L + 127) / 128) * tiles_n < 448;
     if (fuse && small) return SSW_ERR_BAD_ARG;
     const unsigned BM = small ? 64 : 128;
+    if (small)                                                     // 48-pair tiles are three pair tiles of a 128-line block
+        for (int c = 0; c < n_classes; ++c)
+            if (ml.c[c].bn32 == 2) { tiles_n -= ml.c[c].tiles_n; ml.c[c].bn32 = 0; ml.c[c].tiles_n = (ml.c[c].NP + 63) / 64; tiles_n += ml.c[c].tiles_n; }
     const unsigned tiles_m = (L + BM - 1) / BM;
     // ... and 32-pair tiles when that spreads such a (single-class) launch more evenly over the 256 CUs (all its blocks are
     // resident at once, so a launch takes as long as the fullest CU): balance = blocks / (256 * ceil(blocks / 256)); the

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     PairOut po = ml.po;
     po.c1 = ca.c1; po.c2 = ca.c2; po.cs = ca.cs; po.pm = ca.pm; po.np1 = ca.np1; po.p2lo = ca.p2lo; po.bn32 = ca.bn32; po.fold0 = ca.fold0;
     po.gsh = ca.gsh; po.e2off = ca.e2off;
-    const unsigned m0 = tm * BM, p0 = tn * (po.bn32 ? 32u : (unsigned)BN);
+    const unsigned m0 = tm * BM, p0 = tn * (po.bn32 == 1 ? 32u : po.bn32 == 2 ? 48u : (unsigned)BN);      // bn32: tile width code (PairOutT)
     const unsigned tid = threadIdx.x;
     const unsigned lane = tid & 63, wave = tid >> 6;
     const unsigned li = lane & 15, lq = lane >> 4;
@@ -1220,25 +1220,32 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
             else *reinterpret_cast<f32x4*>(po.out + px) = (f32x4){y[0], y[1], y[2], y[3]};
         };
         if (EPI == EPI_FWD || EPI == EPI_INV) {
+            // a round = up to two pair tiles (32 result rows) of one output set; NJ = 3 (48-pair tiles): a second round for the third
+#pragma unroll
+            for (int jb = 0; jb < NJ; jb += 2)
 #pragma unroll
             for (int set = 0; set < 2; ++set) {
+                const int nj2 = NJ - jb < 2 ? NJ - jb : 2;
                 lds_order();
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int jn = 0; jn < NJ; ++jn)
+                    for (int jn = jb; jn < jb + 2; ++jn) {
+                        if (jn >= NJ) continue;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const double a1 = acc1[i][jn][r], a2 = acc2[i][jn][r];
                             const float v = EPI == EPI_FWD ? (float)(set ? a2 : a1) : (float)(set ? a1 - a2 : a1 + a2);
-                            tw[wr0 + (16 * jn + 4 * r) * TPF + 16 * i] = v;
+                            tw[wr0 + (16 * (jn - jb) + 4 * r) * TPF + 16 * i] = v;
                         }
+                    }
                 lds_order();
 #pragma unroll
                 for (int t = 0; t < NRI; ++t) {
-                    const unsigned pair = p0 + wn + t * RPI + rrow;
+                    const unsigned srow = t * RPI + rrow;
+                    const unsigned pair = p0 + wn + 16 * jb + srow;
                     const f32x4 v = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
-                    if (!line_ok || pair >= NP) continue;
+                    if (!line_ok || pair >= NP || srow >= 16u * (unsigned)nj2) continue;
                     const unsigned idx = EPI == EPI_FWD ? (set ? po.c2 + po.cs * p2(pair) : po.c1 + po.cs * pair) : (set ? n - 1 - pair : pair);
                     if (EPI == EPI_FWD && (set ? (pair < po.p2lo || !second_out) : pair >= po.np1)) continue;
                     put_quad(idx, v);
@@ -1364,15 +1371,17 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
     using J3 = std::integral_constant<int, 3>;
     using EVEN = std::integral_constant<bool, false>;
     using ODDK = std::integral_constant<bool, true>;
+    // (tiles of 48 pairs -- po.bn32 == 2 -- always run three pair tiles on the 4 x 1 grid, whatever their valid pair count)
+    const bool j3 = BM == 128 && (po.bn32 == 2 || (!COLS && NP - p0 <= 48));
     if (!SSW_GEMM_DMA_DEV && ((Kp / PBK) & 1u)) {             // (the DMA ring's loop takes any step count)
-        if (NP - p0 <= 16)                 run(std::integral_constant<int, BM / 64>{}, J1{}, ODDK{});
-        else if (NP - p0 <= 32 || po.bn32) run(std::integral_constant<int, BM / 64>{}, J2{}, ODDK{});
-        else if (!COLS && BM == 128 && NP - p0 <= 48) run(std::integral_constant<int, BM / 64>{}, J3{}, ODDK{});
+        if (NP - p0 <= 16 && po.bn32 != 2) run(std::integral_constant<int, BM / 64>{}, J1{}, ODDK{});
+        else if (po.bn32 != 2 && (NP - p0 <= 32 || po.bn32)) run(std::integral_constant<int, BM / 64>{}, J2{}, ODDK{});
+        else if (j3)                       run(std::integral_constant<int, BM / 64>{}, J3{}, ODDK{});
         else                               run(std::integral_constant<int, BM / 32>{}, J2{}, ODDK{});
     } else {
-        if (NP - p0 <= 16)                 run(std::integral_constant<int, BM / 64>{}, J1{}, EVEN{});
-        else if (NP - p0 <= 32 || po.bn32) run(std::integral_constant<int, BM / 64>{}, J2{}, EVEN{});
-        else if (!COLS && BM == 128 && NP - p0 <= 48) run(std::integral_constant<int, BM / 64>{}, J3{}, EVEN{});
+        if (NP - p0 <= 16 && po.bn32 != 2) run(std::integral_constant<int, BM / 64>{}, J1{}, EVEN{});
+        else if (po.bn32 != 2 && (NP - p0 <= 32 || po.bn32)) run(std::integral_constant<int, BM / 64>{}, J2{}, EVEN{});
+        else if (j3)                       run(std::integral_constant<int, BM / 64>{}, J3{}, EVEN{});
         else                               run(std::integral_constant<int, BM / 32>{}, J2{}, EVEN{});
     }
 }

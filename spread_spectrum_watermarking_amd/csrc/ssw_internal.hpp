@@ -162,7 +162,7 @@ bool dct_pair_can_split(size_t len, bool is_row);
 size_t dct_pair_split_kpad(size_t len);
 // tuning.hip: the process-wide table of strategy thresholds / A-B switches (ssw_tuning_set, include/ssw.h)
 enum { TUNE_EFOLD_MIN, TUNE_EFOLD_INV_MIN, TUNE_EFOLD_COLS_MIN, TUNE_CLASS_TILE, TUNE_DEEP_MIN_ROWS, TUNE_DEEP_MIN_COLS, TUNE_PREP_STAGED,
-       TUNE_MERGE_MAX_LINES, TUNE_BN32, TUNE_BAND_SPLIT, TUNE_FUSE_COLS, TUNE_FUSE_INV_COLS, TUNE_UPLOAD_BANDS, TUNE_SPECULATE_K, TUNE_PREP_LIGHT, TUNE_LANE_STAGGER, TUNE_DERIVED_FUSED, TUNE_INV_PREP_LIGHT, TUNE_GEMM_STAGGER, TUNE_GEMM_GROUP_M, TUNE_GEMM_GROUP_M_ROWS, TUNE_MERGE_BATCH, TUNE_COUNT };
+       TUNE_MERGE_MAX_LINES, TUNE_BN32, TUNE_BAND_SPLIT, TUNE_FUSE_COLS, TUNE_FUSE_INV_COLS, TUNE_UPLOAD_BANDS, TUNE_SPECULATE_K, TUNE_PREP_LIGHT, TUNE_LANE_STAGGER, TUNE_DERIVED_FUSED, TUNE_INV_PREP_LIGHT, TUNE_GEMM_STAGGER, TUNE_GEMM_GROUP_M, TUNE_GEMM_GROUP_M_ROWS, TUNE_MERGE_BATCH, TUNE_TILE48, TUNE_COUNT };
 long long tuning(int which);
 unsigned dct_pair_class_tile(size_t len);               // tile width of the class-major plane orders (dct_pair_common.hpp)
 bool dct_pair_efold(size_t len);                        // forward row passes of this length run at level 2 (r4b)

@@ -44,6 +44,7 @@ Entry g_tune[TUNE_COUNT] = {
     {"gemm_group_m", "SSW_GEMM_GROUP_M", 4},           // column passes: tile rows per group of the GEMMs' block -> tile map (1: a line tile's tile columns are consecutive blocks)
     {"gemm_group_m_rows", "SSW_GEMM_GROUP_M_ROWS", 4}, // row passes: the same (r6: 1 cuts a fused row launch's PMC FETCH_SIZE from 1.95 to 1.29 GB and costs 2.8 % of the row stage)
     {"merge_batch", "SSW_MERGE_BATCH", 0},             // r6 A/B: a batch pass's independent launches as one, class after class (PairMulti::cls_major)
+    {"tile48", "SSW_TILE48", 1},                       // r6: 48-pair tiles for classes whose 64-pair tiling ends in a tile of <= 16 pairs (135 = 48 + 48 + 39)
 };
 
 // value and state change together under this lock (first read from the environment, set, reset); the fast path of a reader

@@ -121,10 +121,12 @@ def test_gemm_ring_reproduces_the_register_staged_kernels_planes_bit_for_bit():
 
 def test_gemm_tile_order_and_stagger_knobs_choose_between_equal_results():
     """ssw_tuning_set names of r6 (gemm_group_m, gemm_group_m_rows: tile rows per group of the block -> tile map; gemm_stagger:
-    a launch-time offset for the CUs' second resident blocks) are A/B switches of the schedule: the digests stay the same."""
+    a launch-time offset for the CUs' second resident blocks; merge_batch: a batch pass's launches as one, class after class; tile48: 135 pairs as 48 + 48 + 39 or 64 + 64 + 7)
+    are A/B switches of the schedule: the digests stay the same."""
     import lib_ab_check
     base = lib_ab_check.digests()
-    for env in ({"SSW_GEMM_GROUP_M_ROWS": "1", "SSW_GEMM_GROUP_M": "16"}, {"SSW_GEMM_STAGGER": "2", "SSW_GEMM_GROUP_M_ROWS": "16"}):
+    for env in ({"SSW_GEMM_GROUP_M_ROWS": "1", "SSW_GEMM_GROUP_M": "16"}, {"SSW_GEMM_STAGGER": "2", "SSW_GEMM_GROUP_M_ROWS": "16"},
+                {"SSW_MERGE_BATCH": "1", "SSW_TILE48": "0"}):
         assert lib_ab_check.digests(env=env) == base, env
 
 
