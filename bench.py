@@ -71,8 +71,8 @@ def count_gpus_sysfs(nodes: str = "/sys/class/kfd/kfd/topology/nodes", dri: str 
                         break
         except (OSError, ValueError):
             pass
-    if n == 0:
-        n = len(glob.glob(os.path.join(dri, "renderD*")))
+    render = len(glob.glob(os.path.join(dri, "renderD*")))        # what the container's device cgroup lets through
+    n = render if n == 0 else (min(n, render) if render else n)
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:

@@ -86,6 +86,12 @@ def test_launcher_counts_gpus_from_sysfs_without_a_hip_call(tmp_path, monkeypatc
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
     assert bench.count_gpus_sysfs(str(nodes), str(dri)) == 2
     monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    # a container that sees fewer render nodes than the host's topology lists (device cgroup): the smaller count
+    (dri / "renderD128").write_text("")
+    (dri / "renderD129").write_text("")
+    assert bench.count_gpus_sysfs(str(nodes), str(dri)) == 2
+    (dri / "renderD129").unlink()
+    (dri / "renderD128").unlink()
     # no KFD topology (container without the driver's sysfs): render nodes as the fallback, none -> 0 -> the launcher refuses
     empty = tmp_path / "none"
     empty.mkdir()
