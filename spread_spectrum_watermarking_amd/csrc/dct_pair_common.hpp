@@ -7,6 +7,7 @@ namespace ssw {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 template <typename T> using vec4_t = T __attribute__((ext_vector_type(4)));
 template <typename T> using vec2_t = T __attribute__((ext_vector_type(2)));
 
@@ -239,26 +240,34 @@ __device__ inline float pair_round255(float c) {
     const float x = c * 255.0f;
     return x < 0.5f ? 0.0f : floorf(x + 0.5f);
 }
-template <typename T>
-__device__ inline void pair_store_rgb_quad(const PairOutT<T>& po, size_t px, const float (&y)[4]) {
-    const f32x4 iv = *reinterpret_cast<const f32x4*>(po.iq_i + px);
-    const f32x4 qv = *reinterpret_cast<const f32x4*>(po.iq_q + px);
-    float c[12];
+// the twelve clamped channel values of a quad (yiq.rs:187-197: (y + m1 i) + m2 q per channel, clamped to [0, 1])
+__device__ inline void pair_rgb_of_quad(const float (&y)[4], const f32x4& iv, const f32x4& qv, float (&c)[12]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         c[3 * t + 0] = pair_clamp01_med3(1.0f * y[t] + 0.948262f * iv[t] + 0.624013f * qv[t]);
         c[3 * t + 1] = pair_clamp01_med3(1.0f * y[t] + -0.276066f * iv[t] + -0.639810f * qv[t]);
         c[3 * t + 2] = pair_clamp01_med3(1.0f * y[t] + -1.105450f * iv[t] + 1.729860f * qv[t]);
     }
+}
+// ... as the three dwords of a quad of 8-bit pixels (into_rgb8)
+__device__ inline void pair_rgb8_words(const float (&c)[12], unsigned (&w)[3]) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v = __builtin_amdgcn_cvt_pk_u8_f32(pair_round255(c[4 * d + b]), b, v);   // exact: integer-valued
+        w[d] = v;
+    }
+}
+template <typename T>
+__device__ inline void pair_store_rgb_quad(const PairOutT<T>& po, size_t px, const float (&y)[4]) {
+    const f32x4 iv = *reinterpret_cast<const f32x4*>(po.iq_i + px);
+    const f32x4 qv = *reinterpret_cast<const f32x4*>(po.iq_q + px);
+    float c[12];
+    pair_rgb_of_quad(y, iv, qv, c);
     if (po.rgb_u8) {
         unsigned w[3];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            unsigned v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) v = __builtin_amdgcn_cvt_pk_u8_f32(pair_round255(c[4 * d + b]), b, v);   // exact: integer-valued
-            w[d] = v;
-        }
+        pair_rgb8_words(c, w);
         unsigned* o = reinterpret_cast<unsigned*>(static_cast<uint8_t*>(po.rgb) + 3 * px);
         o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
     } else {

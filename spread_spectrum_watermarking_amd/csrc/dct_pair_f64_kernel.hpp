@@ -46,6 +46,9 @@
 #endif
 // (the host pass never generates code for a kernel body, but it does check it: the LDS-DMA builtins and the s_waitcnt statements
 // made it drop the kernels' launch stubs without a word -- the host sees the register-staged body)
+#ifndef SSW_RGB_NB
+#define SSW_RGB_NB 2           // output rows whose I / Q quads the RGB epilogue keeps in flight together (4: a spill in the loop at 256 VGPRs)
+#endif
 #ifndef SSW_GEMM_NS
 #define SSW_GEMM_NS 2          // stages of the ring.  2: 48 KB of LDS per block, like the register-staged kernel, one k-step ahead; 3: 72 KB, two ahead -- measured equal (r6: rows 56.2-56.9 vs 56.4-56.5 ms, columns 43.5-43.7 vs 43.5-43.9 per 256 4K frames), so the smaller one
 #endif
@@ -1255,6 +1258,18 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
             // EPI_INV_O / EPI_INV_O_RGB: x[n1] = E[n1] + a1, x[n-1-n1] = E[n1] - a1, x[n2] = E[n2] + a2, x[n-1-n2] = E[n2] - a2
             // (n1 = pair, n2 = pair + n/4); a round = 16 pairs: the "+" rows in staging rows 0..15, the "-" rows in 16..31
             const double* tpl = po.tmp + (size_t)z * (n / 2) * W + (m0 + wm - z * W);      // + row * W + 16 i + li, own frame only
+            // EPI_INV_O_RGB: frame of the tile's first line; `rgb_fast`: the tile's last line lies in it too
+            // (the divisions run on the vector unit: without the readfirstlane the resources count as divergent and every access
+            // through them is wrapped in a waterfall loop)
+            const unsigned z0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(m0 / W)), mlast = (m0 + BM <= L ? m0 + BM : L) - 1;
+            const bool rgb_fast = EPI == EPI_INV_O_RGB && __builtin_amdgcn_readfirstlane((int)(mlast / W)) == (int)z0 &&
+                                  (unsigned long long)H * W * 12ull < 0x20000000ull * 3ull;
+            const size_t fpx = (size_t)z0 * H * W;
+            const unsigned fbytes = H * W;
+            const __amdgpu_buffer_rsrc_t rgb_i = __builtin_amdgcn_make_buffer_rsrc((void*)(po.iq_i ? po.iq_i + fpx : po.out), 0, rgb_fast ? fbytes * 4u : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rgb_q = __builtin_amdgcn_make_buffer_rsrc((void*)(po.iq_q ? po.iq_q + fpx : po.out), 0, rgb_fast ? fbytes * 4u : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rgb_o = __builtin_amdgcn_make_buffer_rsrc(
+                po.rgb ? (void*)(static_cast<char*>(po.rgb) + fpx * (po.rgb_u8 ? 3u : 12u)) : (void*)po.out, 0, rgb_fast ? fbytes * (po.rgb_u8 ? 3u : 12u) : 0u, 0x00020000);
 #pragma unroll
             for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -1284,6 +1299,61 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                             tw[wr0 + (16 + 4 * r) * TPF + 16 * i] = (float)(e[i][r] - a);
                         }
                     lds_order();
+                    if constexpr (EPI == EPI_INV_O_RGB) {
+                        // r6: the tile's lines lie in one frame (block-uniform: W % BM == 0 for every frame size of the 4K / 8K / 1080p
+                        // paths): I, Q and the pixels through buffer resources of that frame, a lane outside the tile or the class
+                        // at an offset behind the range -- no branch around a load or a store, so the compiler counts its waits and
+                        // the I / Q quads of four output rows are in flight together (with the branches every quad was its own
+                        // load -> wait -> store chain: `vmcnt(1)`, `vmcnt(0)` per quad in the ISA, the previous quad's stores included)
+                        if (rgb_fast) {
+                            // (one copy of the round per pixel format: a format branch inside it would leave the number of stores
+                            // between two waits open, and the compiler would wait for the previous quad's stores as well)
+                            auto rgb_round = [&](auto u8c) {
+                            constexpr bool U8 = decltype(u8c)::value;
+                            constexpr int NB = NRI < SSW_RGB_NB ? NRI : SSW_RGB_NB;
+#pragma unroll
+                            for (int tb = 0; tb < NRI; tb += NB) {
+                                unsigned off[NB];
+                                float fac[NB];
+                                f32x4 v[NB], iv[NB], qv[NB];
+#pragma unroll
+                                for (int u = 0; u < NB; ++u) {
+                                    const int t = tb + u;
+                                    const unsigned srow = t * RPI + rrow;
+                                    const unsigned pair = p0 + wn + 16 * jn + (srow & 15);
+                                    v[u] = *reinterpret_cast<const f32x4*>(trd + t * RPI * TPF);
+                                    const unsigned pc = pair < NP ? pair : 0;
+                                    const unsigned nn = half ? po.c2 + po.cs * p2(pc) : po.c1 + po.cs * pc;
+                                    const bool ok = line_ok && pair < NP && nn < n / 2;
+                                    const unsigned idx = srow < 16 ? nn : n - 1 - nn;
+                                    off[u] = ok ? idx * W + col : 0x20000000u;             // pixels; x 4 / x 12 / x 3 bytes stays behind every range
+                                    fac[u] = idx == 0 ? ep.first : ep.base;
+                                    iv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgb_i, off[u] * 4u, 0, 0));
+                                    qv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgb_q, off[u] * 4u, 0, 0));
+                                }
+#pragma unroll
+                                for (int u = 0; u < NB; ++u) {
+                                    float y[4], c[12];
+#pragma unroll
+                                    for (int e4 = 0; e4 < 4; ++e4) y[e4] = plain ? v[u][e4] : v[u][e4] * fac[u];
+                                    pair_rgb_of_quad(y, iv[u], qv[u], c);
+                                    if (U8) {
+                                        unsigned w3[3];
+                                        pair_rgb8_words(c, w3);
+                                        __builtin_amdgcn_raw_buffer_store_b96((u32x3){w3[0], w3[1], w3[2]}, rgb_o, off[u] * 3u, 0, 0);
+                                    } else {
+#pragma unroll
+                                        for (int d = 0; d < 3; ++d)
+                                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, (f32x4){c[4 * d], c[4 * d + 1], c[4 * d + 2], c[4 * d + 3]}),
+                                                                                   rgb_o, off[u] * 12u + 16u * d, 0, 0);
+                                    }
+                                }
+                            }
+                            };
+                            if (po.rgb_u8) rgb_round(std::true_type{}); else rgb_round(std::false_type{});
+                            continue;
+                        }
+                    }
 #pragma unroll
                     for (int t = 0; t < NRI; ++t) {
                         const unsigned srow = t * RPI + rrow;                        // staging row: [0, 16) plus, [16, 32) minus
