@@ -983,9 +983,9 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                     const u32x2 raw = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
                     __builtin_amdgcn_raw_buffer_store_b64(raw, trr, voff, soff, 0);
                 };
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    double e[4][NJ][2];
+                // r6: the T2 values of line tile i + 1 are requested BEFORE the stores of line tile i (loads and stores through
+                // buffer resources keep their program order: behind the stores, every line tile was a load -> wait -> store chain)
+                auto load_e = [&](int i, double (&e)[4][NJ][2]) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const unsigned soff = (swm + 16 * i + 4 * r) * (n / 2) * 8u;
@@ -997,6 +997,13 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                                 e[r][jn][h2] = __hiloint2double((int)raw[1], (int)raw[0]);
                             }
                     }
+                };
+                double ea[4][NJ][2], eb[4][NJ][2];
+                load_e(0, ea);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    double (&e)[4][NJ][2] = (i & 1) ? eb : ea;
+                    if (i + 1 < NI) load_e(i + 1, (i & 1) ? ea : eb);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const unsigned soff = (swm + 16 * i + 4 * r) * n * 8u;
@@ -1028,9 +1035,7 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                         fp[jn][h2] = nn == 0 ? ep.first : ep.base;
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    double e[4][NJ][2];
+                auto load_e = [&](int i, double (&e)[4][NJ][2]) {                 // (one line tile ahead of the stores, as above)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const unsigned soff = (swm + 16 * i + 4 * r) * (n / 2) * 8u;
@@ -1042,6 +1047,13 @@ __global__ __launch_bounds__(PT, 2) void pair_gemm_f64_kernel(const PairMulti ml
                                 e[r][jn][h2] = __hiloint2double((int)raw[1], (int)raw[0]);
                             }
                     }
+                };
+                double ea[4][NJ][2], eb[4][NJ][2];
+                load_e(0, ea);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    double (&e)[4][NJ][2] = (i & 1) ? eb : ea;
+                    if (i + 1 < NI) load_e(i + 1, (i & 1) ? ea : eb);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const unsigned soff = (swm + 16 * i + 4 * r) * W * 4u;
